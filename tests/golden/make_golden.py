@@ -1,0 +1,130 @@
+"""tests/golden/make_golden.py -- records golden vectors FROM THE REFERENCE (build container only).
+
+    python tests/golden/make_golden.py [softras] [render] [corr] [vit] [losses] [step]
+
+Each generator runs the reference's own code (imported from /root/reference through the stubs in
+ref_harness.py; its SoftRas kernel bodies host-compiled unchanged) on seeded synthetic inputs and
+writes inputs + expected outputs to tests/golden/*.npz.  Only the .npz files travel to the GPU box;
+this script, ref_harness.py and ref_shim.* cannot run there.  See SURVEY.md section 8(c), G1-G7.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import ref_harness  # noqa: E402
+import scenes  # noqa: E402
+
+# the four SoftRenderer configurations of model/module/renderer.py:13-26
+RENDER_PASSES = {
+    "mask":    dict(sigma_val=1e-4, gamma_val=1e-4, aggr_func_rgb="hard",    bg=(0, 0, 0), texture_type="surface"),
+    "depth":   dict(sigma_val=1e-4, gamma_val=1e-4, aggr_func_rgb="softmax", bg=(1, 1, 1), texture_type="vertex"),
+    "softtex": dict(sigma_val=1e-3, gamma_val=1e-2, aggr_func_rgb="softmax", bg=(1, 1, 1), texture_type="vertex"),
+    "hardtex": dict(sigma_val=1e-4, gamma_val=1e-3, aggr_func_rgb="hard",    bg=(0, 0, 0), texture_type="vertex"),
+}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %-40s %8.1f KB" % (os.path.basename(path), os.path.getsize(path) / 1024.0))
+
+
+def _ref_rasterize(fv, ftex, size, cfg, grad, **extra):
+    """Run the reference SoftRasterizeFunction (functional/soft_rasterize.py:9-102) fwd + bwd."""
+    import soft_renderer.functional as srf
+    fv_t = torch.tensor(fv).requires_grad_(True)
+    tex_t = torch.tensor(ftex).requires_grad_(True)
+    kw = dict(image_size=size, background_color=list(cfg["bg"]), near=1, far=100, fill_back=True,
+              eps=1e-3, sigma_val=cfg["sigma_val"], dist_func="euclidean", dist_eps=1e-4,
+              gamma_val=cfg["gamma_val"], aggr_func_rgb=cfg["aggr_func_rgb"],
+              aggr_func_alpha="prod", texture_type=cfg["texture_type"])
+    kw.update(extra)
+    saved = {}
+    native = sys.modules["soft_renderer.cuda.soft_rasterize"]
+    orig = native.forward_soft_rasterize
+
+    def spy(*a):
+        out = orig(*a)
+        saved["faces_info"] = out[0].clone().numpy()
+        saved["aggrs_info"] = out[1].clone().numpy()
+        return out
+
+    native.forward_soft_rasterize = spy
+    try:
+        img = srf.soft_rasterize(fv_t.reshape(fv.shape[0], fv.shape[1], 9), tex_t, **kw)
+    finally:
+        native.forward_soft_rasterize = orig
+    img.backward(torch.tensor(grad))
+    return dict(soft_colors=img.detach().numpy(), grad_faces=fv_t.grad.numpy().reshape(fv.shape[0], -1, 9),
+                grad_textures=tex_t.grad.numpy(), **saved)
+
+
+def gen_softras():
+    """G1: every renderer configuration on (a) an octahedron @64^2, (b) the reference's 642-vert /
+    1280-face bottle prior @128^2, (c) its 995/1986 laptop prior @256^2 (mask + depth only), plus
+    the rasteriser modes the repo does not use (hard/barycentric distance, sum/hard alpha,
+    surface textures with R=2) on the octahedron."""
+    ref_harness.install()
+    cases = []
+    ov, of = scenes.octahedron()
+    bv, bf = ref_harness.read_obj(ref_harness.REF + "/config/bottle_wild6d/bottle.obj")
+    lv, lf = ref_harness.read_obj(ref_harness.REF + "/config/laptop_wild6d/laptop.obj")
+    for v in (bv, lv):
+        v -= v.mean(0)
+        v /= np.abs(v).max()
+    cases.append(("octa64", ov * 0.9, of, 64, 2, list(RENDER_PASSES)))
+    cases.append(("bottle128", bv, bf, 128, 2, list(RENDER_PASSES)))
+    cases.append(("laptop256", lv, lf, 256, 1, ["mask", "depth", "softtex"]))
+    for tag, v, f, size, n, passes in cases:
+        for pi, pname in enumerate(passes):
+            cfg = RENDER_PASSES[pname]
+            texkind = {"mask": "ones", "depth": "depth", "softtex": "rand", "hardtex": "canon"}[pname]
+            fv, ftex = scenes.raster_inputs(v, f, n, seed=100 + pi, tex="rand" if texkind == "ones" else texkind)
+            if texkind == "ones":
+                ftex = np.ones((n, f.shape[0], 1, 3), np.float32)
+            rng = np.random.default_rng(7 + pi)
+            grad_q = rng.integers(-16, 17, (n, 4, size, size)).astype(np.int8)  # grad = q / 8
+            grad = grad_q.astype(np.float32) / 8
+            out = _ref_rasterize(fv, ftex, size, cfg, grad)
+            save("softras_%s_%s" % (tag, pname), face_vertices=fv, face_textures=ftex,
+                 grad_soft_colors_q8=grad_q, image_size=size, sigma_val=cfg["sigma_val"],
+                 gamma_val=cfg["gamma_val"], aggr_func_rgb=cfg["aggr_func_rgb"],
+                 background_color=np.asarray(cfg["bg"], np.float32), texture_type=cfg["texture_type"],
+                 dist_func="euclidean", aggr_func_alpha="prod", **out)
+    # unused-by-the-repo modes, octahedron only
+    extra_modes = [
+        ("hard_dist", dict(dist_func="hard"), "softmax", "vertex"),
+        ("bary_dist", dict(dist_func="barycentric"), "softmax", "vertex"),
+        ("sum_alpha", dict(aggr_func_alpha="sum"), "softmax", "vertex"),
+        ("hard_alpha", dict(aggr_func_alpha="hard"), "hard", "vertex"),
+        ("surface_r2", dict(), "softmax", "surface"),
+    ]
+    for mi, (tag, extra, rgb, ttype) in enumerate(extra_modes):
+        cfg = dict(sigma_val=3e-4, gamma_val=1e-2, aggr_func_rgb=rgb, bg=(0.2, 0.4, 0.6), texture_type=ttype)
+        fv, ftex = scenes.raster_inputs(ov * 0.9, of, 2, seed=300 + mi)
+        if ttype == "surface":
+            ftex = np.random.default_rng(5).uniform(0, 1, (2, of.shape[0], 4, 3)).astype(np.float32)
+        grad_q = np.random.default_rng(40 + mi).integers(-16, 17, (2, 4, 64, 64)).astype(np.int8)
+        grad = grad_q.astype(np.float32) / 8
+        out = _ref_rasterize(fv, ftex, 64, cfg, grad, **extra)
+        save("softras_octa64_%s" % tag, face_vertices=fv, face_textures=ftex, grad_soft_colors_q8=grad_q,
+             image_size=64, sigma_val=cfg["sigma_val"], gamma_val=cfg["gamma_val"], aggr_func_rgb=rgb,
+             background_color=np.asarray(cfg["bg"], np.float32), texture_type=ttype,
+             dist_func=extra.get("dist_func", "euclidean"),
+             aggr_func_alpha=extra.get("aggr_func_alpha", "prod"), **out)
+
+
+GENERATORS = {"softras": gen_softras}
+
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or list(GENERATORS)
+    for name in todo:
+        GENERATORS[name]()
