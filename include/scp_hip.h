@@ -1,0 +1,82 @@
+/*
+ * include/scp_hip.h -- C ABI of libscp_hip.so, the MI355X (gfx950) hot-path library.
+ *
+ * Plain C: device pointers, sizes, scalars and a HIP stream handle; no torch types.  Every entry
+ * point returns 0 on success or a hipError_t value (scp_last_error() gives the text).  All buffers
+ * are caller-owned device memory; nothing is allocated or retained by the library unless stated.
+ * `stream` is a hipStream_t (NULL = the null stream); launches are asynchronous on it.
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout):
+ *   third-party/softras/soft_renderer/cuda/soft_rasterize_cuda.cpp:59-91,135-138
+ *       forward_soft_rasterize(...)   -> scp_soft_rasterize_forward
+ *   third-party/softras/soft_renderer/cuda/soft_rasterize_cuda.cpp:94-132,135-138
+ *       backward_soft_rasterize(...)  -> scp_soft_rasterize_backward
+ * The reference-side binding a maintainer adds is shown in INTEGRATION.md.
+ */
+#ifndef SCP_HIP_H
+#define SCP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCP_ABI_VERSION 1
+
+/* enum values = the integer ids the reference passes (functional/soft_rasterize.py:22-25) */
+enum { SCP_DIST_HARD = 0, SCP_DIST_BARYCENTRIC = 1, SCP_DIST_EUCLIDEAN = 2 };
+enum { SCP_RGB_HARD = 0, SCP_RGB_SOFTMAX = 1 };
+enum { SCP_ALPHA_HARD = 0, SCP_ALPHA_SUM = 1, SCP_ALPHA_PROD = 2 };
+enum { SCP_SAMPLE_SURFACE = 0, SCP_SAMPLE_VERTEX = 1 };
+
+/* The 12 scalars of forward/backward_soft_rasterize (cpp:59-76) plus the three sizes the
+ * reference derives from tensor shapes (kernel.cu:693-696).  `dist_eps` arrives ALREADY
+ * transformed to log(1/eps - 1), as in the reference (soft_rasterize.py:35). */
+typedef struct scp_raster_params {
+    int batch_size;           /* faces.size(0) */
+    int num_faces;            /* faces.size(1) */
+    int image_size;
+    int texture_size;         /* textures.size(2); texture_res = (int)sqrt(texture_size) */
+    float near_;
+    float far_;
+    float eps;
+    float sigma_val;
+    int func_id_dist;
+    float dist_eps;
+    float gamma_val;
+    int func_id_rgb;
+    int func_id_alpha;
+    int texture_sample_type;
+    int double_side;
+} scp_raster_params;
+
+int scp_abi_version(void);
+const char* scp_last_error(void);
+
+/* Replaces forward_soft_rasterize (cpp:59-91).
+ *   faces        [B,F,9]   in   (x_ndc, y_ndc up, z) per corner
+ *   textures     [B,F,T,3] in
+ *   faces_info   [B,F,27]  out  caller-zeroed; inverse(9) | gram+1(9) | obtuse flag(3) | 0(6)
+ *   aggrs_info   [B,2,S,S] out  softmax: (sum,max); hard: (z_min, face index as float)
+ *   soft_colors  [B,4,S,S] i/o  caller pre-fills background RGB and alpha=1 (soft_rasterize.py:51-54) */
+int scp_soft_rasterize_forward(const float* faces, const float* textures, float* faces_info,
+                               float* aggrs_info, float* soft_colors, const scp_raster_params* p,
+                               void* stream);
+
+/* Replaces backward_soft_rasterize (cpp:94-132).
+ *   grad_faces [B,F,9], grad_textures [B,F,T,3]: caller-zeroed, accumulated into.
+ *   grad_soft_colors [B,4,S,S] contiguous. */
+int scp_soft_rasterize_backward(const float* faces, const float* textures, const float* soft_colors,
+                                const float* faces_info, const float* aggrs_info, float* grad_faces,
+                                float* grad_textures, const float* grad_soft_colors,
+                                const scp_raster_params* p, void* stream);
+
+/* Instrumentation: number of (pixel, face) pairs that survive the reference's bbox test
+ * (kernel.cu:375) -- the `pairs_active` work unit of SURVEY.md 8(d).  `count` is one device
+ * uint64, caller-zeroed. */
+int scp_soft_rasterize_count_pairs(const float* faces, unsigned long long* count,
+                                   const scp_raster_params* p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCP_HIP_H */

@@ -164,6 +164,9 @@ static inline float bary_distance(const float *w)
 static inline float sample_texture(const float *tex, const float *w, int R, int k, int mode)
 {
     if (mode == 0) {
+        /* when a clipped weight is exactly 1 this indexes past the face's own R*R texels, into the
+           next face's texture -- reproduced as is; the caller guarantees the batch's last face is
+           never sampled that way (the reference reads out of bounds there) */
         const int wx = (int)(w[0] * R), wy = (int)(w[1] * R);
         if ((w[0] + w[1]) * R - wx - wy <= 1) return tex[(wy * R + wx) * 3 + k];
         return tex[((R - 1 - wy) * R + (R - 1 - wx)) * 3 + k];

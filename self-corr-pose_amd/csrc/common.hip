@@ -1,0 +1,24 @@
+// self-corr-pose_amd/csrc/common.hip -- ABI version + last-error string of libscp_hip.so.
+#include <cstdio>
+
+#include "scp_common.h"
+#include "scp_hip.h"
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+namespace scp {
+int fail(int code, const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(static_cast<hipError_t>(code)));
+    return code;
+}
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return 0;
+    return fail(static_cast<int>(e), what);
+}
+}  // namespace scp
+
+extern "C" int scp_abi_version(void) { return SCP_ABI_VERSION; }
+extern "C" const char* scp_last_error(void) { return g_err; }

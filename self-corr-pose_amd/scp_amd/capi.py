@@ -1,0 +1,80 @@
+"""scp_amd/capi.py -- ctypes binding of libscp_hip.so (C ABI: include/scp_hip.h).
+
+There is deliberately no fallback: if the library is missing or does not export a declared symbol
+the import of this module's `lib()` raises.  Tensors are passed as raw device pointers and the
+launch goes to torch's current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libscp_hip.so")
+ABI_VERSION = 1
+
+
+class RasterParams(ctypes.Structure):
+    """struct scp_raster_params"""
+    _fields_ = [
+        ("batch_size", ctypes.c_int), ("num_faces", ctypes.c_int), ("image_size", ctypes.c_int),
+        ("texture_size", ctypes.c_int),
+        ("near_", ctypes.c_float), ("far_", ctypes.c_float), ("eps", ctypes.c_float),
+        ("sigma_val", ctypes.c_float), ("func_id_dist", ctypes.c_int), ("dist_eps", ctypes.c_float),
+        ("gamma_val", ctypes.c_float), ("func_id_rgb", ctypes.c_int), ("func_id_alpha", ctypes.c_int),
+        ("texture_sample_type", ctypes.c_int), ("double_side", ctypes.c_int),
+    ]
+
+
+_P = ctypes.c_void_p
+_RP = ctypes.POINTER(RasterParams)
+
+# name -> (restype, argtypes); must list every symbol include/scp_hip.h declares
+SYMBOLS = {
+    "scp_abi_version": (ctypes.c_int, []),
+    "scp_last_error": (ctypes.c_char_p, []),
+    "scp_soft_rasterize_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _RP, _P]),
+    "scp_soft_rasterize_backward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _RP, _P]),
+    "scp_soft_rasterize_count_pairs": (ctypes.c_int, [_P, _P, _RP, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "scp_amd: %s is missing -- build it with `python self-corr-pose_amd/build.py` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if handle.scp_abi_version() != ABI_VERSION:
+            raise RuntimeError("scp_amd: libscp_hip.so ABI %d != expected %d" % (handle.scp_abi_version(), ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError("scp_amd: %s failed (hip error %d): %s" % (what, code, lib().scp_last_error().decode()))
+
+
+def current_stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev_ptr(t, name):
+    """raw device pointer of a contiguous fp32 CUDA tensor; the reference's CHECK_INPUT
+    (soft_rasterize_cuda.cpp:54-56) raises RuntimeError for CPU / non-contiguous tensors, so do we"""
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s must be float32 (the gfx950 kernels are fp32-only)" % name)
+    return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,138 @@
+"""scp_amd.soft_renderer.functional -- the `soft_renderer.functional` (srf) surface the hot path uses.
+
+Own implementation of the behaviour of (reference paths under third-party/softras/soft_renderer/):
+  functional/soft_rasterize.py:9-119   SoftRasterizeFunction / soft_rasterize
+  functional/face_vertices.py:4-22     face_vertices
+  functional/vertex_normals.py:4-36    vertex_normals
+  functional/look_at.py:6-62           look_at
+  functional/orthogonal.py:4-18        orthogonal
+  functional/perspective.py            perspective
+  functional/ambient_lighting.py, directional_lighting.py
+Texture atlas IO / voxelisation (load_obj, save_obj with textures, voxelization) are out of scope:
+the trainer never calls them.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from .cuda import soft_rasterize as _native
+
+DIST_IDS = {"hard": 0, "barycentric": 1, "euclidean": 2}
+RGB_IDS = {"hard": 0, "softmax": 1}
+ALPHA_IDS = {"hard": 0, "sum": 1, "prod": 2}
+SAMPLE_IDS = {"surface": 0, "vertex": 1}
+
+
+class SoftRasterizeFunction(Function):
+    """Autograd node around the native rasteriser; buffer protocol as in the reference
+    (caller allocates: soft_colors = background RGB + alpha 1, infos/grads = 0), but every
+    buffer is created directly on the device (the reference builds them on the host and copies,
+    soft_rasterize.py:47-53)."""
+
+    @staticmethod
+    def forward(ctx, face_vertices, textures, image_size=256, background_color=[0, 0, 0], near=1,
+                far=100, fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func="euclidean",
+                dist_eps=1e-4, gamma_val=1e-4, aggr_func_rgb="softmax", aggr_func_alpha="prod",
+                texture_type="surface"):
+        ctx.scalars = (int(image_size), float(near), float(far), float(eps), float(sigma_val),
+                       DIST_IDS[dist_func], float(np.log(1. / dist_eps - 1.)), float(gamma_val),
+                       RGB_IDS[aggr_func_rgb], ALPHA_IDS[aggr_func_alpha], SAMPLE_IDS[texture_type],
+                       bool(fill_back))
+        nb, nf = face_vertices.shape[:2]
+        fv = face_vertices.detach().reshape(nb, nf, 9).contiguous()
+        tex = textures.detach().reshape(nb, nf, -1, 3).contiguous()
+        dev = fv.device
+        faces_info = torch.zeros(nb, nf, 27, dtype=torch.float32, device=dev)
+        aggrs_info = torch.zeros(nb, 2, image_size, image_size, dtype=torch.float32, device=dev)
+        soft_colors = torch.ones(nb, 4, image_size, image_size, dtype=torch.float32, device=dev)
+        for k in range(3):
+            if background_color[k] != 1:
+                soft_colors[:, k].fill_(float(background_color[k]))
+        _native.forward_soft_rasterize(fv, tex, faces_info, aggrs_info, soft_colors, *ctx.scalars)
+        ctx.save_for_backward(fv, tex, soft_colors, faces_info, aggrs_info)
+        ctx.in_shapes = (face_vertices.shape, textures.shape)
+        return soft_colors
+
+    @staticmethod
+    def backward(ctx, grad_soft_colors):
+        fv, tex, soft_colors, faces_info, aggrs_info = ctx.saved_tensors
+        grad_faces = torch.zeros_like(fv)
+        grad_textures = torch.zeros_like(tex)
+        _native.backward_soft_rasterize(fv, tex, soft_colors, faces_info, aggrs_info, grad_faces,
+                                        grad_textures, grad_soft_colors.contiguous(), *ctx.scalars)
+        return (grad_faces.reshape(ctx.in_shapes[0]), grad_textures.reshape(ctx.in_shapes[1])) + (None,) * 13
+
+
+def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0, 0, 0], near=1,
+                   far=100, fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func="euclidean",
+                   dist_eps=1e-4, gamma_val=1e-4, aggr_func_rgb="softmax", aggr_func_alpha="prod",
+                   texture_type="surface"):
+    return SoftRasterizeFunction.apply(face_vertices, textures, image_size, background_color, near,
+                                       far, fill_back, eps, sigma_val, dist_func, dist_eps, gamma_val,
+                                       aggr_func_rgb, aggr_func_alpha, texture_type)
+
+
+def face_vertices(vertices, faces):
+    """[B,V,C], [B,F,3] -> [B,F,3,C]; backward is an index_put accumulate (autograd)."""
+    assert vertices.dim() == 3 and faces.dim() == 3 and vertices.shape[0] == faces.shape[0]
+    assert vertices.shape[2] == 3 and faces.shape[2] == 3
+    nb, nv = vertices.shape[:2]
+    flat = faces.long() + (torch.arange(nb, device=vertices.device) * nv)[:, None, None]
+    return vertices.reshape(nb * nv, 3)[flat]
+
+
+def vertex_normals(vertices, faces):
+    nb, nv = vertices.shape[:2]
+    fv = face_vertices(vertices, faces).reshape(-1, 3, 3)
+    flat = (faces.long() + (torch.arange(nb, device=vertices.device) * nv)[:, None, None]).reshape(-1, 3)
+    normals = torch.zeros(nb * nv, 3, device=vertices.device, dtype=vertices.dtype)
+    normals.index_add_(0, flat[:, 1], torch.cross(fv[:, 2] - fv[:, 1], fv[:, 0] - fv[:, 1], dim=1))
+    normals.index_add_(0, flat[:, 2], torch.cross(fv[:, 0] - fv[:, 2], fv[:, 1] - fv[:, 2], dim=1))
+    normals.index_add_(0, flat[:, 0], torch.cross(fv[:, 1] - fv[:, 0], fv[:, 2] - fv[:, 0], dim=1))
+    return F.normalize(normals, eps=1e-6, dim=1).reshape(nb, nv, 3)
+
+
+def _as_rows(x, nb, device):
+    x = torch.as_tensor(x, dtype=torch.float32, device=device)
+    return x[None].repeat(nb, 1) if x.dim() == 1 else x
+
+
+def look_at(vertices, eye, at=(0, 0, 0), up=(0, 1, 0)):
+    if vertices.dim() != 3:
+        raise ValueError("vertices Tensor should have 3 dimensions")
+    nb, dev = vertices.shape[0], vertices.device
+    eye, at, up = _as_rows(eye, nb, dev), _as_rows(at, nb, dev), _as_rows(up, nb, dev)
+    z_axis = F.normalize(at - eye, eps=1e-5)
+    x_axis = F.normalize(torch.cross(up, z_axis, dim=1), eps=1e-5)
+    y_axis = F.normalize(torch.cross(z_axis, x_axis, dim=1), eps=1e-5)
+    r = torch.stack((x_axis, y_axis, z_axis), dim=1)
+    return torch.matmul(vertices - eye[:, None, :], r.transpose(1, 2))
+
+
+def orthogonal(vertices, scale):
+    if vertices.dim() != 3:
+        raise ValueError("vertices Tensor should have 3 dimensions")
+    return torch.stack((vertices[:, :, 0] * scale, vertices[:, :, 1] * scale, vertices[:, :, 2]), dim=2)
+
+
+def perspective(vertices, angle=30.):
+    if vertices.dim() != 3:
+        raise ValueError("vertices Tensor should have 3 dimensions")
+    width = math.tan(math.radians(angle))
+    z = vertices[:, :, 2]
+    return torch.stack((vertices[:, :, 0] / z / width, vertices[:, :, 1] / z / width, z), dim=2)
+
+
+def ambient_lighting(light, light_intensity=0.5, light_color=(1, 1, 1)):
+    color = torch.as_tensor(light_color, dtype=torch.float32, device=light.device).reshape(1, 1, 3)
+    return light + light_intensity * color
+
+
+def directional_lighting(light, normals, light_intensity=0.5, light_color=(1, 1, 1), light_direction=(0, 1, 0)):
+    color = torch.as_tensor(light_color, dtype=torch.float32, device=light.device).reshape(1, 1, 3)
+    direction = torch.as_tensor(light_direction, dtype=torch.float32, device=light.device).reshape(1, 1, 3)
+    cosine = F.relu(torch.sum(normals * direction, dim=2))
+    return light + light_intensity * (color * cosine[:, :, None])

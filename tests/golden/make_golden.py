@@ -111,6 +111,10 @@ def gen_softras():
         fv, ftex = scenes.raster_inputs(ov * 0.9, of, 2, seed=300 + mi)
         if ttype == "surface":
             ftex = np.random.default_rng(5).uniform(0, 1, (2, of.shape[0], 4, 3)).astype(np.float32)
+            # the reference's surface sampler indexes one texel row past a face's texture when a
+            # clipped weight is exactly 1 (kernel.cu:182-185); for the very last face of the batch
+            # that is an out-of-bounds read.  Park that face off-screen so the fixture is defined.
+            fv[-1, -1, :, :2] = np.array([[5.0, 5.0], [5.01, 5.0], [5.0, 5.01]], np.float32)
         grad_q = np.random.default_rng(40 + mi).integers(-16, 17, (2, 4, 64, 64)).astype(np.int8)
         grad = grad_q.astype(np.float32) / 8
         out = _ref_rasterize(fv, ftex, 64, cfg, grad, **extra)

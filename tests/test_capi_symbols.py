@@ -1,0 +1,56 @@
+"""CPU-side checks of the drop-in boundary: libscp_hip.so loads and exports exactly what
+include/scp_hip.h declares; the Python binding lists the same symbols; no compute is launched."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "scp_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(scp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    syms = declared_symbols()
+    assert "scp_soft_rasterize_forward" in syms and "scp_soft_rasterize_backward" in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from scp_amd import capi
+    assert os.path.exists(capi.LIB_PATH), "build with python self-corr-pose_amd/build.py"
+    handle = ctypes.CDLL(capi.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(handle, name), name
+
+
+def test_binding_covers_header():
+    from scp_amd import capi
+    assert sorted(capi.SYMBOLS) == declared_symbols()
+    assert capi.lib().scp_abi_version() == capi.ABI_VERSION
+
+
+def test_product_path_fails_loudly_without_gpu_tensors():
+    """no CPU fallback: CPU tensors are rejected like the reference's CHECK_CUDA does"""
+    import torch
+    from scp_amd.soft_renderer import functional as srf
+    fv = torch.rand(1, 4, 3, 3)
+    tex = torch.rand(1, 4, 3, 3)
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    with pytest.raises(RuntimeError):
+        srf.soft_rasterize(fv, tex, 32, texture_type="vertex")
+
+
+def test_product_does_not_reference_the_oracle():
+    """the shipped package must not import or call anything under oracle/"""
+    pkg = os.path.join(ROOT, "self-corr-pose_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, os.path.join(dirpath, f)

@@ -1,0 +1,205 @@
+"""GPU parity of the HIP rasteriser (csrc/softras.hip through the C ABI) -- run with -m gpu.
+
+Comparators: (1) the committed golden vectors recorded from the reference kernels, (2) the CPU
+oracle on fresh seeded scenes, (3) size-independent properties at BASELINE.json's full size
+(B=32, 256^2, 642 verts / 1280 faces).
+
+Tolerances (north_star: 1e-4 relative fp32).  The HIP kernels keep the reference's evaluation order
+and fp64 promotions and are built with -ffp-contract=off, so forward differences can only come
+from the last ulp of expf (ocml vs glibc):
+  forward images / aggregates : |d| <= 2e-6 + 1e-5 |ref| on EVERY pixel (no pixel may flip)
+  faces_info                  : bit exact (no transcendental involved)
+  gradients                   : summation order differs (wavefront tree + atomics vs raster order):
+                                |d| <= 1e-4 * max|ref| element-wise and relative L2 <= 2e-5
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_io
+import scenes
+from oracle import softras as oracle
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def hip_render(fv, ftex, grad=None, **kw):
+    """product path: autograd Function -> native boundary -> HIP kernels"""
+    from scp_amd.soft_renderer import functional as srf
+    from scp_amd.soft_renderer.cuda import soft_rasterize as native
+    assert "scp_amd" in native.__name__
+    captured = {}
+    orig = native.forward_soft_rasterize
+
+    def spy(*a):
+        out = orig(*a)
+        captured["faces_info"], captured["aggrs_info"] = out[0], out[1]
+        return out
+
+    native.forward_soft_rasterize = spy
+    try:
+        fv_t = torch.tensor(fv, device=DEV, requires_grad=True)
+        tex_t = torch.tensor(ftex, device=DEV, requires_grad=True)
+        img = srf.soft_rasterize(fv_t, tex_t, **kw)
+    finally:
+        native.forward_soft_rasterize = orig
+    out = {"soft_colors": img.detach().cpu().numpy(),
+           "faces_info": captured["faces_info"].cpu().numpy(),
+           "aggrs_info": captured["aggrs_info"].cpu().numpy()}
+    if grad is not None:
+        img.backward(torch.tensor(grad, device=DEV))
+        out["grad_faces"] = fv_t.grad.cpu().numpy().reshape(fv.shape[0], -1, 9)
+        out["grad_textures"] = tex_t.grad.cpu().numpy()
+    return out
+
+
+def assert_forward_close(got, ref):
+    np.testing.assert_array_equal(got["faces_info"], ref["faces_info"])
+    for key in ("soft_colors", "aggrs_info"):
+        d = np.abs(got[key].astype(np.float64) - ref[key])
+        tol = 2e-6 + 1e-5 * np.abs(ref[key])
+        bad = d > tol
+        assert not bad.any(), "%s: %d px out of tolerance, max abs diff %.3e" % (key, bad.sum(), d.max())
+
+
+def assert_grad_close(got, ref, key):
+    g, r = got[key].astype(np.float64).ravel(), ref[key].astype(np.float64).ravel()
+    scale = np.abs(r).max()
+    if scale == 0:
+        assert np.abs(g).max() == 0
+        return
+    assert np.abs(g - r).max() <= 1e-4 * scale, "%s max abs diff %.3e vs scale %.3e" % (key, np.abs(g - r).max(), scale)
+    assert np.linalg.norm(g - r) <= 2e-5 * np.linalg.norm(r), "%s rel L2 %.3e" % (key, np.linalg.norm(g - r) / np.linalg.norm(r))
+
+
+@pytest.mark.parametrize("case", golden_io.softras_cases())
+def test_hip_matches_reference_golden(case):
+    d = golden_io.load(case)
+    got = hip_render(d["face_vertices"], d["face_textures"], d["grad_soft_colors"], **golden_io.softras_kwargs(d))
+    ref = dict(d)
+    ref["grad_textures"] = d["grad_textures"].reshape(got["grad_textures"].shape)
+    assert_forward_close(got, ref)
+    assert_grad_close(got, ref, "grad_faces")
+    assert_grad_close(got, ref, "grad_textures")
+
+
+PASSES = {
+    "mask": dict(sigma_val=1e-4, gamma_val=1e-4, aggr_func_rgb="hard", background_color=[0, 0, 0], texture_type="surface"),
+    "depth": dict(sigma_val=1e-4, gamma_val=1e-4, aggr_func_rgb="softmax", background_color=[1, 1, 1], texture_type="vertex"),
+    "softtex": dict(sigma_val=1e-3, gamma_val=1e-2, aggr_func_rgb="softmax", background_color=[1, 1, 1], texture_type="vertex"),
+    "hardtex": dict(sigma_val=1e-4, gamma_val=1e-3, aggr_func_rgb="hard", background_color=[0, 0, 0], texture_type="vertex"),
+}
+
+
+@pytest.mark.parametrize("pname", list(PASSES))
+@pytest.mark.parametrize("size,subdiv,n", [(96, 2, 3), (250, 3, 2)])
+def test_hip_matches_oracle_fresh_scenes(pname, size, subdiv, n):
+    """sizes that are not multiples of the 16-px tile, other meshes, other seeds"""
+    v, f = scenes.bottle_like(subdiv)
+    texkind = {"mask": "rand", "depth": "depth", "softtex": "rand", "hardtex": "canon"}[pname]
+    fv, ftex = scenes.raster_inputs(v, f, n, seed=size + subdiv, tex=texkind)
+    if pname == "mask":
+        ftex = np.ones((n, f.shape[0], 1, 3), np.float32)
+    grad = np.random.default_rng(size).standard_normal((n, 4, size, size)).astype(np.float32)
+    kw = dict(image_size=size, dist_func="euclidean", aggr_func_alpha="prod", **PASSES[pname])
+    ref = oracle.render(fv, ftex, grad_soft_colors=grad, **kw)
+    got = hip_render(fv, ftex, grad, **kw)
+    assert_forward_close(got, ref)
+    assert_grad_close(got, ref, "grad_faces")
+    assert_grad_close(got, ref, "grad_textures")
+
+
+def test_ragged_and_empty_inputs():
+    from scp_amd.soft_renderer import functional as srf
+    # a single off-screen triangle: background everywhere, alpha exactly 0, zero gradients
+    fv = torch.tensor([[[[5., 5., 3.], [5.1, 5., 3.], [5., 5.1, 3.]]]], device=DEV, requires_grad=True)
+    tex = torch.ones(1, 1, 3, 3, device=DEV, requires_grad=True)
+    img = srf.soft_rasterize(fv, tex, 40, [0.25, 0.5, 0.75], sigma_val=1e-4, texture_type="vertex")
+    assert torch.equal(img[0, 3], torch.zeros(40, 40, device=DEV))
+    assert torch.allclose(img[0, :3].mean((1, 2)).cpu(), torch.tensor([0.25, 0.5, 0.75]))
+    img.sum().backward()
+    assert fv.grad.abs().max().item() == 0
+    # more faces than one binning list holds (LIST_CAP) all covering one tile, degenerate faces too
+    rng = np.random.default_rng(3)
+    n_f = 3000
+    tri = rng.uniform(-0.05, 0.05, (1, n_f, 3, 3)).astype(np.float32)
+    tri[..., 2] = rng.uniform(3, 6, (1, n_f, 3))
+    tri[0, 5] = tri[0, 5, :1]          # zero-area face
+    tri[0, 7, :, :2] = 0.0             # all corners identical in x,y
+    t = rng.uniform(0, 1, (1, n_f, 3, 3)).astype(np.float32)
+    grad = rng.standard_normal((1, 4, 48, 48)).astype(np.float32)
+    kw = dict(image_size=48, sigma_val=1e-4, gamma_val=1e-2, aggr_func_rgb="softmax", texture_type="vertex",
+              background_color=[1, 1, 1], dist_func="euclidean", aggr_func_alpha="prod")
+    ref = oracle.render(tri, t, grad_soft_colors=grad, **kw)
+    got = hip_render(tri, t, grad, **kw)
+    assert_forward_close(got, ref)
+    assert_grad_close(got, ref, "grad_faces")
+
+
+def test_native_boundary_rejects_bad_tensors():
+    from scp_amd.soft_renderer.cuda import soft_rasterize as native
+    fv = torch.rand(1, 2, 9)
+    with pytest.raises(RuntimeError):
+        native.forward_soft_rasterize(fv, fv, fv, fv, fv, 16, 1., 100., 1e-3, 1e-4, 2, 9.2, 1e-4, 1, 2, 1, True)
+    g = torch.rand(1, 2, 18, device=DEV)[:, :, ::2]
+    with pytest.raises(RuntimeError):
+        native.forward_soft_rasterize(g, g, g, g, g, 16, 1., 100., 1e-3, 1e-4, 2, 9.2, 1e-4, 1, 2, 1, True)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json full size: B=32, 256x256, 642 verts / 1280 faces
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full_scene():
+    v, f = scenes.bottle_like(3)
+    assert v.shape[0] == 642 and f.shape[0] == 1280
+    fv, ftex = scenes.raster_inputs(v, f, 32, seed=2024, tex="rand")
+    return fv, ftex
+
+
+def test_full_size_subset_against_oracle(full_scene):
+    fv, ftex = full_scene
+    grad = np.random.default_rng(1).standard_normal((32, 4, 256, 256)).astype(np.float32)
+    kw = dict(image_size=256, dist_func="euclidean", aggr_func_alpha="prod", **PASSES["softtex"])
+    got = hip_render(fv, ftex, grad, **kw)
+    pick = [0, 13, 31]
+    ref = oracle.render(fv[pick], ftex[pick], grad_soft_colors=grad[pick], **kw)
+    sub = {k: v[pick] for k, v in got.items()}
+    assert_forward_close(sub, ref)
+    assert_grad_close(sub, ref, "grad_faces")
+    assert_grad_close(sub, ref, "grad_textures")
+
+
+def test_full_size_properties(full_scene):
+    from scp_amd.soft_renderer import functional as srf
+    from scp_amd.soft_renderer.cuda import soft_rasterize as native
+    fv, ftex = full_scene
+    fv_t, tex_t = torch.tensor(fv, device=DEV), torch.tensor(ftex, device=DEV)
+    kw_d = dict(image_size=256, dist_func="euclidean", aggr_func_alpha="prod", **PASSES["depth"])
+    kw_m = dict(image_size=256, dist_func="euclidean", aggr_func_alpha="prod", **PASSES["mask"])
+    depth = srf.soft_rasterize(fv_t, tex_t, **kw_d)
+    mask = srf.soft_rasterize(fv_t, torch.ones(32, 1280, 1, 3, device=DEV), **kw_m)
+    # (1) alpha in [0,1]; the mask and depth passes share sigma -> identical alpha
+    assert depth[:, 3].min() >= 0 and depth[:, 3].max() <= 1
+    assert torch.equal(depth[:, 3], mask[:, 3])
+    # (2) batch-permutation equivariance, bit exact (checks tile -> image mapping at full grid size)
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(0)).to(DEV)
+    depth_p = srf.soft_rasterize(fv_t[perm], tex_t[perm], **kw_d)
+    assert torch.equal(depth_p, depth[perm])
+    # (3) run-to-run determinism of the forward
+    assert torch.equal(srf.soft_rasterize(fv_t, tex_t, **kw_d), depth)
+    # (4) backward is linear in the incoming gradient
+    fv_g = fv_t.clone().requires_grad_(True)
+    img = srf.soft_rasterize(fv_g, tex_t, **kw_d)
+    g1 = torch.randn(img.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(1))
+    g2 = torch.randn(img.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(2))
+    ga, = torch.autograd.grad(img, fv_g, g1, retain_graph=True)
+    gb, = torch.autograd.grad(img, fv_g, g2, retain_graph=True)
+    gc, = torch.autograd.grad(img, fv_g, g1 + 2 * g2)
+    assert torch.linalg.norm(gc - (ga + 2 * gb)) <= 1e-5 * torch.linalg.norm(gc)
+    # (5) the instrumentation kernel agrees with the oracle's pair count on a few images
+    n_gpu = native.count_pairs(fv_t[:3].reshape(3, 1280, 9).contiguous(), 256, 1e-4, float(np.log(1. / 1e-4 - 1.)))
+    n_cpu = oracle.count_pairs(np.ascontiguousarray(fv[:3].reshape(3, 1280, 9)), 256, 1e-4, float(np.log(1. / 1e-4 - 1.)))
+    assert n_gpu == n_cpu
