@@ -1,0 +1,170 @@
+"""scp_amd/dino.py -- frozen DINO ViT-S/8 key-feature extractor.
+
+Behaviour restated from model/module/network/dino.py (DINO :9-108: block-9 KEYS of a ViT-S/8,
+cls token dropped, channel = head*64 + d, output [n,384,32,32]; raw keys, not normalised; input not
+ImageNet-normalised -- SURVEY F6) and third-party/zsp/zsp/method/vision_transformer_flexible.py
+(PatchEmbed :134-149, interpolate_pos_encoding :192-212, prepare_tokens :214-225, Block :108-132,
+Attention :73-101, Mlp :54-70, get_specific_tokens :249-262, vit_small :283-287).
+
+MI355X-first differences, all output-preserving:
+  * only what the output depends on is computed: blocks 0-8 in full, then norm1 and the K slice of
+    block 9's qkv projection (the reference runs 12 blocks and materialises q,k,v and the
+    [n,6,1025,1025] attention of blocks 9 and 11) -- SURVEY F5;
+  * attention never materialises the score matrix (fused kernel), the bicubic-interpolated
+    positional embedding is computed once per input size and cached;
+  * callers pass each unique image once; there is no empty_cache()/chunking.
+The module tree and parameter names equal the DINO checkpoint's, so
+`pretrain/dino_deitsmall8_pretrain.pth` loads with strict=True and MeshNet's state_dict keys are
+`pretrain_corr_net.net.model.*` as in the reference.
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# the reference cannot be constructed without the checkpoint file (dino.py:40-44); synthetic-weight
+# runs (bench, tests) flip this on explicitly
+ALLOW_RANDOM_INIT = False
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        b, n, c = x.shape
+        qkv = self.qkv(x).reshape(b, n, 3, self.num_heads, c // self.num_heads).permute(2, 0, 3, 1, 4)
+        y = attention(qkv[0], qkv[1], qkv[2], self.scale)
+        return self.proj(y.transpose(1, 2).reshape(b, n, c))
+
+    def keys(self, x):
+        """only the K third of the qkv projection: [b, heads, n, d]"""
+        b, n, c = x.shape
+        k = F.linear(x, self.qkv.weight[c:2 * c], self.qkv.bias[c:2 * c])
+        return k.reshape(b, n, self.num_heads, c // self.num_heads).permute(0, 2, 1, 3)
+
+
+def attention(q, k, v, scale):
+    """softmax(q k^T * scale) v over [b, h, n, d] without materialising the [n, n] scores"""
+    return F.scaled_dot_product_attention(q, k, v, scale=scale)
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attention(dim, num_heads)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x):
+        x = x + self.attn(self.norm1(x))
+        return x + self.mlp(self.norm2(x))
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, patch_size, embed_dim, img_size=224):
+        super().__init__()
+        self.patch_size = patch_size
+        self.num_patches = (img_size // patch_size) ** 2
+        self.proj = nn.Conv2d(3, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, patch_size=8, embed_dim=384, depth=12, num_heads=6):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.patch_embed = _PatchEmbed(patch_size, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches + 1, embed_dim))
+        self.blocks = nn.ModuleList([_Block(embed_dim, num_heads) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+        nn.init.trunc_normal_(self.cls_token, std=.02)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=.02)
+                nn.init.zeros_(m.bias)
+        self._pos_cache = {}
+
+    def interpolate_pos_encoding(self, npatch, w, h):
+        n = self.pos_embed.shape[1] - 1
+        if npatch == n and w == h:
+            return self.pos_embed
+        key = (w, h, self.pos_embed.device, self.pos_embed._version)
+        if key not in self._pos_cache:
+            dim = self.pos_embed.shape[-1]
+            side = int(math.sqrt(n))
+            w0, h0 = w // self.patch_embed.patch_size + 0.1, h // self.patch_embed.patch_size + 0.1
+            grid = F.interpolate(self.pos_embed[:, 1:].reshape(1, side, side, dim).permute(0, 3, 1, 2),
+                                 scale_factor=(w0 / math.sqrt(n), h0 / math.sqrt(n)), mode="bicubic")
+            assert int(w0) == grid.shape[-2] and int(h0) == grid.shape[-1]
+            grid = grid.permute(0, 2, 3, 1).reshape(1, -1, dim)
+            self._pos_cache = {key: torch.cat((self.pos_embed[:, :1], grid), 1).detach()}
+        return self._pos_cache[key]
+
+    def prepare_tokens(self, x):
+        b, _, w, h = x.shape
+        tok = self.patch_embed(x)
+        tok = torch.cat((self.cls_token.expand(b, -1, -1), tok), 1)
+        return tok + self.interpolate_pos_encoding(tok.shape[1] - 1, w, h)
+
+    def key_features(self, x, layer=9):
+        """keys of block `layer`: [b, heads, tokens, d]"""
+        tok = self.prepare_tokens(x)
+        for blk in self.blocks[:layer]:
+            tok = blk(tok)
+        blk = self.blocks[layer]
+        return blk.attn.keys(blk.norm1(tok))
+
+    def forward(self, x):
+        tok = self.prepare_tokens(x)
+        for blk in self.blocks:
+            tok = blk(tok)
+        return self.norm(tok)[:, 0]
+
+
+def vit_small(patch_size=8):
+    return VisionTransformer(patch_size=patch_size, embed_dim=384, depth=12, num_heads=6)
+
+
+class DINO(nn.Module):
+    def __init__(self, pretrain_path="pretrain/dino_deitsmall8_pretrain.pth"):
+        super().__init__()
+        self.patch_size, self.feat_layer, self.num_patches = 8, 9, 32
+        self.model_name, self.pretrain_path = "vit_small", pretrain_path
+        self.model = vit_small(self.patch_size)
+        if os.path.exists(pretrain_path):
+            self.model.load_state_dict(torch.load(pretrain_path, map_location="cpu"))
+        elif not ALLOW_RANDOM_INIT:
+            raise FileNotFoundError("%s not found (set scp_amd.dino.ALLOW_RANDOM_INIT for synthetic weights)" % pretrain_path)
+        self.model.eval()
+
+    def train(self, mode=True):
+        return super().train(False)  # frozen feature extractor, always eval (pretrained_corr.py:21)
+
+    @torch.no_grad()
+    def forward(self, img):
+        k = self.model.key_features(img, self.feat_layer)[:, :, 1:, :]     # drop cls: b,h,t,d
+        b, nh, t, d = k.shape
+        side = int(math.sqrt(t))
+        return k.permute(0, 1, 3, 2).reshape(b, nh * d, side, side)

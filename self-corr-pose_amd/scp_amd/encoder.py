@@ -1,0 +1,42 @@
+"""scp_amd/encoder.py -- image / mesh encoder of the step (model/module/encoder.py:13-52).
+
+Stock PyTorch-ROCm (MIOpen convolutions) by design: north_star keeps everything but the three hot
+operators on PyTorch.  Called twice per step (here and from the rotation-cycle loss)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import imgops
+from .nets import MeshEncoder, PosePredictor, ResNet_Decoder, ResNet_Encoder, ShapePredictor
+
+
+class Encoder(nn.Module):
+    def __init__(self, opts):
+        super().__init__()
+        self.opts = opts
+        self.resnet_transform = imgops.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])
+        self.random_jitter = imgops.ColorJitter(0.2, 0.2, 0.2, 0.05)
+        self.backbone = ResNet_Encoder()
+        self.featnet = ResNet_Decoder(is_proj=True, out_channel=opts.n_corr_feat,
+                                      downsample=opts.img_size // opts.corr_h)
+        self.featnet_mesh = MeshEncoder(opts.n_corr_feat)
+        self.shape_code_predictor = nn.Linear(512, opts.codedim)
+        self.shape_predictor = ShapePredictor(opts)
+        self.pose_predictor = PosePredictor(opts, 512)
+
+    def encode_img(self, img):
+        c2, c3, c4, c5 = self.backbone(self.resnet_transform(self.random_jitter(img)))
+        img_code = c5.mean((2, 3))
+        feat = self.featnet(c2, c3, c4, c5).reshape(img.shape[0], self.opts.n_corr_feat, -1)
+        return img_code, F.normalize(feat, 2, 1)
+
+    def forward(self, img, mean_v, pp_crop, foc_crop):
+        img_code, img_feat = self.encode_img(img)
+        pred_v = self.shape_predictor(mean_v, self.shape_code_predictor(img_code))
+        mesh_feat = F.normalize(self.featnet_mesh(pred_v.detach()), 2, -1)
+        rotation, trans, scale = self.pose_predictor(img_code)
+        pred_v = pred_v * scale[:, None]
+        # principal-point compensation of the in-plane translation (encoder.py:49)
+        xy = trans[:, :2] - (pp_crop / foc_crop) * trans[:, 2:].detach()
+        translation = torch.cat((xy, trans[:, 2:]), 1)
+        return img_feat, mesh_feat, pred_v, rotation.reshape(-1, 3, 3), translation.reshape(-1, 1, 3), scale

@@ -1,0 +1,112 @@
+"""scp_amd/imgops.py -- the three torchvision image ops the training step calls (torchvision is not
+on the target image): Normalize, ColorJitter, rotate.
+
+torchvision 0.11 is an un-vendored dependency of the reference (README.md:25-29), so these follow
+its published algorithms and are "parity unpinned" against the real package: golden runs replace
+the jitter by identity and use angles that are multiples of 90 degrees, where `rotate` is exact
+(the same substitution is made on the reference side, tests/golden/ref_harness.py).
+Call sites in the reference: model/module/encoder.py:18-19,31 and correspondence.py:87-89.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class Normalize(nn.Module):
+    def __init__(self, mean, std):
+        super().__init__()
+        self.register_buffer("mean", torch.tensor(mean, dtype=torch.float32).view(1, -1, 1, 1), persistent=False)
+        self.register_buffer("std", torch.tensor(std, dtype=torch.float32).view(1, -1, 1, 1), persistent=False)
+
+    def forward(self, x):
+        return (x - self.mean) / self.std
+
+
+def _gray(img):
+    r, g, b = img.unbind(-3)
+    return (0.2989 * r + 0.587 * g + 0.114 * b).unsqueeze(-3)
+
+
+def _blend(a, b, ratio):
+    return (ratio * a + (1.0 - ratio) * b).clamp(0, 1)
+
+
+def _rgb_to_hsv(img):
+    r, g, b = img.unbind(-3)
+    maxc, minc = img.max(-3)[0], img.min(-3)[0]
+    eqc = maxc == minc
+    cr = maxc - minc
+    ones = torch.ones_like(maxc)
+    s = cr / torch.where(eqc, ones, maxc)
+    crd = torch.where(eqc, ones, cr)
+    rc, gc, bc = (maxc - r) / crd, (maxc - g) / crd, (maxc - b) / crd
+    hr = (maxc == r) * (bc - gc)
+    hg = ((maxc == g) & (maxc != r)) * (2.0 + rc - bc)
+    hb = ((maxc != g) & (maxc != r)) * (4.0 + gc - rc)
+    h = torch.fmod((hr + hg + hb) / 6.0 + 1.0, 1.0)
+    return torch.stack((h, s, maxc), -3)
+
+
+def _hsv_to_rgb(img):
+    h, s, v = img.unbind(-3)
+    i = torch.floor(h * 6.0)
+    f = h * 6.0 - i
+    i = i.to(torch.int32) % 6
+    p = (v * (1.0 - s)).clamp(0, 1)
+    q = (v * (1.0 - s * f)).clamp(0, 1)
+    t = (v * (1.0 - s * (1.0 - f))).clamp(0, 1)
+    mask = i.unsqueeze(-3) == torch.arange(6, device=img.device).view(-1, 1, 1)
+    a1 = torch.stack((v, q, p, p, t, v), -3)
+    a2 = torch.stack((t, v, v, q, p, p), -3)
+    a3 = torch.stack((p, p, t, v, v, q), -3)
+    a4 = torch.stack((a1, a2, a3), -4)
+    return torch.einsum("...ijk,...xijk->...xjk", mask.to(img.dtype), a4)
+
+
+class ColorJitter(nn.Module):
+    """brightness / contrast / saturation / hue jitter, one random order and one factor set per call
+    (applied to the whole batch, as torchvision does for a batched tensor)"""
+
+    def __init__(self, brightness=0., contrast=0., saturation=0., hue=0.):
+        super().__init__()
+        self.brightness, self.contrast, self.saturation, self.hue = brightness, contrast, saturation, hue
+
+    def forward(self, img):
+        order = torch.randperm(4).tolist()
+        rnd = torch.empty(4).uniform_(-1, 1).tolist()  # host RNG, no device sync
+        for op in order:
+            if op == 0 and self.brightness > 0:
+                img = _blend(img, torch.zeros_like(img), 1.0 + self.brightness * rnd[0])
+            elif op == 1 and self.contrast > 0:
+                mean = _gray(img).mean((-3, -2, -1), keepdim=True)
+                img = _blend(img, mean, 1.0 + self.contrast * rnd[1])
+            elif op == 2 and self.saturation > 0:
+                img = _blend(img, _gray(img), 1.0 + self.saturation * rnd[2])
+            elif op == 3 and self.hue > 0:
+                hsv = _rgb_to_hsv(img)
+                h = (hsv[..., 0:1, :, :] + self.hue * rnd[3]) % 1.0
+                img = _hsv_to_rgb(torch.cat((h, hsv[..., 1:, :, :]), -3))
+        return img
+
+
+def rotate(img, angle, interpolation="nearest"):
+    """counter-clockwise rotation about the image centre, zero fill, output size = input size.
+    Multiples of 90 degrees on square images are exact (rot90); other angles resample through an
+    inverse affine grid like torchvision's tensor backend."""
+    k = angle / 90.0
+    if img.shape[-1] == img.shape[-2] and abs(k - round(k)) < 1e-9:
+        return torch.rot90(img, int(round(k)) % 4, dims=(-2, -1))
+    squeeze = img.dim() == 3
+    if squeeze:
+        img = img[None]
+    n, _, h, w = img.shape
+    a = math.radians(angle)
+    # output pixel (x, y), centred, y down -> source location: rotate by +a in image coordinates
+    cos, sin = math.cos(a), math.sin(a)
+    theta = torch.tensor([[cos, -sin * h / w, 0.0], [sin * w / h, cos, 0.0]], dtype=img.dtype, device=img.device)
+    grid = F.affine_grid(theta[None].expand(n, -1, -1), (n, 1, h, w), align_corners=False)
+    out = F.grid_sample(img, grid, mode="bilinear" if interpolation == "bilinear" else "nearest",
+                        padding_mode="zeros", align_corners=False)
+    return out[0] if squeeze else out

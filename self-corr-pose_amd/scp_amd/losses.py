@@ -1,0 +1,195 @@
+"""scp_amd/losses.py -- image-space losses, regularisers and batch re-pairing of the training step.
+
+They consume the HIP kernels' outputs and stay on PyTorch.  Semantics
+restated from model/util/loss_utils.py: pinhole_cam :38-47, render :49-61, LaplacianLoss :63-97,
+FlattenLoss :99-183, compute_camera_loss :228-234, compute_mask_loss :236-244 (the "pyramid" is a
+1-D area pooling along W because 3-D tensors are fed to F.interpolate -- SURVEY F13 -- kept),
+compute_texture_loss :246-252, compute_depth_loss :273-284, compute_match_loss :317-320,
+compute_imatch_loss :322-324, divide_by_{frame,instance,both} :326-345.
+Differences (numerically equivalent, no host sync): boolean-mask means in compute_depth_loss are
+masked sums; pinhole_cam/render are functional (the reference mutates its argument in place).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import soft_renderer as sr
+
+
+def pinhole_cam(verts, pp, foc):
+    """NDC pinhole projection of camera-space points; z is kept"""
+    if verts.dim() == 3:
+        x = pp[:, 0][:, None] + verts[:, :, 0] * foc[:, 0][:, None] / verts[:, :, 2]
+        y = pp[:, 1][:, None] + verts[:, :, 1] * foc[:, 1][:, None] / verts[:, :, 2]
+        return torch.stack((x, y, verts[:, :, 2]), 2)
+    if verts.dim() == 2:
+        x = pp[0] + verts[:, 0] * foc[0] / verts[:, 2]
+        y = pp[1] + verts[:, 1] * foc[1] / verts[:, 2]
+        return torch.stack((x, y, verts[:, 2]), 1)
+    raise ValueError("vertices shape must be (bsz, N, 3) or (N, 3).")
+
+
+def project_for_render(verts, foc, pp, rotation, translation, rotation_detach=False, translation_detach=False):
+    rot = rotation.detach() if rotation_detach else rotation
+    trans = translation.detach() if translation_detach else translation
+    cam = pinhole_cam(verts.bmm(rot) + trans, pp, foc)
+    return torch.stack((cam[:, :, 0], -cam[:, :, 1], cam[:, :, 2]), 2)  # image y is flipped
+
+
+def render(renderer, verts, faces, tex, foc, pp, rotation, translation, rotation_detach=False,
+           translation_detach=False, render_depth=False, render_mask=False, texture_type="vertex"):
+    verts = project_for_render(verts, foc, pp, rotation, translation, rotation_detach, translation_detach)
+    if render_depth:
+        tex = verts
+    if render_mask:
+        return renderer.render_mesh(sr.Mesh(verts, faces))
+    return renderer.render_mesh(sr.Mesh(verts, faces, tex, texture_type=texture_type))
+
+
+class LaplacianLoss(nn.Module):
+    def __init__(self, vertex, faces, average=False):
+        super().__init__()
+        nv = vertex.size(0)
+        f = faces.detach().cpu().numpy()
+        lap = np.zeros([nv, nv], np.float32)
+        for a, b in ((0, 1), (1, 2), (2, 0)):
+            lap[f[:, a], f[:, b]] = -1
+            lap[f[:, b], f[:, a]] = -1
+        idx = np.arange(nv)
+        lap[idx, idx] = -lap.sum(1)
+        diag = lap[idx, idx].copy()
+        nz = diag != 0
+        lap[nz] /= diag[nz][:, None]
+        self.average = average
+        self.register_buffer("laplacian", torch.from_numpy(lap))
+
+    def forward(self, x):
+        y = torch.matmul(self.laplacian, x).pow(2).sum(tuple(range(1, x.dim())))
+        return y.sum() / x.size(0) if self.average else y
+
+
+class FlattenLoss(nn.Module):
+    """dihedral-angle smoothness over interior edges"""
+
+    def __init__(self, faces, average=False):
+        super().__init__()
+        f = faces.detach().cpu().numpy()
+        edge_faces = {}
+        for fi, tri in enumerate(f):
+            for a, b in ((0, 1), (1, 2), (2, 0)):
+                key = (min(tri[a], tri[b]), max(tri[a], tri[b]))
+                edge_faces.setdefault(key, []).append(fi)
+        # the reference enumerates the edges through a python set of (v0,v1) tuples; the loss is a
+        # sum over edges, so any order is equivalent
+        v0s, v1s, v2s, v3s = [], [], [], []
+        for (a, b), fl in sorted(edge_faces.items()):
+            if len(fl) < 2:
+                continue
+            others = [int([v for v in f[fi] if v != a and v != b][0]) for fi in sorted(fl)[:2]]
+            v0s.append(a); v1s.append(b); v2s.append(others[0]); v3s.append(others[1])
+        for name, val in (("v0s", v0s), ("v1s", v1s), ("v2s", v2s), ("v3s", v3s)):
+            self.register_buffer(name, torch.tensor(val, dtype=torch.long))
+        self.average = average
+
+    def forward(self, vertices, eps=1e-6):
+        v0, v1 = vertices[:, self.v0s], vertices[:, self.v1s]
+        a = v1 - v0
+        al2 = a.pow(2).sum(-1)
+
+        def perp(vk):
+            b = vk - v0
+            bl1 = (b.pow(2).sum(-1) + eps).sqrt()
+            ab = (a * b).sum(-1)
+            cos = ab / ((al2 + eps).sqrt() * bl1 + eps)
+            sin = (1 - cos.pow(2) + eps).sqrt()
+            return b - a * (ab / (al2 + eps))[:, :, None], bl1 * sin
+
+        cb1, l1 = perp(vertices[:, self.v2s])
+        cb2, l2 = perp(vertices[:, self.v3s])
+        cos = (cb1 * cb2).sum(-1) / (l1 * l2 + eps)
+        loss = (cos + 1).pow(2).sum(tuple(range(1, cos.dim())))
+        return loss.sum() / vertices.size(0) if self.average else loss
+
+
+def compute_camera_loss(m1, m2):
+    m = torch.bmm(m1, m2.transpose(1, 2))
+    cos = (m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2] - 1) / 2
+    return torch.acos(F.hardtanh(cos, -1, 1))
+
+
+def _pool_w(x, level):
+    """F.interpolate(x[B,H,W], scale_factor=0.5**level, mode='area') == mean over groups of
+    2**level along W (H acts as the channel dimension)"""
+    if level == 0:
+        return x
+    k = 2 ** level
+    return x.reshape(x.shape[0], x.shape[1], x.shape[2] // k, k).mean(-1)
+
+
+def compute_mask_loss(img, mask, mask_pred, occ=None):
+    total = 0
+    for level in range(5):
+        diff = (_pool_w(mask_pred, level) - _pool_w(mask, level)).pow(2)
+        # area-upsampling back to [H,W] = nearest repeat along W (and identity along H)
+        total = total + diff.repeat_interleave(2 ** level, dim=2)
+    if occ is not None:
+        total = total * (1. - occ)
+    return 0.2 * total.mean((1, 2))
+
+
+def compute_texture_loss(img, mask, tex_pred, tex_mask, occ=None):
+    fg = (mask > 0).float()[:, None]
+    img_gt = img * fg
+    img_gt_white = 1 - fg + img_gt
+    per_px = 0.75 * (img_gt - tex_pred * tex_mask[:, None]).pow(2).sum(1) + (img_gt_white - tex_pred).abs().mean(1)
+    if occ is not None:
+        per_px = per_px * (1. - occ)
+    return per_px.mean((1, 2))
+
+
+def compute_depth_loss(depth, depth_pred, depth_mask, mask):
+    keep = ((mask * depth_mask).detach() != 0) & (depth != 0)
+    m_pred = (depth_mask != 0).to(depth_pred.dtype)
+    m_gt = (mask * depth != 0).to(depth.dtype)
+    depth_scale = ((depth_pred * m_pred).sum() / m_pred.sum()) / ((depth * m_gt).sum() / m_gt.sum())
+    depth_diff = torch.where(keep, depth_pred - depth_scale * depth, torch.zeros_like(depth_pred))
+    sq = depth_diff.pow(2)
+    loss = 1. - torch.relu(1. - sq)
+    return loss.mean((1, 2)), depth_diff
+
+
+def compute_match_loss(match, match_gt, match_mask, mask):
+    valid = (match_mask > 0) & (mask > 0)
+    return ((match - match_gt).norm(2, 1) * valid).mean((1, 2))
+
+
+def compute_imatch_loss(imatch, imatch_gt, depth_weight):
+    return ((imatch - imatch_gt).norm(2, 1) * depth_weight).mean(1)
+
+
+def divide_by_frame(x, batch_size, repeat):
+    src = x.reshape(batch_size, repeat, *x.shape[1:])
+    tgt = torch.roll(src, -1, 1)
+    return src.reshape(-1, *src.shape[2:]), tgt.reshape(-1, *tgt.shape[2:])
+
+
+def divide_by_instance(x, batch_size, repeat):
+    src = x.reshape(batch_size, repeat, *x.shape[1:])
+    tgt = torch.roll(src, -1, 0)
+    return src.reshape(-1, *src.shape[2:]), tgt.reshape(-1, *tgt.shape[2:])
+
+
+def divide_by_both(x, batch_size, repeat):
+    sf, tf = divide_by_frame(x, batch_size, repeat)
+    si, ti = divide_by_instance(x, batch_size, repeat)
+    return torch.cat((sf, si), 0), torch.cat((tf, ti), 0)
+
+
+def pair_indices(kind, batch_size, repeat, device=None):
+    """index form of divide_by_*: (src_idx, tgt_idx) into the per-rank batch of batch_size*repeat
+    images, so that per-image quantities (e.g. DINO features) are computed once and gathered
+    """
+    ids = torch.arange(batch_size * repeat, device=device)
+    fn = {"frame": divide_by_frame, "instance": divide_by_instance, "both": divide_by_both}[kind]
+    return fn(ids, batch_size, repeat)

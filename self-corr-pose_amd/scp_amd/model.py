@@ -1,0 +1,110 @@
+"""scp_amd/model.py -- MeshNet: one self-supervised training forward.
+
+API of model/model.py (MeshNet.__init__ :44-58, forward :61-152,309, load_network :313-328): the
+same 12-tuple in, `(total_loss, aux_output)` out in training and the same 10-tuple in eval; the same
+sub-module names (mesh, encoder, pretrain_corr_net, triangle_loss_fn) so checkpoints and the
+optimiser's name-based parameter groups carry over.  The per-`vis_freq` visualisation block
+(model.py:155-307: host-side drawing with cv2/trimesh) is not part of the hot path and is omitted.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import losses
+from .correspondence import Correspondence
+from .encoder import Encoder
+from .mesh import CanonicalMesh
+from .pretrained_corr import PretrainedCorrespondence
+from .renderer import Renderer
+from .weights import Weights
+
+
+class MeshNet(nn.Module):
+    def __init__(self, opts, prior=None):
+        super().__init__()
+        self.opts = opts
+        self.mesh = CanonicalMesh(opts, prior)
+        self.weights = Weights(opts)
+        self.encoder = Encoder(opts)
+        self.corr_net = Correspondence(opts)
+        self.pretrain_corr_net = PretrainedCorrespondence(opts, self.mesh, pretrained=True)
+        self.renderer = Renderer(opts, self.mesh)
+        self.iters = 0
+        self.triangle_loss_fn = losses.LaplacianLoss(self.mesh.mean_v, self.mesh.faces, average=True)
+        if opts.flatten_loss:
+            self.flatten_loss_fn = losses.FlattenLoss(self.mesh.faces, average=True)
+        self.rotation_angle = None   # test hook: pins the rotation-cycle angle
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.corr_net.to(self.mesh.mean_v.device)   # Correspondence is a plain object holding a grid
+        return out
+
+    def forward(self, data):
+        opts, wts = self.opts, self.weights
+        wts.schedule(self.iters)
+        img, mask, depth, occ, center, length, foc, foc_crop, pp, pp_crop, indices, gt = data
+        bsz = img.shape[0]
+        mean_v = self.mesh.mean_v[None].expand(bsz, -1, -1)
+        faces = self.mesh.faces[None].expand(bsz, -1, -1)
+
+        img_feat, mesh_feat, pred_v, rotation, translation, scale = self.encoder(img, mean_v, pp_crop, foc_crop)
+        pointcorr, match, imatch, match_conf = self.corr_net.match(img_feat, mesh_feat, mask, pred_v)
+        tex = self.mesh.get_texture(pred_v, faces, imatch, img)
+        if not opts.train:
+            return pred_v, faces, tex, imatch, match, match_conf, rotation, translation, scale, pointcorr
+
+        (mask_render, tex_render, depth_render, match_gt, imatch_gt, tex_mask, depth_mask, match_mask,
+         depth_weight) = self.renderer.render_all(pred_v, faces, tex, foc_crop, pp_crop, rotation, translation, scale)
+
+        occ_arg = occ if opts.use_occ else None
+        mask_loss = wts.mask_wt * losses.compute_mask_loss(img, mask, mask_render, occ_arg).mean(0)
+        texture_loss = wts.tex_wt * losses.compute_texture_loss(img, mask, tex_render, tex_mask, occ_arg).mean(0)
+        if opts.use_depth:
+            if opts.depth_loss_chamfer:
+                raise NotImplementedError("depth_loss_chamfer is off in every shipped config")
+            depth_loss_sub, _ = losses.compute_depth_loss(depth, depth_render, depth_mask, mask)
+            depth_loss = wts.depth_wt * depth_loss_sub.mean(0)
+        match_loss = wts.match_wt * losses.compute_match_loss(match, match_gt, match_mask, mask).mean(0)
+        imatch_loss = wts.imatch_wt * losses.compute_imatch_loss(imatch, imatch_gt, depth_weight).mean(0)
+
+        symmetry_loss = wts.symmetry_wt * self.mesh.compute_symmetry_loss(pred_v, faces)
+        triangle_loss = wts.triangle_wt * self.triangle_loss_fn(pred_v) * pred_v.shape[1] / 64.
+        if opts.flatten_loss:
+            triangle_loss = triangle_loss + wts.triangle_wt * self.flatten_loss_fn(pred_v) * 0.1 * np.sqrt(pred_v.shape[1] / 64.)
+        pullfar_loss = wts.pullfar_wt * F.relu(1 - translation[:, :, -1]).mean()
+        deform_loss = wts.deform_wt * F.smooth_l1_loss(pred_v, mean_v, reduction="mean")
+
+        cycle_loss_pt = self.pretrain_corr_net.compute_cycle_loss(img, mask, depth_weight, pointcorr)[0] * wts.cycle_loss_pt_wt
+        cycle_loss = self.corr_net.compute_rotation_cycle_loss(img, mask, img_feat, self.encoder,
+                                                               angle=self.rotation_angle)[0] * wts.cycle_loss_wt
+
+        total_loss = (mask_loss + symmetry_loss + triangle_loss + deform_loss + pullfar_loss + texture_loss +
+                      match_loss + imatch_loss + cycle_loss_pt + cycle_loss)
+        if opts.use_depth:
+            total_loss = total_loss + depth_loss
+        if opts.camera_loss:
+            rot2 = rotation.detach().reshape(-1, opts.repeat, 3, 3).roll(-1, 1).reshape(bsz, 3, 3)
+            cam_loss = wts.camera_wt * losses.compute_camera_loss(rotation, rot2).mean()
+            total_loss = total_loss + cam_loss
+
+        aux_output = {
+            "total_loss": total_loss, "mask_loss": mask_loss, "triangle_loss": triangle_loss,
+            "deform_loss": deform_loss, "pullfar_loss": pullfar_loss, "symmetry_loss": symmetry_loss,
+            "match_loss": match_loss, "texture_loss": texture_loss, "imatch_loss": imatch_loss,
+            "cycle_loss_pretrain": cycle_loss_pt, "cycle_loss": cycle_loss,
+        }
+        if opts.use_depth:
+            aux_output["depth_loss"] = depth_loss
+        if opts.camera_loss:
+            aux_output["cam_loss"] = cam_loss
+        self.last_pose = (rotation.detach(), translation.detach())
+        return total_loss, aux_output
+
+    def load_network(self, model_path, iter=0):
+        states = torch.load(model_path, map_location="cpu")
+        for name in list(states.keys()):
+            if "symm_rots" in name or "triangle_loss_fn" in name or "flatten_loss_fn" in name:
+                states.pop(name)
+        self.load_state_dict(states, strict=False)

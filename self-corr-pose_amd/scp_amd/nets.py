@@ -1,0 +1,222 @@
+"""scp_amd/nets.py -- the small stock-PyTorch networks around the hot path (north_star leaves them on
+PyTorch-ROCm / MIOpen).  Module and parameter NAMES follow the reference so that its checkpoints
+load and its optimiser's name-based parameter groups (optimizers.py:16-35) keep working.
+
+Restated from (reference file:line):
+  torchvision resnet18 (un-vendored; standard topology, torchvision key names) as used by
+      model/module/network/image_encoder.py:119-139 (ResNet_Encoder; fc dropped)
+  image_encoder.py:141-193   ResNet_Decoder (conv+LeakyReLU(0.1) units, bilinear 2x upsampling)
+  network/net_blocks.py:336-359  conv2DBatchNormRelu (with_bn=False as instantiated)
+  network/mesh_encoder.py:6-39   STN3d_noBN + MeshEncoder
+  network/pose_predictor.py:22-83  PosePredictor (6D rotation, Gram-Schmidt, offsets)
+  network/shape_predictor.py:12-43 + third-party/nerf/models.py:336-417, train_utils.py:9-33
+      ShapePredictor = conditional MLP on (vertex, shape code)
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------
+# ResNet18 trunk (torchvision key names: conv1, bn1, layer{1..4}.{0,1}.{conv1,bn1,conv2,bn2,downsample})
+# ------------------------------------------------------------------------------------------------
+class _BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        skip = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        return self.relu(self.bn2(self.conv2(y)) + skip)
+
+
+class ResNet18Trunk(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        widths = [64, 128, 256, 512]
+        cin = 64
+        for i, w in enumerate(widths):
+            stride = 1 if i == 0 else 2
+            setattr(self, "layer%d" % (i + 1), nn.Sequential(_BasicBlock(cin, w, stride), _BasicBlock(w, w, 1)))
+            cin = w
+        self.fc = None
+        for m in self.modules():  # torchvision's default init
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+
+class ResNet_Encoder(nn.Module):
+    """returns the four pyramid levels (1/4 .. 1/32 resolution: 64, 128, 256, 512 channels)"""
+
+    def __init__(self):
+        super().__init__()
+        self.resnet = ResNet18Trunk()
+
+    def forward(self, x):
+        r = self.resnet
+        x = r.maxpool(r.relu(r.bn1(r.conv1(x))))
+        c2 = r.layer1(x)
+        c3 = r.layer2(c2)
+        c4 = r.layer3(c3)
+        c5 = r.layer4(c4)
+        return c2, c3, c4, c5
+
+
+class _ConvUnit(nn.Module):
+    """3x3 conv + LeakyReLU(0.1); parameters live under `.cbr_unit.0` like the reference's"""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.cbr_unit = nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1, bias=True), nn.LeakyReLU(0.1, inplace=True))
+
+    def forward(self, x):
+        return self.cbr_unit(x)
+
+
+class ResNet_Decoder(nn.Module):
+    def __init__(self, is_proj=True, out_channel=64, downsample=4):
+        super().__init__()
+        self.is_proj, self.downsample = is_proj, downsample
+        self.upconv5, self.iconv4 = _ConvUnit(512, 256), _ConvUnit(512, 256)
+        self.upconv4, self.iconv3 = _ConvUnit(256, 128), _ConvUnit(256, 128)
+        self.upconv3, self.iconv2 = _ConvUnit(128, 64), _ConvUnit(128, 64)
+        if is_proj:
+            self.proj = nn.Conv2d(64 if downsample == 4 else 128, out_channel, 1)
+
+    @staticmethod
+    def _up(x, like):
+        return F.interpolate(x, like.shape[2:], mode="bilinear", align_corners=False)
+
+    def forward(self, c2, c3, c4, c5):
+        c4 = self.iconv4(torch.cat((c4, self.upconv5(self._up(c5, c4))), 1))
+        c3 = self.iconv3(torch.cat((c3, self.upconv4(self._up(c4, c3))), 1))
+        c2 = self.iconv2(torch.cat((c2, self.upconv3(self._up(c3, c2))), 1))
+        feat = c2 if self.downsample == 4 else c3
+        return self.proj(feat) if self.is_proj else feat
+
+
+# ------------------------------------------------------------------------------------------------
+# mesh feature net
+# ------------------------------------------------------------------------------------------------
+class STN3d_noBN(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv1d(3, 128, 1)
+        self.fc = nn.Linear(128, 9)
+
+    def forward(self, x):  # x: b,3,n
+        h = F.relu(self.conv1(x)).max(2)[0]
+        eye = torch.eye(3, device=x.device, dtype=x.dtype).reshape(1, 9)
+        return (self.fc(h) + eye).view(-1, 3, 3)
+
+
+class MeshEncoder(nn.Module):
+    def __init__(self, n_feat):
+        super().__init__()
+        self.stn = STN3d_noBN()
+        self.conv1 = nn.Conv1d(3, n_feat, 1)
+
+    def forward(self, x):  # b,n,3 -> b,n,c
+        trans = self.stn(x.transpose(2, 1))
+        x = torch.bmm(x, trans).transpose(2, 1)
+        return F.relu(self.conv1(x)).transpose(2, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# pose head
+# ------------------------------------------------------------------------------------------------
+def _fc_stack(cin, cout, n):
+    layers = []
+    for _ in range(n):
+        layers.append(nn.Sequential(nn.Linear(cin, cout), nn.LeakyReLU(0.1, inplace=True)))
+        cin = cout
+    net = nn.Sequential(*layers)
+    for m in net.modules():
+        if isinstance(m, nn.Linear):
+            m.weight.data.normal_(0, 0.02)
+            m.bias.data.zero_()
+    return net
+
+
+class PosePredictor(nn.Module):
+    def __init__(self, opts, nc_input):
+        super().__init__()
+        self.offset = opts.depth_offset
+        self.use_scale = opts.use_scale
+        self.n_hypo = opts.num_multipose_az * opts.num_multipose_el
+        assert self.n_hypo == 1
+        self.rot_pred_layer = nn.Sequential(_fc_stack(nc_input, 128, 3), nn.Linear(128, 6 * self.n_hypo))
+        self.trans_pred_layer = nn.Linear(nc_input, 3 * self.n_hypo)
+        if self.use_scale:
+            self.scale_pred_layer = nn.Linear(nc_input, 3 * self.n_hypo)
+        r_off = [float(r) for r in opts.rotation_offset]
+        self.x_offset = nn.Parameter(torch.tensor([r_off[:3]]), requires_grad=False)
+        self.y_offset = nn.Parameter(torch.tensor([r_off[3:]]), requires_grad=False)
+
+    def forward(self, feat):
+        n = feat.shape[0] * self.n_hypo
+        rot6 = self.rot_pred_layer(feat).reshape(n, 6)
+        x = F.normalize(rot6[:, :3] + self.x_offset)
+        y = rot6[:, 3:] + self.y_offset
+        z = F.normalize(torch.cross(x, y, dim=1))
+        y = F.normalize(torch.cross(z, x, dim=1))
+        rot = torch.stack((x, y, z), 2)
+        t = self.trans_pred_layer(feat).reshape(n, 3)
+        trans = torch.cat((t[:, :2] * 0.1, t[:, 2:] + self.offset), 1)
+        if self.use_scale:
+            scale = self.scale_pred_layer(feat).reshape(n, 3) * 0.1 + 1.
+        else:
+            scale = torch.ones((n, 3), device=feat.device, dtype=feat.dtype)
+        return rot, trans, scale
+
+
+# ------------------------------------------------------------------------------------------------
+# shape head: conditional MLP  (vertex xyz ++ shape code) -> xyz offset
+# ------------------------------------------------------------------------------------------------
+class CondNeRFModel(nn.Module):
+    """the 2-layer configuration the reference instantiates (shape_predictor.py:15-24): only the
+    layers that exist for num_layers=2, no positional encoding, no view directions"""
+
+    def __init__(self, codesize, hidden_size=256, out_channel=3):
+        super().__init__()
+        self.codesize = codesize
+        self.layer1 = nn.Linear(3 + codesize, hidden_size)
+        self.layers_xyz = nn.ModuleList([nn.Linear(hidden_size, hidden_size)])
+        self.layers_dir = nn.ModuleList([nn.Linear(hidden_size, hidden_size // 2)])
+        self.fc_alpha = nn.Linear(hidden_size, 1)   # present in checkpoints, never used for the shape
+        self.fc_rgb = nn.Linear(hidden_size // 2, out_channel)
+        self.fc_feat = nn.Linear(hidden_size, hidden_size)
+
+    def forward(self, x):  # [..., 3 + codesize] -> [..., out_channel]
+        h = self.layer1(x)                       # (no activation after layer1 in the reference)
+        h = F.relu(self.layers_xyz[0](h))
+        h = F.relu(self.fc_feat(h))
+        h = F.relu(self.layers_dir[0](h))
+        return self.fc_rgb(h)
+
+
+class ShapePredictor(nn.Module):
+    def __init__(self, opts):
+        super().__init__()
+        self.shapenerf = CondNeRFModel(codesize=opts.codedim)
+        self.no_deform, self.deform_ratio = opts.no_deform, opts.deform_ratio
+
+    def forward(self, mean_v, shape_code):
+        if self.no_deform:
+            return mean_v
+        code = shape_code[:, None].expand(-1, mean_v.shape[1], -1)
+        delta = self.shapenerf(torch.cat((mean_v.detach(), code), -1))
+        delta = delta - delta.mean(1, keepdim=True)
+        return mean_v + delta * self.deform_ratio

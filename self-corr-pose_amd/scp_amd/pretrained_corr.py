@@ -1,0 +1,94 @@
+"""scp_amd/pretrained_corr.py -- DINO-supervised cycle loss.
+
+API and semantics of model/module/pretrained_corr.py: PretrainedCorrespondence.match :48-104
+(mutual nearest neighbours of DINO keys between image pairs, top-k most cycle-consistent target
+pixels), compute_cycle_loss :107-140 (soft pixel->pixel map bridged through the vertices, L2 to
+the DINO matches).  Batch re-pairing: model/util/loss_utils.py:326-345.
+
+MI355X-first differences, value-preserving: DINO runs once per unique image and the src/tgt lists
+are gathers of feature maps (the reference pushes 4B images through the ViT for B
+unique ones); `pointcorr` is pooled once per image before pairing; the bridge `corr` matrix is only
+formed for the k gathered target columns.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .correspondence import make_meshgrid
+from .dino import DINO
+from .losses import pair_indices
+
+
+class PretrainedCorrespondence(nn.Module):
+    def __init__(self, opts, mesh, pretrained=True):
+        super().__init__()
+        self.opts = opts
+        self.mesh = mesh
+        self.net = DINO().eval()
+        self.img_size, self.feat_size = opts.img_size, opts.img_size // 8
+        self.tau_img, self.tau_mesh, self.k = opts.tau_img, opts.tau_mesh, opts.pretrain_k
+        self.hf, self.wf = opts.corr_h, opts.corr_w
+        self.register_buffer("meshgrid", make_meshgrid(self.hf, self.wf), persistent=False)
+        for p in self.net.parameters():
+            p.requires_grad = False
+        if opts.divide_fn not in ("frame", "instance", "both"):
+            raise ValueError
+        self.divide_kind = opts.divide_fn
+        self.topk_override = None   # test hook: indices [N,k] (topk tie-breaking is backend-defined)
+
+    def half_grid(self, bsz):
+        grid = self.meshgrid.reshape(2, self.hf, self.wf)[None].expand(bsz, -1, -1, -1)
+        return F.interpolate(grid, (self.hf // 2, self.wf // 2), mode="bilinear")
+
+    # -- reference signature: images in, DINO inside --------------------------------------------
+    def match(self, src_img, tgt_img, src_mask, tgt_mask, grid):
+        bsz = src_img.shape[0]
+        feats = self.net(torch.cat((src_img, tgt_img), 0))
+        return self.match_features(feats[:bsz], feats[bsz:], src_mask, tgt_mask, grid)
+
+    def match_features(self, src_feat, tgt_feat, src_mask, tgt_mask, grid):
+        bsz = src_feat.shape[0]
+        fs = self.feat_size
+        src_feat, tgt_feat = src_feat.reshape(bsz, src_feat.shape[1], -1), tgt_feat.reshape(bsz, tgt_feat.shape[1], -1)
+        src_mask_down = F.interpolate(src_mask[:, None], (fs, fs), mode="nearest").reshape(bsz, -1)
+        tgt_mask_down = F.interpolate(tgt_mask[:, None], (fs, fs), mode="nearest").reshape(bsz, -1)
+        bw, fw = ops.mutual_nn(src_feat, tgt_feat, src_mask_down, tgt_mask_down)
+        cy = torch.gather(fw, -1, bw)
+        grid = grid.reshape(bsz, 2, -1)
+        pick = lambda idx: torch.gather(grid, -1, idx[:, None].expand(-1, 2, -1))
+        match, cycle = pick(bw), pick(cy)
+        distance = (cycle - grid).norm(2, 1)
+        distance = torch.where(tgt_mask_down > 0, distance, torch.full_like(distance, 1e5))
+        if self.topk_override is not None:
+            indices = self.topk_override
+        else:
+            indices = torch.topk(-distance, k=self.k, dim=1).indices
+        self.last_distance = distance.detach()
+        match = torch.gather(match, -1, indices[:, None].expand(-1, 2, -1))
+        grid_k = torch.gather(grid, -1, indices[:, None].expand(-1, 2, -1))
+        match_mask = torch.gather(tgt_mask_down, -1, indices)
+        indices_match = torch.gather(bw, -1, indices)
+        return match, grid_k, indices_match, indices, match_mask
+
+    def compute_cycle_loss(self, img, mask, depth_weight, pointcorr):
+        num_verts = pointcorr.shape[-1]
+        src_idx, tgt_idx = pair_indices(self.divide_kind, self.opts.batch_size, self.opts.repeat, img.device)
+        n = src_idx.shape[0]
+        hh, wh = self.hf // 2, self.wf // 2
+        grid = self.half_grid(n)
+
+        feats = self.net(img)                                                    # once per unique image
+        pts_src, pts_tgt, indices_src, indices_tgt, mask_k = self.match_features(
+            feats[src_idx], feats[tgt_idx], mask[src_idx], mask[tgt_idx], grid)
+
+        # bilinear half-resolution (= exact 2x2 mean) of the score maps, once per image
+        pooled = F.interpolate(pointcorr.permute(0, 2, 1).reshape(-1, num_verts, self.hf, self.wf),
+                               (hh, wh), mode="bilinear").reshape(-1, num_verts, hh * wh).permute(0, 2, 1)  # b,p,v
+        pc_src = pooled[src_idx]
+        pc_tgt_sel = torch.gather(pooled[tgt_idx], 1, indices_tgt[:, :, None].expand(-1, -1, num_verts))
+        keep = depth_weight >= 0.5
+        match = ops.vertex_bridge_match(pc_src, pc_tgt_sel, keep[src_idx], keep[tgt_idx],
+                                        grid.reshape(n, 2, -1), self.tau_img, self.tau_mesh)
+        cycle_loss = ((match - pts_src).norm(2, 1) * mask_k).mean()
+        return cycle_loss, pts_src, pts_tgt, match, mask_k, img[src_idx], img[tgt_idx]

@@ -125,7 +125,134 @@ def gen_softras():
              aggr_func_alpha=extra.get("aggr_func_alpha", "prod"), **out)
 
 
-GENERATORS = {"softras": gen_softras}
+def _stats(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
+
+
+def gen_step():
+    """G7 (+G5): one full reference MeshNet.forward/backward (model/model.py:61-152) on the synthetic
+    batch of SURVEY 8(d): B = batch_size 2 x repeat 2, 256^2, bottle prior (642 v / 1280 f), laptop
+    flags, recipe weights (tests/recipe.py), jitter = identity, rotation angle pinned to 90 degrees,
+    symmetry sample injected, top-k selection recorded."""
+    import tempfile
+    import recipe
+    import synth
+    sys.path.insert(0, os.path.join(ROOT, "self-corr-pose_amd"))
+    from scp_amd.flags import PRESETS, DEFAULTS
+
+    flags = ref_harness.install()
+    work = tempfile.mkdtemp(prefix="scp_golden_")
+    os.makedirs(os.path.join(work, "pretrain"))
+    os.chdir(work)
+    import config  # noqa: F401  (reference config.py: base flags)
+    for k in ("img_size", "repeat", "use_occ"):
+        setattr(flags, k, DEFAULTS[k])
+
+    # a DINO "checkpoint" from the recipe so that reference and build hold the same ViT weights
+    from zsp.zsp.method import vision_transformer_flexible as vits
+    vit = vits.vit_small(patch_size=8)
+    ck = {k: recipe.tensor_for("pretrain_corr_net.net.model." + k, v) for k, v in vit.state_dict().items()}
+    torch.save(ck, os.path.join(work, "pretrain", "dino_deitsmall8_pretrain.pth"))
+
+    from model.model import MeshNet
+    for k, v in PRESETS["laptop_wild6d"].items():
+        setattr(flags, k, v)
+    bottle = ref_harness.REF + "/config/bottle_wild6d/bottle.obj"
+    flags.shape_prior_path = bottle
+    flags.batch_size, flags.repeat, flags.train, flags.vis_freq = 2, 2, True, 10 ** 9
+    ref_harness.PINNED_ANGLE[0] = 90.0
+
+    bsz = 4
+    torch.manual_seed(0)
+    model = MeshNet(flags)
+    missing, unexpected = model.load_state_dict(recipe.recipe_state_dict(model), strict=False)
+    assert not unexpected, unexpected
+    model.train()
+    model.iters = 0
+
+    # injected symmetry sample (k = 2 symmetry rotations for the laptop flags)
+    k = model.mesh.symm_rots.shape[0]
+    fi, bary = recipe.symmetry_sample(k * bsz, 10000, model.mesh.num_faces)
+    hook = sys.modules["pytorch3d.ops"].sample_points_from_meshes
+    type(hook).face_idx, type(hook).bary = fi, bary
+
+    data = synth.make_batch(2, 2, 256, seed=0)
+    cap = {}
+    enc_fwd = model.encoder.forward
+
+    def enc_spy(*a, **kw):
+        out = enc_fwd(*a, **kw)
+        cap["enc"] = out
+        return out
+
+    model.encoder.forward = enc_spy
+    match_fn = model.corr_net.match
+
+    def match_spy(*a, **kw):
+        out = match_fn(*a, **kw)
+        cap["match"] = out
+        return out
+
+    model.corr_net.match = match_spy
+    render_fn = model.renderer.render_all
+
+    def render_spy(*a, **kw):
+        out = render_fn(*a, **kw)
+        cap["render"] = out
+        return out
+
+    model.renderer.render_all = render_spy
+    topk_orig = torch.topk
+
+    def topk_spy(x, k, dim=-1, **kw):
+        out = topk_orig(x, k=k, dim=dim, **kw)
+        cap.setdefault("topk", []).append((x.detach().clone(), out.indices.clone()))
+        return out
+
+    torch.topk = topk_spy
+    dino_fwd = model.pretrain_corr_net.net.forward
+    try:
+        total, aux = model(data)
+    finally:
+        torch.topk = topk_orig
+    total.mean().backward()
+
+    img_feat, mesh_feat, pred_v, rotation, translation, scale = cap["enc"]
+    pointcorr, match, imatch, _ = cap["match"]
+    (mask_render, tex_render, depth_render, match_gt, imatch_gt, tex_mask, depth_mask, match_mask,
+     depth_weight) = cap["render"]
+    neg_dist, topk_idx = cap["topk"][0]
+    with torch.no_grad():
+        dino_feat = dino_fwd(data[0][:2])
+    out = {("aux_" + k): np.float64(v.item()) for k, v in aux.items()}
+    params = dict(model.named_parameters())
+    grads = {
+        "grad_mean_v": params["mesh.mean_v"].grad,
+        "grad_resnet_conv1": params["encoder.backbone.resnet.conv1.weight"].grad,
+        "grad_featnet_proj": params["encoder.featnet.proj.weight"].grad,
+        "grad_pose_trans": params["encoder.pose_predictor.trans_pred_layer.weight"].grad,
+        "grad_shapenerf_fc_rgb": params["encoder.shape_predictor.shapenerf.fc_rgb.weight"].grad,
+        "grad_mesh_stn_fc": params["encoder.featnet_mesh.stn.fc.weight"].grad,
+    }
+    v_raw, f_raw = ref_harness.read_obj(bottle)
+    save("step_laptopflags_bottle_b2x2",
+         prior_verts=v_raw.astype(np.float32), prior_faces=f_raw.astype(np.int64),
+         input_stats=np.stack([_stats(data[0]), _stats(data[1]), _stats(data[2]), _stats(data[7]), _stats(data[9])]),
+         rotation=rotation.detach().numpy(), translation=translation.detach().numpy(),
+         pred_v=pred_v.detach().numpy(), imatch=imatch.detach().numpy(), imatch_gt=imatch_gt.detach().numpy(),
+         depth_weight=depth_weight.detach().numpy(),
+         stats_img_feat=_stats(img_feat), stats_mesh_feat=_stats(mesh_feat), stats_pointcorr=_stats(pointcorr),
+         stats_match=_stats(match), stats_mask_render=_stats(mask_render), stats_tex_render=_stats(tex_render),
+         stats_depth_render=_stats(depth_render), stats_match_gt=_stats(match_gt), stats_tex_mask=_stats(tex_mask),
+         topk_indices=topk_idx.numpy().astype(np.int16), topk_neg_distance=neg_dist.numpy(),
+         dino_feat_sub=dino_feat[:, ::8, ::4, ::4].numpy(), dino_feat_stats=_stats(dino_feat),
+         **{k: v.detach().numpy() for k, v in grads.items()}, **out)
+    for k, v in sorted(out.items()):
+        print("  %-28s %.9g" % (k, v))
+
+
+GENERATORS = {"softras": gen_softras, "step": gen_step}
 
 
 if __name__ == "__main__":

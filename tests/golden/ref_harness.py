@@ -134,16 +134,16 @@ def read_obj(path):
     return np.asarray(vs, np.float64), np.asarray(fs, np.int64)
 
 
-ROTATE_ANGLE_LOG = []
+PINNED_ANGLE = [None]   # when set, every rotate() call uses this angle (the reference draws it from the host RNG)
 
 
 def _rot90_exact(img, angle, interpolation=None, **kw):
     """torchvision.transforms.functional.rotate stand-in: exact for multiples of 90 degrees
     (counter-clockwise, like torchvision); golden runs pin the angle to such a value."""
-    k = int(round(angle / 90.0)) % 4
+    if PINNED_ANGLE[0] is not None:
+        angle = PINNED_ANGLE[0]
     assert abs(angle - 90.0 * round(angle / 90.0)) < 1e-6, "golden runs must use multiples of 90"
-    ROTATE_ANGLE_LOG.append(angle)
-    return torch.rot90(img, k, dims=(-2, -1))
+    return torch.rot90(img, int(round(angle / 90.0)) % 4, dims=(-2, -1))
 
 
 def _make_resnet18_factory():

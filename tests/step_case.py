@@ -1,0 +1,68 @@
+"""tests/step_case.py -- builds the build's MeshNet in the exact configuration of the golden step
+(tests/golden/step_*.npz, recorded from the reference by make_golden.py gen_step)."""
+import numpy as np
+import torch
+
+import golden_io
+import recipe
+import synth
+
+
+def build(device="cpu", case="step_laptopflags_bottle_b2x2"):
+    import scp_amd.dino as dino
+    from scp_amd.flags import Options
+    from scp_amd.model import MeshNet
+    d = golden_io.load(case)
+    dino.ALLOW_RANDOM_INIT = True
+    opts = Options("laptop_wild6d", batch_size=2, repeat=2, train=True, vis_freq=10 ** 9)
+    torch.manual_seed(0)
+    model = MeshNet(opts, prior=(d["prior_verts"], d["prior_faces"]))
+    recipe.load_recipe(model)
+    model.encoder.random_jitter = torch.nn.Identity()      # golden runs: jitter off on both sides
+    model.rotation_angle = 90.0                            # ... and the rotation-cycle angle pinned
+    k = model.mesh.symm_rots.shape[0]
+    fi, bary = recipe.symmetry_sample(k * 4, 10000, model.mesh.num_faces)
+    model = model.to(device).train()
+    model.mesh.sample_override = (fi.to(device), bary.to(device))
+    model.pretrain_corr_net.topk_override = torch.tensor(d["topk_indices"].astype(np.int64), device=device)
+    model.iters = 0
+    data = synth.make_batch(2, 2, 256, seed=0, device=device)
+    return model, data, d
+
+
+def stats(t):
+    t = t.detach().double().cpu()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
+
+
+def run_and_compare(model, data, d, rtol_loss=1e-4, grad_rel_l2=1e-3):
+    """north_star: every loss scalar and the predicted pose within 1e-4 relative of the reference;
+    gradients: relative L2 (summation orders differ between CPU BLAS / MIOpen / wavefront trees)"""
+    # inputs really are the recorded ones
+    got_in = np.stack([stats(data[0]), stats(data[1]), stats(data[2]), stats(data[7]), stats(data[9])])
+    np.testing.assert_allclose(got_in, d["input_stats"], rtol=1e-6)
+    total, aux = model(data)
+    total.mean().backward()
+    report = {}
+    for k, v in aux.items():
+        ref = float(d["aux_" + k])
+        got = float(v)
+        report[k] = (got, ref)
+        assert abs(got - ref) <= rtol_loss * max(abs(ref), 1e-6), "%s: %.9g vs reference %.9g" % (k, got, ref)
+    rot, trans = model.last_pose
+    np.testing.assert_allclose(rot.cpu().numpy(), d["rotation"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(trans.cpu().numpy(), d["translation"], rtol=1e-4, atol=1e-5)
+    params = dict(model.named_parameters())
+    names = {"grad_mean_v": "mesh.mean_v", "grad_resnet_conv1": "encoder.backbone.resnet.conv1.weight",
+             "grad_featnet_proj": "encoder.featnet.proj.weight",
+             "grad_pose_trans": "encoder.pose_predictor.trans_pred_layer.weight",
+             "grad_shapenerf_fc_rgb": "encoder.shape_predictor.shapenerf.fc_rgb.weight",
+             "grad_mesh_stn_fc": "encoder.featnet_mesh.stn.fc.weight"}
+    for key, pname in names.items():
+        g = params[pname].grad.detach().double().cpu().numpy().ravel()
+        r = d[key].astype(np.float64).ravel()
+        rel = np.linalg.norm(g - r) / np.linalg.norm(r)
+        cos = g @ r / (np.linalg.norm(g) * np.linalg.norm(r))
+        report[key] = (rel, cos)
+        assert rel <= grad_rel_l2 and cos >= 0.9999, "%s: rel L2 %.3e cos %.7f" % (key, rel, cos)
+    return report
