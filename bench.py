@@ -1,0 +1,216 @@
+"""bench.py -- train iterations/s of the self-corr-pose hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full training iteration of the reference's loop body (model/trainer.py:118-125):
+MeshNet.forward (encoder, feature<->vertex correspondence, 4 SoftRas passes, DINO cycle loss,
+rotation cycle loss, all losses) + backward + gradient all-reduce (N>1) + per-group clipping +
+AdamW/OneCycle.  Workload = BASELINE.json's metric configuration: B = batch_size 8 x repeat 4 = 32
+images of 256x256 per GPU, 642-vertex / 1280-face prior mesh ("1280" mesh), the
+laptop_wild6d flag set, synthetic batch (tests/synth.py), random-init weights (no network for the
+ImageNet / DINO checkpoints).  Weak scaling: every rank processes its own 32 images; `value` counts
+32-image iterations completed by all ranks per second.
+
+Extra JSON objects (tier contract):
+  roofline      the dominant hand-written kernel of the step (SoftRas backward of the sigma=1e-3
+                texture pass).  `achieved` = algorithmic HBM bytes of one launch / its mean duration
+                measured with HIP events on the launch stream inside the timed region.  The kernel
+                is fp32-VALU bound on active (pixel,face) pairs, not HBM bound, so the
+                pair rate is reported beside it under "valu".
+  cpu_baseline  the same step on the host CPU cores (torch CPU + the C oracle rasteriser), rank 0,
+                N=1 only, on a bounded sample (one B=4 iteration), scaled to 32-image iterations/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "self-corr-pose_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s HBM3E
+FP32_VALU_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 vector peak
+FLOP_PER_PAIR_BWD = 220.0   # ~220 flop per active pair in the backward
+
+
+class KernelTimer:
+    """HIP-event timing of one native entry point on torch's current stream (the stream the C ABI
+    launches on)."""
+
+    def __init__(self, module, name, select):
+        self.module, self.name, self.select = module, name, select
+        self.orig = getattr(module, name)
+        self.events = []
+        self.enabled = False
+
+    def __enter__(self):
+        def wrapped(*args):
+            if not (self.enabled and self.select(*args)):
+                return self.orig(*args)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.orig(*args)
+            e1.record()
+            self.events.append((e0, e1))
+            return out
+        setattr(self.module, self.name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        setattr(self.module, self.name, self.orig)
+
+    def mean_ms(self):
+        return float(np.mean([a.elapsed_time(b) for a, b in self.events])) if self.events else None
+
+
+def build_trainer(device, world, batch_size=8, repeat=4, seed=0):
+    import scenes
+    import scp_amd.dino as dino
+    from scp_amd.flags import Options
+    from scp_amd.trainer import Trainer
+    dino.ALLOW_RANDOM_INIT = True
+    opts = Options("laptop_wild6d", batch_size=batch_size, repeat=repeat, train=True, ngpu=world, vis_freq=10 ** 9)
+    torch.manual_seed(seed)
+    return Trainer(opts, prior=scenes.bottle_like(3), device=device), opts
+
+
+def cpu_baseline(sample_bs=2, sample_repeat=2):
+    """the step on the host cores: torch-CPU for the networks/correspondence, the C oracle for the
+    rasteriser (tests/oracle_backend.py).  Checker code, used here only as the thing being timed
+    for the baseline -- never on the product path."""
+    import oracle_backend
+    import synth
+    from scp_amd.soft_renderer.cuda import soft_rasterize as native
+    saved = (native.forward_soft_rasterize, native.backward_soft_rasterize)
+    native.forward_soft_rasterize = oracle_backend.forward_soft_rasterize
+    native.backward_soft_rasterize = oracle_backend.backward_soft_rasterize
+    try:
+        threads = torch.get_num_threads()
+        tr, _ = build_trainer("cpu", 1, sample_bs, sample_repeat)
+        data = synth.make_batch(sample_bs, sample_repeat, 256, seed=0, device="cpu")
+        tr.step(data)  # warm-up (allocator, oneDNN primitive caches)
+        t0 = time.perf_counter()
+        tr.step(data)
+        dt = time.perf_counter() - t0
+    finally:
+        native.forward_soft_rasterize, native.backward_soft_rasterize = saved
+    n_img = sample_bs * sample_repeat
+    return {"value": (n_img / 32.0) / dt, "unit": "train iters/sec (32-image iterations)", "cores": threads,
+            "kind": "port", "sample": "1 full training step at B=%d (256x256, 642v/1280f), %.2f s, scaled by %d/32"
+                                      % (n_img, dt, n_img)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    import synth
+    from scp_amd.soft_renderer.cuda import soft_rasterize as native
+    tr, opts = build_trainer(device, world)
+    if tr.reducer is not None:
+        tr.reducer.broadcast_parameters(0)
+    data = synth.make_batch(opts.batch_size, opts.repeat, opts.img_size, seed=100 + rank, device=device)
+    n_faces, n_verts = tr.model.mesh.num_faces, tr.model.mesh.num_verts
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # dominant hand-written kernel: backward of the sigma=1e-3 softmax texture pass
+    is_softtex = lambda *a: abs(a[12] - 1e-3) < 1e-9   # sigma_val of backward_soft_rasterize(...)
+    with KernelTimer(native, "backward_soft_rasterize", is_softtex) as kt:
+        for _ in range(args.warmup):
+            tr.step(data)
+        sync()
+        kt.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.step(data)
+        sync()
+        elapsed = time.perf_counter() - t0
+        kt.enabled = False
+        kernel_ms = kt.mean_ms()
+
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        B, S = opts.batch_size * opts.repeat, opts.img_size
+        # algorithmic bytes of one softtex backward launch: faces + textures +
+        # faces_info in, soft_colors + aggrs_info + grad_soft_colors in, grad_faces + grad_textures out
+        alg_bytes = 4.0 * B * (n_faces * (9 + 9 + 27) + S * S * (4 + 2 + 4) + n_faces * (9 + 9))
+        roofline = None
+        if kernel_ms:
+            fv = None
+            pairs = None
+            try:  # pairs_active of this batch for the VALU-side figure
+                with torch.no_grad():
+                    from scp_amd.losses import project_for_render
+                    m = tr.model
+                    mean_v = m.mesh.mean_v[None].expand(B, -1, -1)
+                    _, _, pred_v, rot, trans, _ = m.encoder(data[0], mean_v, data[9], data[7])
+                    pv = project_for_render(pred_v, data[7], data[9], rot, trans)
+                    pv = torch.stack((pv[..., 0], pv[..., 1], pv[..., 2] + 2.7320508), -1)
+                    fv = pv[:, m.mesh.faces].reshape(B, n_faces, 9).contiguous()
+                    pairs = native.count_pairs(fv, S, 1e-3, float(np.log(1. / 1e-4 - 1.)))
+            except Exception as e:  # instrumentation only
+                pairs = None
+            achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+            roofline = {"kernel": "raster_backward_kernel<softmax,vertex> (sigma=1e-3 texture pass)",
+                        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes}
+            if pairs:
+                tf = pairs * FLOP_PER_PAIR_BWD / (kernel_ms * 1e-3) / 1e12
+                roofline["valu"] = {"pairs_active": pairs, "flop_per_pair": FLOP_PER_PAIR_BWD,
+                                    "achieved_TFLOPs": tf, "peak_TFLOPs": FP32_VALU_PEAK_TF,
+                                    "frac": tf / FP32_VALU_PEAK_TF}
+        out = {
+            "metric": "train iters/sec (batch=32, 256x256, 1280-face/642-vert mesh)",
+            "value": world * args.steps / elapsed, "unit": "iters/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: B=32 (batch_size 8 x repeat 4) 256x256 per GPU, 642v/1280f mesh, "
+                                   "laptop_wild6d flags, full training step (fwd+bwd+clip+AdamW)",
+                       "images_per_sec": world * args.steps * B / elapsed, "parallelism": "dp%d" % world},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,40 @@
+"""G7 on the GPU: the full training forward/backward with the HIP kernels in the loop reproduces
+the reference's losses / poses / gradients recorded in tests/golden/step_*.npz.
+
+Tolerances: north_star's 1e-4 relative on every loss scalar and on the predicted pose; gradients are
+compared in relative L2 (1e-3) + cosine (0.9999): MIOpen/rocBLAS and the wavefront reductions sum
+in different orders than the CPU reference."""
+import pytest
+import torch
+
+import step_case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_full_step_matches_reference_on_gpu():
+    model, data, d = step_case.build("cuda")
+    from scp_amd.soft_renderer.cuda import soft_rasterize as native
+    assert native.forward_soft_rasterize.__module__.startswith("scp_amd"), "HIP path must be the one that runs"
+    report = step_case.run_and_compare(model, data, d)
+    print({k: v for k, v in report.items()})
+
+
+def test_trainer_step_runs_and_updates():
+    import scp_amd.dino as dino
+    from scp_amd.flags import Options
+    from scp_amd.trainer import Trainer
+    import scenes
+    import synth
+    dino.ALLOW_RANDOM_INIT = True
+    opts = Options("laptop_wild6d", batch_size=2, repeat=2, train=True, total_iters=100)
+    torch.manual_seed(0)
+    tr = Trainer(opts, prior=scenes.bottle_like(3), device="cuda")
+    data = synth.make_batch(2, 2, 256, seed=1, device="cuda")
+    before = tr.model.encoder.featnet.proj.weight.detach().clone()
+    losses = []
+    for _ in range(3):
+        total, aux, grad = tr.step(data)
+        losses.append(float(total))
+    assert all(l == l and abs(l) < 1e3 for l in losses)
+    assert not torch.equal(before, tr.model.encoder.featnet.proj.weight)
