@@ -35,7 +35,10 @@ class PretrainedCorrespondence(nn.Module):
         if opts.divide_fn not in ("frame", "instance", "both"):
             raise ValueError
         self.divide_kind = opts.divide_fn
-        self.topk_override = None   # test hook: indices [N,k] (topk tie-breaking is backend-defined)
+        # test hooks (discrete selections are backend-defined at ties / near-ties)
+        self.topk_override = None   # indices [N,k]
+        self.nn_override = None     # (bw [N,P], fw [N,P]) mutual-NN argmax indices
+        self.last_nn = None
 
     def half_grid(self, bsz):
         grid = self.meshgrid.reshape(2, self.hf, self.wf)[None].expand(bsz, -1, -1, -1)
@@ -54,6 +57,9 @@ class PretrainedCorrespondence(nn.Module):
         src_mask_down = F.interpolate(src_mask[:, None], (fs, fs), mode="nearest").reshape(bsz, -1)
         tgt_mask_down = F.interpolate(tgt_mask[:, None], (fs, fs), mode="nearest").reshape(bsz, -1)
         bw, fw = ops.mutual_nn(src_feat, tgt_feat, src_mask_down, tgt_mask_down)
+        self.last_nn = (bw, fw)
+        if self.nn_override is not None:
+            bw, fw = self.nn_override
         cy = torch.gather(fw, -1, bw)
         grid = grid.reshape(bsz, 2, -1)
         pick = lambda idx: torch.gather(grid, -1, idx[:, None].expand(-1, 2, -1))

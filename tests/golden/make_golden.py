@@ -212,10 +212,23 @@ def gen_step():
 
     torch.topk = topk_spy
     dino_fwd = model.pretrain_corr_net.net.forward
+    # mutual-NN argmax indices + top-2 gaps of the DINO score matrix (near-ties may flip on another backend)
+    max_orig = torch.Tensor.max
+
+    def max_spy(self, *a, **kw):
+        out = max_orig(self, *a, **kw)
+        if self.dim() == 3 and self.shape[1] == self.shape[2] == 1024 and len(a) == 1 and len(cap.get("nn", [])) < 2:
+            top2 = topk_orig(self, 2, dim=a[0]).values
+            cap.setdefault("nn", []).append((out.indices.clone(), (top2.select(a[0], 0) - top2.select(a[0], 1)).clone(),
+                                             top2.select(a[0], 0).clone()))
+        return out
+
+    torch.Tensor.max = max_spy
     try:
         total, aux = model(data)
     finally:
         torch.topk = topk_orig
+        torch.Tensor.max = max_orig
     total.mean().backward()
 
     img_feat, mesh_feat, pred_v, rotation, translation, scale = cap["enc"]
@@ -246,6 +259,8 @@ def gen_step():
          stats_match=_stats(match), stats_mask_render=_stats(mask_render), stats_tex_render=_stats(tex_render),
          stats_depth_render=_stats(depth_render), stats_match_gt=_stats(match_gt), stats_tex_mask=_stats(tex_mask),
          topk_indices=topk_idx.numpy().astype(np.int16), topk_neg_distance=neg_dist.numpy(),
+         nn_bw=cap["nn"][0][0].numpy().astype(np.int16), nn_bw_gap=cap["nn"][0][1].numpy(), nn_bw_top=cap["nn"][0][2].numpy(),
+         nn_fw=cap["nn"][1][0].numpy().astype(np.int16), nn_fw_gap=cap["nn"][1][1].numpy(), nn_fw_top=cap["nn"][1][2].numpy(),
          dino_feat_sub=dino_feat[:, ::8, ::4, ::4].numpy(), dino_feat_stats=_stats(dino_feat),
          **{k: v.detach().numpy() for k, v in grads.items()}, **out)
     for k, v in sorted(out.items()):

@@ -25,6 +25,8 @@ def build(device="cpu", case="step_laptopflags_bottle_b2x2"):
     model = model.to(device).train()
     model.mesh.sample_override = (fi.to(device), bary.to(device))
     model.pretrain_corr_net.topk_override = torch.tensor(d["topk_indices"].astype(np.int64), device=device)
+    model.pretrain_corr_net.nn_override = (torch.tensor(d["nn_bw"].astype(np.int64), device=device),
+                                           torch.tensor(d["nn_fw"].astype(np.int64), device=device))
     model.iters = 0
     data = synth.make_batch(2, 2, 256, seed=0, device=device)
     return model, data, d
@@ -66,3 +68,20 @@ def run_and_compare(model, data, d, rtol_loss=1e-4, grad_rel_l2=1e-3):
         report[key] = (rel, cos)
         assert rel <= grad_rel_l2 and cos >= 0.9999, "%s: rel L2 %.3e cos %.7f" % (key, rel, cos)
     return report
+
+
+def check_mutual_nn_validity(model, d, rel_gap=2e-4, max_flip_frac=0.10):
+    """the build's own mutual-NN argmax (computed on this backend, before the override)
+    may differ from the reference's only at near-ties of the reference's score matrix"""
+    bw, fw = model.pretrain_corr_net.last_nn
+    out = {}
+    for name, got in (("bw", bw), ("fw", fw)):
+        ref = d["nn_" + name].astype(np.int64)
+        gap, top = d["nn_%s_gap" % name], d["nn_%s_top" % name]
+        flips = got.cpu().numpy() != ref
+        live = top > -1e4                      # fully masked rows/columns are all-ties by construction
+        bad = flips & live & (gap > rel_gap * np.abs(top))
+        out[name] = float((flips & live).sum()) / max(live.sum(), 1)
+        assert not bad.any(), "%s: %d argmax flips at non-ties (max gap %.3g)" % (name, bad.sum(), gap[bad].max())
+        assert out[name] <= max_flip_frac
+    return out

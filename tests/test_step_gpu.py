@@ -17,6 +17,7 @@ def test_full_step_matches_reference_on_gpu():
     from scp_amd.soft_renderer.cuda import soft_rasterize as native
     assert native.forward_soft_rasterize.__module__.startswith("scp_amd"), "HIP path must be the one that runs"
     report = step_case.run_and_compare(model, data, d)
+    report["nn_flip_fraction"] = step_case.check_mutual_nn_validity(model, d)
     print({k: v for k, v in report.items()})
 
 
