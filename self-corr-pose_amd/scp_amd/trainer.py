@@ -27,6 +27,9 @@ class Trainer:
     def __init__(self, opts, prior=None, device=None, process_group=None, sync_bn=False):
         self.opts = opts
         self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        # MIOpen solver search, as the reference does (train.py:21 cudnn.benchmark = True); without
+        # it MIOpen's immediate mode falls back to naive fp32 convolutions for several layers
+        torch.backends.cudnn.benchmark = True
         self.model = MeshNet(opts, prior)
         if opts.model_path:
             self.model.load_network(opts.model_path)
