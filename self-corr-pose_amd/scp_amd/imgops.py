@@ -57,12 +57,13 @@ def _hsv_to_rgb(img):
     p = (v * (1.0 - s)).clamp(0, 1)
     q = (v * (1.0 - s * f)).clamp(0, 1)
     t = (v * (1.0 - s * (1.0 - f))).clamp(0, 1)
-    mask = i.unsqueeze(-3) == torch.arange(6, device=img.device).view(-1, 1, 1)
-    a1 = torch.stack((v, q, p, p, t, v), -3)
-    a2 = torch.stack((t, v, v, q, p, p), -3)
-    a3 = torch.stack((p, p, t, v, v, q), -3)
-    a4 = torch.stack((a1, a2, a3), -4)
-    return torch.einsum("...ijk,...xijk->...xjk", mask.to(img.dtype), a4)
+    # sector table (torchvision builds the same table and contracts it with a one-hot einsum, which
+    # lands on a degenerate K=6 batched GEMM; a gather is the same selection)
+    idx = i.to(torch.int64).unsqueeze(-3)
+    r = torch.gather(torch.stack((v, q, p, p, t, v), -3), -3, idx)
+    g = torch.gather(torch.stack((t, v, v, q, p, p), -3), -3, idx)
+    b = torch.gather(torch.stack((p, p, t, v, v, q), -3), -3, idx)
+    return torch.cat((r, g, b), -3)
 
 
 class ColorJitter(nn.Module):

@@ -64,3 +64,13 @@ def vertex_bridge_match(pc_src, pc_tgt_sel, keep_src, keep_tgt, grid, tau_img, t
     corr = p_mesh.bmm(p_img.transpose(1, 2))                       # N,P,K
     corr = corr / (corr.sum(1, keepdim=True) + 1e-5)
     return grid.bmm(corr)
+
+
+def pool2x2_scores(pc, hf, wf):
+    """pc [B, hf*wf, V] -> [B, (hf/2)*(wf/2), V]: 2x2 spatial mean of every vertex' score map.
+    The reference reaches it through a bilinear F.interpolate to half resolution of the permuted
+    [B,V,hf,wf] view (pretrained_corr.py:120-123), which for an exact factor 2 with
+    align_corners=False is this mean (weights 1/4 each; last-ulp rounding order differs)."""
+    b, _, v = pc.shape
+    x = pc.reshape(b, hf // 2, 2, wf // 2, 2, v)
+    return ((x[:, :, 0, :, 0] + x[:, :, 0, :, 1]) * 0.5 * 0.5 + (x[:, :, 1, :, 0] + x[:, :, 1, :, 1]) * 0.5 * 0.5).reshape(b, -1, v)

@@ -89,8 +89,7 @@ class PretrainedCorrespondence(nn.Module):
             feats[src_idx], feats[tgt_idx], mask[src_idx], mask[tgt_idx], grid)
 
         # bilinear half-resolution (= exact 2x2 mean) of the score maps, once per image
-        pooled = F.interpolate(pointcorr.permute(0, 2, 1).reshape(-1, num_verts, self.hf, self.wf),
-                               (hh, wh), mode="bilinear").reshape(-1, num_verts, hh * wh).permute(0, 2, 1)  # b,p,v
+        pooled = ops.pool2x2_scores(pointcorr, self.hf, self.wf)                                    # b,p,v
         pc_src = pooled[src_idx]
         pc_tgt_sel = torch.gather(pooled[tgt_idx], 1, indices_tgt[:, :, None].expand(-1, -1, num_verts))
         keep = depth_weight >= 0.5
