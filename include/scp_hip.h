@@ -16,6 +16,8 @@
 #ifndef SCP_HIP_H
 #define SCP_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -75,6 +77,41 @@ int scp_soft_rasterize_backward(const float* faces, const float* textures, const
  * uint64, caller-zeroed. */
 int scp_soft_rasterize_count_pairs(const float* faces, unsigned long long* count,
                                    const scp_raster_params* p, void* stream);
+
+/* ---- dense correspondence: masked softmax / soft-argmax over an all-pairs score tensor ------------
+ * scores S[N,P,Q], Q contiguous.  A score is "masked" (treated as the constant -1e5, like
+ * model/module/correspondence.py:44 and pretrained_corr.py:86) when rowmask[n,p] <= 0 or
+ * colmask[n,q] <= 0; either mask pointer may be NULL.
+ *
+ * Column soft-argmax, replaces  softmax(tau*S, dim=P) followed by  grid @ P
+ * (correspondence.py:47,52 `imatch`; :107-110 `cycle_match`; pretrained_corr.py:124,136):
+ *   out[n,:,q]      = sum_p grid[:,p] * softmax_p(tau * S[n,p,q])          [N,2,Q]
+ *   colstats[n,:,q] = (max_p tau*S, sum_p exp(tau*S - max))                [N,2,Q]  (for backward)
+ *   scores_masked_out (nullable, may alias scores): S with masked entries set to -1e5.
+ *   grid is [2,P] (grid_batched = 0) or [N,2,P]; workspace >= scp_softargmax_cols_workspace() bytes. */
+size_t scp_softargmax_cols_workspace(int N, int P, int Q);
+int scp_softargmax_cols_forward(const float* scores, float* scores_masked_out, const float* rowmask,
+                                const float* colmask, const float* grid, int grid_batched, float tau,
+                                int N, int P, int Q, float* out, float* colstats, float* workspace,
+                                size_t workspace_bytes, void* stream);
+
+/* Row softmax with a weighted sum, replaces  softmax(tau*S, dim=Q) @ weights
+ * (correspondence.py:48,53 `match` with weights = pred_v [N,Q,3]):
+ *   out[n,p,:]      = sum_q softmax_q(tau*S[n,p,q]) * weights[n,q,:]       [N,P,W], W in {2,3}
+ *   rowstats[n,p,:] = (max_q tau*S, sum_q exp(tau*S - max))                [N,P,2] */
+int scp_softmax_rows_weighted_forward(const float* scores, const float* weights, int W, float tau, int N,
+                                      int P, int Q, float* out, float* rowstats, void* stream);
+
+/* Fused backward of both reductions w.r.t. the scores (what autograd does through the two softmaxes
+ * and bmm's of correspondence.py:47-53 / :107-110).  Either part is skipped when its stats pointer
+ * is NULL; g_scores_in (nullable) is added; masked entries get 0.
+ *   g_scores_out = g_in + tau_c P_c (g_c.grid_p - g_c.out_c) + tau_r P_r (g_r.w_q - g_r.out_r) */
+int scp_dual_softmax_backward(const float* scores, const float* rowmask, const float* colmask,
+                              const float* g_scores_in, float* g_scores_out, const float* colstats,
+                              const float* col_out, const float* g_col_out, const float* grid,
+                              int grid_batched, float tau_c, const float* rowstats, const float* row_out,
+                              const float* g_row_out, const float* weights, int W, float tau_r, int N,
+                              int P, int Q, void* stream);
 
 #ifdef __cplusplus
 }

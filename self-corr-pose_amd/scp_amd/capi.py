@@ -27,6 +27,8 @@ class RasterParams(ctypes.Structure):
 
 
 _P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
 _RP = ctypes.POINTER(RasterParams)
 
 # name -> (restype, argtypes); must list every symbol include/scp_hip.h declares
@@ -36,6 +38,11 @@ SYMBOLS = {
     "scp_soft_rasterize_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _RP, _P]),
     "scp_soft_rasterize_backward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _RP, _P]),
     "scp_soft_rasterize_count_pairs": (ctypes.c_int, [_P, _P, _RP, _P]),
+    "scp_softargmax_cols_workspace": (ctypes.c_size_t, [_I, _I, _I]),
+    "scp_softargmax_cols_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P, _P, _P, ctypes.c_size_t, _P]),
+    "scp_softmax_rows_weighted_forward": (ctypes.c_int, [_P, _P, _I, _F, _I, _I, _I, _P, _P, _P]),
+    "scp_dual_softmax_backward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _F,
+                                                _I, _I, _I, _P]),
 }
 
 _lib = None
@@ -78,3 +85,8 @@ def dev_ptr(t, name):
     if t.dtype != torch.float32:
         raise RuntimeError("%s must be float32 (the gfx950 kernels are fp32-only)" % name)
     return ctypes.c_void_p(t.data_ptr())
+
+
+def opt_ptr(t, name):
+    """like dev_ptr, but None -> NULL"""
+    return ctypes.c_void_p(0) if t is None else dev_ptr(t, name)

@@ -1,0 +1,106 @@
+"""scp_amd/corr_ops.py -- autograd nodes over the HIP correspondence kernels (csrc/corr.hip, C ABI in
+include/scp_hip.h).  GPU tensors only; scp_amd.ops routes here."""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import capi
+
+
+def _ws(n, p, q, device):
+    nbytes = capi.lib().scp_softargmax_cols_workspace(n, p, q)
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device), nbytes
+
+
+def cols_forward(scores, rowmask, colmask, grid, tau, masked_out=None):
+    n, p, q = scores.shape
+    out = torch.empty(n, 2, q, dtype=torch.float32, device=scores.device)
+    stats = torch.empty(n, 2, q, dtype=torch.float32, device=scores.device)
+    ws, nbytes = _ws(n, p, q, scores.device)
+    code = capi.lib().scp_softargmax_cols_forward(
+        capi.dev_ptr(scores, "scores"), capi.opt_ptr(masked_out, "scores_masked_out"),
+        capi.opt_ptr(rowmask, "rowmask"), capi.opt_ptr(colmask, "colmask"), capi.dev_ptr(grid, "grid"),
+        int(grid.dim() == 3), float(tau), n, p, q, capi.dev_ptr(out, "out"), capi.dev_ptr(stats, "colstats"),
+        capi.dev_ptr(ws, "workspace"), ctypes.c_size_t(nbytes), capi.current_stream())
+    capi.check(code, "scp_softargmax_cols_forward")
+    return out, stats
+
+
+def rows_forward(scores, weights, tau):
+    n, p, q = scores.shape
+    w = weights.shape[-1]
+    out = torch.empty(n, p, w, dtype=torch.float32, device=scores.device)
+    stats = torch.empty(n, p, 2, dtype=torch.float32, device=scores.device)
+    code = capi.lib().scp_softmax_rows_weighted_forward(
+        capi.dev_ptr(scores, "scores"), capi.dev_ptr(weights, "weights"), w, float(tau), n, p, q,
+        capi.dev_ptr(out, "out"), capi.dev_ptr(stats, "rowstats"), capi.current_stream())
+    capi.check(code, "scp_softmax_rows_weighted_forward")
+    return out, stats
+
+
+def dual_backward(scores, rowmask, colmask, g_in, col=None, row=None):
+    """col = (stats, out, g_out, grid, tau) or None; row = (stats, out, g_out, weights, tau) or None"""
+    n, p, q = scores.shape
+    g = torch.empty_like(scores)
+    cs, co, gco, grid, tau_c = col if col is not None else (None, None, None, None, 0.)
+    rs, ro, gro, wts, tau_r = row if row is not None else (None, None, None, None, 0.)
+    code = capi.lib().scp_dual_softmax_backward(
+        capi.dev_ptr(scores, "scores"), capi.opt_ptr(rowmask, "rowmask"), capi.opt_ptr(colmask, "colmask"),
+        capi.opt_ptr(g_in, "g_scores_in"), capi.dev_ptr(g, "g_scores_out"),
+        capi.opt_ptr(cs, "colstats"), capi.opt_ptr(co, "col_out"), capi.opt_ptr(gco, "g_col_out"),
+        capi.opt_ptr(grid, "grid"), int(grid is not None and grid.dim() == 3), float(tau_c),
+        capi.opt_ptr(rs, "rowstats"), capi.opt_ptr(ro, "row_out"), capi.opt_ptr(gro, "g_row_out"),
+        capi.opt_ptr(wts, "weights"), 3 if wts is None else wts.shape[-1], float(tau_r), n, p, q,
+        capi.current_stream())
+    capi.check(code, "scp_dual_softmax_backward")
+    return g
+
+
+def _c(t):
+    return None if t is None else t.contiguous().float()
+
+
+class FeatureVertexMatch(Function):
+    """pointcorr [B,P,V], match [B,P,3], imatch [B,2,V] from unit features (correspondence.py:42-53)"""
+
+    @staticmethod
+    def forward(ctx, img_feat, mesh_feat, mask_down, verts, grid, tau_img, tau_mesh):
+        img_feat, mesh_feat = img_feat.contiguous(), mesh_feat.contiguous()
+        mask_down, verts, grid = _c(mask_down), _c(verts), _c(grid)
+        pc = torch.bmm(img_feat.transpose(1, 2), mesh_feat.transpose(1, 2))       # [B,P,V], library GEMM (K = C)
+        imatch, cstats = cols_forward(pc, mask_down, None, grid, tau_mesh, masked_out=pc)  # masks in place
+        match, rstats = rows_forward(pc, verts, tau_img)
+        ctx.save_for_backward(img_feat, mesh_feat, mask_down, verts, grid, pc, imatch, cstats, match, rstats)
+        ctx.taus = (float(tau_img), float(tau_mesh))
+        return pc, match, imatch
+
+    @staticmethod
+    def backward(ctx, g_pc, g_match, g_imatch):
+        img_feat, mesh_feat, mask_down, verts, grid, pc, imatch, cstats, match, rstats = ctx.saved_tensors
+        tau_img, tau_mesh = ctx.taus
+        col = (cstats, imatch, _c(g_imatch), grid, tau_mesh) if g_imatch is not None else None
+        row = (rstats, match, _c(g_match), verts, tau_img) if g_match is not None else None
+        ds = dual_backward(pc, mask_down, None, _c(g_pc), col, row)                 # [B,P,V]
+        dst = ds.transpose(1, 2)
+        g_img = torch.bmm(mesh_feat.transpose(1, 2), dst) if ctx.needs_input_grad[0] else None      # [B,C,P]
+        g_mesh = torch.bmm(dst, img_feat.transpose(1, 2)) if ctx.needs_input_grad[1] else None      # [B,V,C]
+        return g_img, g_mesh, None, None, None, None, None
+
+
+class ColsSoftArgmax(Function):
+    """out [N,2,Q] = grid @ softmax_P(tau * masked(scores))"""
+
+    @staticmethod
+    def forward(ctx, scores, rowmask, colmask, grid, tau):
+        scores, rowmask, colmask, grid = scores.contiguous(), _c(rowmask), _c(colmask), _c(grid)
+        out, stats = cols_forward(scores, rowmask, colmask, grid, tau)
+        ctx.save_for_backward(scores, rowmask, colmask, grid, out, stats)
+        ctx.tau = float(tau)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        scores, rowmask, colmask, grid, out, stats = ctx.saved_tensors
+        g = dual_backward(scores, rowmask, colmask, None, (stats, out, _c(g_out), grid, ctx.tau), None)
+        return g, None, None, None, None

@@ -1,15 +1,17 @@
 """scp_amd/ops.py -- the dense correspondence operators of the step, behind one small interface.
 
-Each function states the tensor contract once; Correspondence / PretrainedCorrespondence call these
-and nothing else for all-pairs work.  GPU tensors run the hand-written HIP kernels of
-csrc/ (through scp_amd.capi); the formulations below in plain torch ops are the exact definition of
-every operator and run for non-GPU tensors (host-logic tests).
+Each function states its tensor contract once; Correspondence / PretrainedCorrespondence call these
+and nothing else for all-pairs work.  GPU tensors run the hand-written HIP kernels (csrc/corr.hip via
+scp_amd.corr_ops); non-GPU tensors evaluate the plain-torch definition written next to it (host-logic
+tests on machines without a GPU; this is stock PyTorch, not the oracle).
 
 Reference call sites: model/module/correspondence.py:42-53 (feature_vertex_match), :58-60
 (nearest_vertex), :105-110 (pixel_pixel_softargmax); model/module/pretrained_corr.py:85-102
-(mutual_nn_topk), :120-137 (vertex_bridge_match).
+(mutual_nn), :120-137 (pool2x2_scores, vertex_bridge_match).
 """
 import torch
+
+from . import corr_ops
 
 
 def _masked(pc, keep):
@@ -17,10 +19,26 @@ def _masked(pc, keep):
     return torch.where(keep, pc, torch.full_like(pc, -1e5))
 
 
+def cols_softargmax(scores, rowmask, colmask, grid, tau):
+    """scores [N,P,Q]; rowmask [N,P] / colmask [N,Q] or None (entry masked to -1e5 where a mask is 0);
+    grid [2,P] or [N,2,P]  ->  [N,2,Q] = grid @ softmax_P(tau * masked(scores))"""
+    if scores.is_cuda:
+        return corr_ops.ColsSoftArgmax.apply(scores, rowmask, colmask, grid, tau)
+    keep = torch.ones_like(scores, dtype=torch.bool)
+    if rowmask is not None:
+        keep = keep & (rowmask > 0)[:, :, None]
+    if colmask is not None:
+        keep = keep & (colmask > 0)[:, None, :]
+    g = grid if grid.dim() == 3 else grid[None].expand(scores.shape[0], -1, -1)
+    return g.bmm(torch.softmax(tau * _masked(scores, keep), dim=1))
+
+
 def feature_vertex_match(img_feat, mesh_feat, mask_down, verts, grid, tau_img, tau_mesh):
     """img_feat [B,C,P], mesh_feat [B,V,C], mask_down [B,P], verts [B,V,3] (no grad), grid [2,P]
     -> pointcorr [B,P,V] (masked scores), match [B,P,3] = softmax_V(tau_img*pc) @ verts,
        imatch [B,2,V] = grid @ softmax_P(tau_mesh*pc)"""
+    if img_feat.is_cuda:
+        return corr_ops.FeatureVertexMatch.apply(img_feat, mesh_feat, mask_down, verts, grid, tau_img, tau_mesh)
     pc = mesh_feat.bmm(img_feat).permute(0, 2, 1)
     pc = _masked(pc, (mask_down > 0)[:, :, None])
     p_mesh = torch.softmax(tau_mesh * pc, dim=1)
@@ -31,7 +49,7 @@ def feature_vertex_match(img_feat, mesh_feat, mask_down, verts, grid, tau_img, t
 
 
 def nearest_vertex(points, verts):
-    """points [B,P,3], verts [B,V,3] -> index [B,P] of the nearest vertex (L2)"""
+    """points [B,P,3], verts [B,V,3] -> index [B,P] of the nearest vertex (L2); eval only"""
     d = points.pow(2).sum(-1)[:, :, None] - 2 * points.bmm(verts.transpose(1, 2)) + verts.pow(2).sum(-1)[:, None, :]
     return d.argmin(2)
 
@@ -40,37 +58,45 @@ def pixel_pixel_softargmax(src_feat, tgt_feat, src_mask, tgt_mask, grid, tau):
     """src/tgt_feat [B,C,P], masks [B,P], grid [B,2,P] -> [B,2,P_tgt] = grid @ softmax_src(tau*pc)
     with pc = src^T tgt masked by src_mask x tgt_mask"""
     pc = src_feat.transpose(1, 2).bmm(tgt_feat)
-    keep = (src_mask[:, :, None] * tgt_mask[:, None, :]) > 0
-    return grid.bmm(torch.softmax(tau * _masked(pc, keep), dim=1))
+    return cols_softargmax(pc, src_mask, tgt_mask, grid, tau)
 
 
 def mutual_nn(src_feat, tgt_feat, src_mask, tgt_mask):
     """src/tgt_feat [N,C,P] -> (bw [N,P_tgt] = argmax over src, fw [N,P_src] = argmax over tgt) of the
-    masked score matrix; ties resolve to the lowest index"""
+    masked score matrix; ties resolve to the lowest index on CPU, backend-defined elsewhere"""
     pc = src_feat.transpose(1, 2).bmm(tgt_feat)
     pc = _masked(pc, (src_mask[:, :, None] * tgt_mask[:, None, :]) > 0)
     return pc.max(1).indices, pc.max(2).indices
-
-
-def vertex_bridge_match(pc_src, pc_tgt_sel, keep_src, keep_tgt, grid, tau_img, tau_mesh):
-    """soft pixel->pixel map through the vertices, evaluated only at the selected target pixels.
-    pc_src [N,P,V] (all source pixels), pc_tgt_sel [N,K,V] (selected target pixels),
-    keep_src/keep_tgt [N,V] bool (vertex visible), grid [N,2,P]
-    -> [N,2,K]: grid @ normalise_columns( softmax_P(tau_mesh*pc_src)*keep_src @ (softmax_V(tau_img*pc_tgt_sel)*keep_tgt)^T )
-    (pretrained_corr.py:123-137; a column of `corr` depends only on its own target pixel, so
-    restricting to the K gathered columns is exact)"""
-    p_mesh = torch.softmax(tau_mesh * pc_src, dim=1) * keep_src[:, None, :]
-    p_img = torch.softmax(tau_img * pc_tgt_sel, dim=2) * keep_tgt[:, None, :]
-    corr = p_mesh.bmm(p_img.transpose(1, 2))                       # N,P,K
-    corr = corr / (corr.sum(1, keepdim=True) + 1e-5)
-    return grid.bmm(corr)
 
 
 def pool2x2_scores(pc, hf, wf):
     """pc [B, hf*wf, V] -> [B, (hf/2)*(wf/2), V]: 2x2 spatial mean of every vertex' score map.
     The reference reaches it through a bilinear F.interpolate to half resolution of the permuted
     [B,V,hf,wf] view (pretrained_corr.py:120-123), which for an exact factor 2 with
-    align_corners=False is this mean (weights 1/4 each; last-ulp rounding order differs)."""
+    align_corners=False is this mean, evaluated in the same order (0.5*(0.5a+0.5b)+0.5*(0.5c+0.5d))."""
     b, _, v = pc.shape
     x = pc.reshape(b, hf // 2, 2, wf // 2, 2, v)
     return ((x[:, :, 0, :, 0] + x[:, :, 0, :, 1]) * 0.5 * 0.5 + (x[:, :, 1, :, 0] + x[:, :, 1, :, 1]) * 0.5 * 0.5).reshape(b, -1, v)
+
+
+def vertex_bridge_match(pooled, src_idx, tgt_idx, tgt_pixels, keep, grid_half, tau_img, tau_mesh):
+    """Soft pixel->pixel map through the vertices, evaluated at the selected target pixels.
+    pooled [B,P,V] per-image pooled scores; src_idx/tgt_idx [N] image pairs; tgt_pixels [N,K] selected
+    target pixels; keep [B,V] bool (vertex visible); grid_half [2,P]  ->  [N,2,K].
+
+    Reference (pretrained_corr.py:123-137):  corr = (softmax_P(tau_mesh*pc_src)*keep_src) @
+    (softmax_V(tau_img*pc_tgt)*keep_tgt)^T, columns normalised by (sum_P + 1e-5), match = grid @ corr,
+    then gathered at tgt_pixels.  Re-associated, exactly the same sums:
+        grid @ corr[:, :, k]  =  sum_v keep_src[v] keep_tgt[v] P_img[k,v] * (grid @ P_mesh)[:, v]
+        sum_P corr[:, :, k]   =  sum_v keep_src[v] keep_tgt[v] P_img[k,v] * (sum_p P_mesh[p,v] = 1)
+    so the [N,P,P] matrix and its 86-134 GFLOP GEMM are never formed; (grid @ P_mesh) is one column
+    soft-argmax per unique image."""
+    num_verts = pooled.shape[-1]
+    mxy = cols_softargmax(pooled, None, None, grid_half, tau_mesh)                       # [B,2,V]
+    pc_tgt_sel = torch.gather(pooled[tgt_idx], 1, tgt_pixels[:, :, None].expand(-1, -1, num_verts))
+    p_img = torch.softmax(tau_img * pc_tgt_sel, dim=2)                                   # [N,K,V]
+    both = (keep[src_idx] & keep[tgt_idx]).to(pooled.dtype)                              # [N,V]
+    p_img = p_img * both[:, None, :]
+    num = mxy[src_idx].bmm(p_img.transpose(1, 2))                                        # [N,2,K]
+    den = p_img.sum(2)[:, None, :] + 1e-5
+    return num / den

@@ -267,7 +267,59 @@ def gen_step():
         print("  %-28s %.9g" % (k, v))
 
 
-GENERATORS = {"softras": gen_softras, "step": gen_step}
+def gen_corr():
+    """G3: the reference's Correspondence.match (correspondence.py:36-73) forward + gradients w.r.t.
+    both feature sets for a fixed random linear loss, and compute_rotation_cycle_loss's all-pairs part
+    via a stub encoder; B=2, 16x16 feature grid, 162 vertices, 16 channels."""
+    flags = ref_harness.install()
+    import config  # noqa: F401
+    from model.module.correspondence import Correspondence
+    flags.corr_h = flags.corr_w = 16
+    flags.n_corr_feat = 16
+    flags.train = True
+    flags.tau_img = flags.tau_mesh = 10.
+    g = torch.Generator().manual_seed(11)
+    B, C, V, P = 2, 16, 162, 256
+    img_feat = F_normalize(torch.randn(B, C, P, generator=g), 1).requires_grad_(True)
+    mesh_feat = F_normalize(torch.randn(B, V, C, generator=g), 2).requires_grad_(True)
+    pred_v = torch.randn(B, V, 3, generator=g) * 0.5
+    mask = (torch.rand(B, 64, 64, generator=g) > 0.35).float()
+    corr = Correspondence(flags)
+    pointcorr, match, imatch, _ = corr.match(img_feat, mesh_feat, mask, pred_v)
+    w_pc = torch.randn(pointcorr.shape, generator=g) * (pointcorr.detach() > -1e4)
+    w_m, w_i = torch.randn(match.shape, generator=g), torch.randn(imatch.shape, generator=g)
+    loss = (pointcorr * w_pc).sum() * 1e-2 + (match * w_m).sum() + (imatch * w_i).sum()
+    loss.backward()
+    save("corr_match_b2", img_feat=img_feat.detach().numpy(), mesh_feat=mesh_feat.detach().numpy(),
+         pred_v=pred_v.numpy(), mask=mask.numpy(), w_pc=w_pc.numpy(), w_match=w_m.numpy(), w_imatch=w_i.numpy(),
+         pointcorr=pointcorr.detach().numpy(), match=match.detach().numpy(), imatch=imatch.detach().numpy(),
+         grad_img_feat=img_feat.grad.numpy(), grad_mesh_feat=mesh_feat.grad.numpy(), meshgrid=corr.meshgrid.numpy())
+
+    # rotation cycle: a stub encoder whose encode_img returns a fixed feature map
+    class Enc:
+        def __init__(self, feat):
+            self.feat = feat
+
+        def encode_img(self, img):
+            return None, self.feat
+
+    ref_harness.PINNED_ANGLE[0] = 270.0
+    src_feat = F_normalize(torch.randn(B, C, P, generator=g), 1).requires_grad_(True)
+    tgt_feat = F_normalize(torch.randn(B, C, P, generator=g), 1).requires_grad_(True)
+    src_img = torch.rand(B, 3, 64, 64, generator=g)
+    loss, cycle_match, cycle_match_gt, tgt_mask_down = corr.compute_rotation_cycle_loss(src_img, mask, src_feat, Enc(tgt_feat))
+    loss.backward()
+    save("corr_rotcycle_b2", src_feat=src_feat.detach().numpy(), tgt_feat=tgt_feat.detach().numpy(), mask=mask.numpy(),
+         src_img=src_img.numpy(), angle=270.0, loss=np.float64(loss.item()), cycle_match=cycle_match.detach().numpy(),
+         cycle_match_gt=cycle_match_gt.numpy(), tgt_mask_down=tgt_mask_down.numpy(),
+         grad_src_feat=src_feat.grad.numpy(), grad_tgt_feat=tgt_feat.grad.numpy())
+
+
+def F_normalize(x, dim):
+    return torch.nn.functional.normalize(x, 2, dim)
+
+
+GENERATORS = {"softras": gen_softras, "step": gen_step, "corr": gen_corr}
 
 
 if __name__ == "__main__":
