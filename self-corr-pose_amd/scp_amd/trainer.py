@@ -37,6 +37,9 @@ class Trainer:
         if sync_bn:
             self.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.model, process_group)
         self.model = self.model.to(self.device)
+        if self.device.type == "cuda":
+            self.model.encoder.backbone.to(memory_format=torch.channels_last)
+            self.model.encoder.featnet.to(memory_format=torch.channels_last)
         self.model.train()
         self.optim = Optimizers(opts, self.model)
         self.reducer = GradientAllReducer(self.model, process_group) if torch.distributed.is_initialized() else None

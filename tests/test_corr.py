@@ -157,7 +157,7 @@ def test_hip_match_vs_oracle_ragged(B, C, P, V):
     w_pc, w_m, w_i = torch.randn(B, P, V, generator=g), torch.randn(B, P, 3, generator=g), torch.randn(B, 2, V, generator=g)
 
     def run(dev, fn):
-        a, b = img.to(dev).requires_grad_(True), mesh.to(dev).requires_grad_(True)
+        a, b = img.detach().clone().to(dev).requires_grad_(True), mesh.detach().clone().to(dev).requires_grad_(True)
         pc, match, imatch = fn(a, b, mask.to(dev), verts.to(dev), grid.to(dev), 10., 10.)
         live = (pc.detach() > -1e4).float()
         ((pc * w_pc.to(dev) * live).sum() * 1e-2 + (match * w_m.to(dev)).sum() + (imatch * w_i.to(dev)).sum()).backward()
@@ -182,7 +182,7 @@ def test_hip_cols_softargmax_masks_and_batched_grid():
     w = torch.randn(N, 2, Q, generator=g)
 
     def run(dev):
-        x = s.to(dev).requires_grad_(True)
+        x = s.detach().clone().to(dev).requires_grad_(True)
         out = ops.cols_softargmax(x, rm.to(dev), cm.to(dev), grid.to(dev), 10.)
         (out * w.to(dev)).sum().backward()
         return out, x.grad

@@ -23,6 +23,52 @@ for _ in range(5):
     tr.step(data)
 torch.cuda.synchronize()
 print("step: %.2f ms" % ((time.perf_counter() - t) / 5 * 1e3))
+# ---- coarse per-stage GPU time (HIP events around the stage entry points) -------------------------
+stages = {}
+
+
+def timed(obj, name, label):
+    fn = getattr(obj, name)
+
+    def wrapper(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*a, **k)
+        e1.record()
+        stages.setdefault(label, []).append((e0, e1))
+        return out
+    setattr(obj, name, wrapper)
+
+
+m = tr.model
+timed(m.encoder, "forward", "fwd encoder (1st pass)")
+timed(m.corr_net, "match", "fwd feature<->vertex match")
+timed(m.renderer, "render_all", "fwd 4 render passes")
+timed(m.mesh, "compute_symmetry_loss", "fwd symmetry loss")
+timed(m.pretrain_corr_net, "compute_cycle_loss", "fwd DINO cycle loss (incl. ViT)")
+timed(m.pretrain_corr_net.net, "forward", "  of which DINO ViT")
+timed(m.corr_net, "compute_rotation_cycle_loss", "fwd rotation cycle (2nd encoder pass)")
+timed(m, "forward", "FORWARD total")
+timed(tr, "collect_grad", "clip + nan guard")
+timed(tr.optim, "step", "AdamW + scheduler")
+e_all0, e_all1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e_all0.record()
+for _ in range(5):
+    tr.step(data)
+e_all1.record()
+torch.cuda.synchronize()
+tot = e_all0.elapsed_time(e_all1) / 5
+print("GPU-timeline step: %.2f ms" % tot)
+acc = 0
+for label, evs in stages.items():
+    ms = sum(a.elapsed_time(b) for a, b in evs) / 5
+    print("  %-42s %7.2f ms" % (label, ms))
+fwd = sum(a.elapsed_time(b) for a, b in stages["FORWARD total"]) / 5
+rest = sum(sum(a.elapsed_time(b) for a, b in stages[k]) / 5 for k in ("clip + nan guard", "AdamW + scheduler"))
+print("  %-42s %7.2f ms" % ("BACKWARD (+zero_grad) = total - fwd - rest", tot - fwd - rest))
+sys.stdout.flush()
+if "--ops" not in sys.argv:
+    sys.exit(0)
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     tr.step(data)
     torch.cuda.synchronize()
