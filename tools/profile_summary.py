@@ -27,5 +27,40 @@ def main(path, top=45):
     print('"TOTAL",%d,%.3f,,100' % (sum(int(r["Calls"]) for r in rows), total / 1e6))
 
 
+def from_trace(path, marker, skip, top=45):
+    """stats of the kernel TRACE restricted to launches after the `skip`-th launch of a kernel whose name
+    contains `marker` (drops warm-up, e.g. MIOpen's solver-search trials)"""
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    seen, t0 = 0, None
+    for r in rows:
+        if marker in r["Kernel_Name"]:
+            seen += 1
+            if seen == skip + 1:
+                t0 = int(r["Start_Timestamp"])
+                break
+    agg = {}
+    for r in rows:
+        if t0 is not None and int(r["Start_Timestamp"]) < t0:
+            continue
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        a = agg.setdefault(r["Kernel_Name"], [0, 0])
+        a[0] += 1
+        a[1] += d
+    total = sum(v[1] for v in agg.values())
+    span = int(rows[-1]["End_Timestamp"]) - (t0 or int(rows[0]["Start_Timestamp"]))
+    print("# kernels after the %d-th launch of *%s*: busy %.1f ms of a %.1f ms window" % (skip, marker, total / 1e6, span / 1e6))
+    print("kernel,calls,total_ms,avg_us,pct")
+    items = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    for k, (c, t) in items[:top]:
+        print('"%s",%d,%.3f,%.1f,%.2f' % (short(k), c, t / 1e6, t / c / 1e3, 100.0 * t / total))
+    rest = items[top:]
+    print('"(%d other kernels)",%d,%.3f,,%.2f' % (len(rest), sum(v[0] for _, v in rest), sum(v[1] for _, v in rest) / 1e6,
+                                                  100.0 * sum(v[1] for _, v in rest) / total))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 45)
+    if sys.argv[1] == "--trace":
+        from_trace(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 45)
+    else:
+        main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 45)
