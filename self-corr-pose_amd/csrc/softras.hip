@@ -66,7 +66,10 @@ struct RasterArgs {
     float near_, far_, eps, sigma, dist_eps, gamma;
     float threshold, margin;
     int dist_mode, alpha_mode, double_side;
+    int dbg;   // profiling ablations (tools/softras_ablate.py): 1 = skip reduction+flush, 2 = skip pair math
 };
+
+int g_debug_flags = 0;
 
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
@@ -467,30 +470,45 @@ __global__ __launch_bounds__(THREADS) void raster_forward_kernel(const RasterArg
 // ------------------------------------------------------------------------------------------------
 // backward (kernel.cu:486-668)
 // ------------------------------------------------------------------------------------------------
-// wavefront reduce-scatter of NV (8 or 16) values: afterwards lane l (l < NV) of the wavefront
-// holds the sum over all 64 lanes of g[l]
-template <int NV>
-__device__ __forceinline__ float wave_reduce_scatter(float* g) {
-    const int lane = threadIdx.x & 63;
+// Cross-lane reductions with DPP (data-parallel primitives: the cross-lane operand is read through
+// the VALU's DPP path, no LDS traffic -- ds_bpermute based __shfl_xor made the reduction 60 % of the
+// kernel).  DPP controls (gfx9 family): quad_perm [1,0,3,2] = lane^1, [2,3,0,1] = lane^2,
+// row_half_mirror = lane^7 (within 8), row_mirror = lane^15 (within 16).
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
+template <int HALF, int CTRL>
+__device__ __forceinline__ void scatter_step(float* g, int lane) {
+    const bool up = (lane & HALF) != 0;   // the partner (lane ^ 15 / ^7 / ^2 / ^1) has this bit flipped
 #pragma unroll
-    for (int half = NV / 2; half >= 1; half >>= 1) {
-        const bool up = (lane & half) != 0;
-#pragma unroll
-        for (int i = 0; i < half; i++) {
-            const float keep = up ? g[i + half] : g[i];
-            const float send = up ? g[i] : g[i + half];
-            g[i] = keep + __shfl_xor(send, half);
-        }
+    for (int i = 0; i < HALF; i++) {
+        const float keep = up ? g[i + HALF] : g[i];
+        const float send = up ? g[i] : g[i + HALF];
+        g[i] = keep + dpp_get<CTRL>(send);
     }
-    float r = g[0];
-#pragma unroll
-    for (int m = NV; m < 64; m <<= 1) r += __shfl_xor(r, m);
-    return r;
 }
 
-__device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
+// reduce-scatter of NV (8 or 16) values over groups of NV lanes: afterwards lane l holds the sum over
+// its NV-lane group of g[l & (NV-1)]
+template <int NV>
+__device__ __forceinline__ float group_reduce_scatter(float* g) {
+    const int lane = threadIdx.x & 63;
+    if (NV == 16) scatter_step<8, DPP_MIRROR>(g, lane);
+    scatter_step<4, DPP_HALF_MIRROR>(g, lane);
+    scatter_step<2, DPP_XOR2>(g, lane);
+    scatter_step<1, DPP_XOR1>(g, lane);
+    return g[0];
+}
+
+// sum over the 16-lane row, result in every lane of the row
+__device__ __forceinline__ float row_sum16(float x) {
+    x += dpp_get<DPP_XOR1>(x);
+    x += dpp_get<DPP_XOR2>(x);
+    x += dpp_get<DPP_HALF_MIRROR>(x);
+    x += dpp_get<DPP_MIRROR>(x);
     return x;
 }
 
@@ -539,7 +557,7 @@ __global__ __launch_bounds__(THREADS) void raster_backward_kernel(const RasterAr
 #pragma unroll
                 for (int k = 0; k < 18; k++) g[k] = 0.f;
                 bool active = false;
-                if (px.valid && !(px.xp > bb.y || px.xp < bb.x || px.yp > bb.w || px.yp < bb.z)) {
+                if (px.valid && !(a.dbg & 2) && !(px.xp > bb.y || px.xp < bb.x || px.yp > bb.w || px.yp < bb.z)) {
                     float v[9];
 #pragma unroll
                     for (int k = 0; k < 9; k++) v[k] = rec[R_V + k];
@@ -633,17 +651,20 @@ __global__ __launch_bounds__(THREADS) void raster_backward_kernel(const RasterAr
                 }
                 // wavefront-uniform: nothing to add if no lane produced a term
                 if (__ballot(active) == 0ull) continue;
+                if (a.dbg & 1) { if (g[0] + g[5] + g[11] == 12345.f) acc[0] = 1.f; continue; }
                 float* slot_acc = acc + q * NACC;
+                // the 4 rows (8 groups) of the wavefront are merged by the LDS atomics themselves
                 if (FULL) {
-                    const float g16 = wave_sum(g[16]), g17 = wave_sum(g[17]);
-                    const float r = wave_reduce_scatter<16>(g);
-                    if (lane < 16) atomicAdd(slot_acc + lane, r);
-                    else if (lane == 16) atomicAdd(slot_acc + 16, g16);
-                    else if (lane == 17) atomicAdd(slot_acc + 17, g17);
+                    const float g16 = row_sum16(g[16]), g17 = row_sum16(g[17]);
+                    const float r = group_reduce_scatter<16>(g);
+                    const int l16 = lane & 15;
+                    atomicAdd(slot_acc + l16, r);
+                    if (l16 < 2) atomicAdd(slot_acc + 16 + l16, l16 == 0 ? g16 : g17);
                 } else {
                     float h[8] = {g[0], g[1], g[3], g[4], g[6], g[7], 0.f, 0.f};
-                    const float r = wave_reduce_scatter<8>(h);
-                    if (lane < 6) atomicAdd(slot_acc + (lane + (lane >> 1)), r);  // 0,1,3,4,6,7
+                    const float r = group_reduce_scatter<8>(h);
+                    const int l8 = lane & 7;
+                    if (l8 < 6) atomicAdd(slot_acc + (l8 + (l8 >> 1)), r);  // 0,1,3,4,6,7
                 }
             }
             __syncthreads();
@@ -734,6 +755,7 @@ int fill_args(RasterArgs& a, const scp_raster_params* p) {
     a.threshold = p->dist_eps * p->sigma_val;  // kernel.cu:352 (fp32 product)
     a.margin = sqrtf(a.threshold);             // kernel.cu:375 (fp32 sqrt)
     a.dist_mode = p->func_id_dist; a.alpha_mode = p->func_id_alpha; a.double_side = p->double_side != 0;
+    a.dbg = g_debug_flags;
     return 0;
 }
 
@@ -759,6 +781,8 @@ template <int RGB, int SAMPLE> struct BwdLaunch {
 };
 
 }  // namespace
+
+extern "C" void scpdbg_set_flags(int flags) { g_debug_flags = flags; }
 
 extern "C" int scp_soft_rasterize_forward(const float* faces, const float* textures, float* faces_info,
                                           float* aggrs_info, float* soft_colors,
