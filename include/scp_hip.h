@@ -113,6 +113,15 @@ int scp_dual_softmax_backward(const float* scores, const float* rowmask, const f
                               const float* g_row_out, const float* weights, int W, float tau_r, int N,
                               int P, int Q, void* stream);
 
+/* ---- ViT multi-head self-attention forward (frozen DINO ViT-S/8) -----------------------------------
+ * Replaces Attention.forward of third-party/zsp/zsp/method/vision_transformer_flexible.py:85-101
+ * between the qkv and proj Linear layers:
+ *   qkv [B,N,3,H,head_dim] contiguous (the output of `self.qkv(x)` viewed as in :87)
+ *   out [B,N,H*head_dim] = (softmax(q k^T * scale) v).transpose(1,2).reshape(B,N,C)   (:90,:94)
+ * head_dim must be 64.  No score tensor is materialised. */
+int scp_vit_attention_forward(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

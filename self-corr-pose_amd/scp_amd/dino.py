@@ -49,9 +49,13 @@ class _Attention(nn.Module):
 
     def forward(self, x):
         b, n, c = x.shape
-        qkv = self.qkv(x).reshape(b, n, 3, self.num_heads, c // self.num_heads).permute(2, 0, 3, 1, 4)
-        y = attention(qkv[0], qkv[1], qkv[2], self.scale)
-        return self.proj(y.transpose(1, 2).reshape(b, n, c))
+        qkv = self.qkv(x)
+        if qkv.is_cuda and not torch.is_grad_enabled():
+            y = fused_attention(qkv, b, n, self.num_heads, c // self.num_heads, self.scale)   # HIP, [b,n,c]
+        else:
+            qkv = qkv.reshape(b, n, 3, self.num_heads, c // self.num_heads).permute(2, 0, 3, 1, 4)
+            y = attention(qkv[0], qkv[1], qkv[2], self.scale).transpose(1, 2).reshape(b, n, c)
+        return self.proj(y)
 
     def keys(self, x):
         """only the K third of the qkv projection: [b, heads, n, d]"""
@@ -61,8 +65,20 @@ class _Attention(nn.Module):
 
 
 def attention(q, k, v, scale):
-    """softmax(q k^T * scale) v over [b, h, n, d] without materialising the [n, n] scores"""
+    """softmax(q k^T * scale) v over [b, h, n, d] (stock torch; non-GPU tensors / autograd)"""
     return F.scaled_dot_product_attention(q, k, v, scale=scale)
+
+
+def fused_attention(qkv, b, n, heads, head_dim, scale):
+    """HIP flash-style attention on the fp32 matrix cores (csrc/vit_attn.hip): qkv [b,n,3*heads*head_dim]
+    as produced by the qkv Linear -> [b, n, heads*head_dim], forward only (the ViT is frozen)"""
+    from . import capi
+    qkv = qkv.contiguous()
+    out = torch.empty(b, n, heads * head_dim, dtype=torch.float32, device=qkv.device)
+    code = capi.lib().scp_vit_attention_forward(capi.dev_ptr(qkv, "qkv"), capi.dev_ptr(out, "out"), b, n, heads,
+                                                head_dim, float(scale), capi.current_stream())
+    capi.check(code, "scp_vit_attention_forward")
+    return out
 
 
 class _Block(nn.Module):
