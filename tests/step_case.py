@@ -37,7 +37,7 @@ def stats(t):
     return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
 
 
-def run_and_compare(model, data, d, rtol_loss=1e-4, grad_rel_l2=1e-3):
+def run_and_compare(model, data, d, rtol_loss=1e-4, grad_rel_l2=1e-3, grad_cos=0.9999):
     """north_star: every loss scalar and the predicted pose within 1e-4 relative of the reference;
     gradients: relative L2 (summation orders differ between CPU BLAS / MIOpen / wavefront trees)"""
     # inputs really are the recorded ones
@@ -66,7 +66,7 @@ def run_and_compare(model, data, d, rtol_loss=1e-4, grad_rel_l2=1e-3):
         rel = np.linalg.norm(g - r) / np.linalg.norm(r)
         cos = g @ r / (np.linalg.norm(g) * np.linalg.norm(r))
         report[key] = (rel, cos)
-        assert rel <= grad_rel_l2 and cos >= 0.9999, "%s: rel L2 %.3e cos %.7f" % (key, rel, cos)
+        assert rel <= grad_rel_l2 and cos >= grad_cos, "%s: rel L2 %.3e cos %.7f" % (key, rel, cos)
     return report
 
 
