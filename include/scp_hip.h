@@ -122,6 +122,14 @@ int scp_dual_softmax_backward(const float* scores, const float* rowmask, const f
 int scp_vit_attention_forward(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale,
                               void* stream);
 
+/* ---- brute-force 1-nearest-neighbour (symmetry loss) -----------------------------------------------
+ * Replaces pytorch3d.ops.knn_points(x, y, K=1).idx as used by model/util/chamfer.py:135 for
+ * model/module/mesh.py:53-62:  index[n,i] = argmin_j |x[n,i] - y[n,j]|^2  (lowest j on ties).
+ *   x [N,P1,3], y [N,P2,3] fp32; index [N,P1] int64; workspace >= scp_nearest_point_workspace() bytes. */
+size_t scp_nearest_point_workspace(int N, int P1);
+int scp_nearest_point(const float* x, const float* y, int N, int P1, int P2, long long* index,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

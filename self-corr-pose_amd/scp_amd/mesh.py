@@ -63,6 +63,10 @@ def nearest_sq_dist(x, y, chunk_bytes=2 << 30):
     selected y (pytorch3d knn_points K=1 semantics)"""
     n, p1, _ = x.shape
     p2 = y.shape[1]
+    if x.is_cuda:
+        idx = _nearest_index_hip(x.detach(), y.detach())
+        y_nn = torch.gather(y, 1, idx[..., None].expand(-1, -1, 3))
+        return (x - y_nn).pow(2).sum(-1)
     per_item = p1 * p2 * 4
     step = max(1, int(chunk_bytes // max(per_item, 1)))
     idx = []
@@ -74,6 +78,22 @@ def nearest_sq_dist(x, y, chunk_bytes=2 << 30):
     idx = torch.cat(idx, 0)
     y_nn = torch.gather(y, 1, idx[..., None].expand(-1, -1, 3))
     return (x - y_nn).pow(2).sum(-1)
+
+
+def _nearest_index_hip(x, y):
+    """argmin_j |x_i - y_j|^2 on the GPU (csrc/nearest.hip): exact differences, no [N,P1,P2] matrix"""
+    import ctypes
+    from . import capi
+    x, y = x.contiguous().float(), y.contiguous().float()
+    n, p1, _ = x.shape
+    idx = torch.empty(n, p1, dtype=torch.int64, device=x.device)
+    nbytes = capi.lib().scp_nearest_point_workspace(n, p1)
+    ws = torch.empty(nbytes // 8, dtype=torch.int64, device=x.device)
+    code = capi.lib().scp_nearest_point(capi.dev_ptr(x, "x"), capi.dev_ptr(y, "y"), n, p1, y.shape[1],
+                                        ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                        ctypes.c_size_t(nbytes), capi.current_stream())
+    capi.check(code, "scp_nearest_point")
+    return idx
 
 
 class CanonicalMesh(nn.Module):

@@ -218,3 +218,22 @@ def test_hip_match_full_size_properties():
     _close(pc[sub], r_pc.numpy())
     _close(match[sub], r_match.numpy())
     _close(imatch[sub], r_imatch.numpy())
+
+
+@pytest.mark.gpu
+def test_hip_nearest_point_matches_bruteforce():
+    """symmetry-loss 1-NN (csrc/nearest.hip) vs an exact torch brute force, incl. exact ties"""
+    from scp_amd.mesh import nearest_sq_dist
+    g = torch.Generator().manual_seed(4)
+    x, y = torch.randn(5, 300, 3, generator=g), torch.randn(5, 2500, 3, generator=g)
+    y[:, 100] = y[:, 50]                      # duplicate candidate: lowest index must win
+    x[:, 0] = y[:, 50]
+    d = (x[:, :, None] - y[:, None]).pow(2).sum(-1)
+    ref_d, ref_i = d.min(-1)
+    xg, yg = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    got = nearest_sq_dist(xg, yg)
+    torch.testing.assert_close(got.cpu(), ref_d, rtol=1e-6, atol=1e-7)
+    from scp_amd.mesh import _nearest_index_hip
+    assert torch.equal(_nearest_index_hip(x.cuda(), y.cuda()).cpu(), ref_i)
+    got.sum().backward()
+    assert torch.isfinite(xg.grad).all() and yg.grad.abs().sum() > 0

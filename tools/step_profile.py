@@ -73,6 +73,6 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     tr.step(data)
     torch.cuda.synchronize()
 rows = prof.key_averages(group_by_input_shape=True)
-rows = sorted(rows, key=lambda r: -r.device_time_total)[:45]
+rows = sorted(rows, key=lambda r: -r.device_time_total)[:130]
 for r in rows:
     print("%9.3f ms  x%-4d %-60s %s" % (r.device_time_total / 1e3, r.count, r.key[:60], str(r.input_shapes)[:110]))
