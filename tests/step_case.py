@@ -32,6 +32,25 @@ def build(device="cpu", case="step_laptopflags_bottle_b2x2"):
     return model, data, d
 
 
+def pin_encoder_geometry(model, d):
+    """Replace the VALUES of the encoder's geometric outputs (pred_v, rotation, translation) by the
+    ones the reference produced, keeping the autograd path (value = recorded, gradient = computed).
+    On the GPU the stock MIOpen/rocBLAS encoder rounds differently from the CPU reference (poses
+    differ by ~5e-6); the silhouette-sensitive render losses (sigma = 1e-4, gamma = 1e-4)
+    amplify that to ~1e-4 relative, which would otherwise mask what the test is about: the HIP
+    kernels downstream of the encoder."""
+    fwd = model.encoder.forward
+
+    def pinned(*a, **k):
+        img_feat, mesh_feat, pred_v, rot, trans, scale = fwd(*a, **k)
+        dev = pred_v.device
+
+        def pin(x, key):
+            return torch.tensor(d[key], device=dev) + (x - x.detach())
+        return img_feat, mesh_feat, pin(pred_v, "pred_v"), pin(rot, "rotation"), pin(trans, "translation"), scale
+    model.encoder.forward = pinned
+
+
 def stats(t):
     t = t.detach().double().cpu()
     return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])

