@@ -31,10 +31,13 @@ def test_full_step_matches_reference_on_gpu():
 
 def test_full_step_free_running_on_gpu():
     """nothing pinned but the discrete selections: the stock-PyTorch encoder's library rounding
-    (MIOpen solver choice varies run to run) moves the silhouette-sensitive losses by up to ~1e-4
-    relative; bound: 5e-4 on every loss, 1e-4 on the pose"""
+    (MIOpen's solver choice varies from process to process) perturbs pred_v / pose at the 5e-6 level,
+    and the silhouette-sensitive render losses amplify that to 1e-5 ... 8e-4 relative (observed
+    spread over runs; SURVEY F12 measured the same amplification between two builds of the reference
+    itself).  Sanity bound only: 2e-3 on every loss, 1e-4 on the pose -- the parity claim is the
+    pinned test above."""
     model, data, d = step_case.build("cuda")
-    step_case.run_and_compare(model, data, d, rtol_loss=5e-4, grad_rel_l2=5e-2, grad_cos=0.9995)
+    step_case.run_and_compare(model, data, d, rtol_loss=2e-3, grad_rel_l2=0.1, grad_cos=0.995)
 
 
 def test_trainer_step_runs_and_updates():
