@@ -35,7 +35,14 @@ class Renderer:
 
     def render_all(self, pred_v, faces, tex, foc_crop, pp_crop, rotation, translation, scale):
         cam = (foc_crop, pp_crop, rotation, translation)
-        mask_render = render(self.renderer_mask, pred_v, faces, None, *cam, render_mask=True)[:, -1]
+        # The mask pass and the depth pass share sigma, distance function and alpha aggregation, so
+        # their alpha planes are bit-identical (checked in tests/test_softras_gpu.py) and the
+        # mask pass' gradient reaches the geometry only through alpha: taking the mask from the depth
+        # pass' alpha channel is the same forward value and -- by linearity of the backward in the
+        # incoming alpha gradient -- the same gradient, with one rasterisation + one backward less.
+        fuse_mask = bool(self.opts.use_depth) and getattr(self, "share_mask_with_depth", True)
+        if not fuse_mask:
+            mask_render = render(self.renderer_mask, pred_v, faces, None, *cam, render_mask=True)[:, -1]
 
         if tex is not None:
             tex_out = render(self.renderer_softtex, pred_v, faces, tex, *cam, texture_type=self.mesh.texture_type)
@@ -44,6 +51,8 @@ class Renderer:
             tex_mask = tex_render = None
 
         depth_out = render(self.renderer_depth, pred_v, faces, None, *cam, render_depth=True, texture_type="vertex")
+        if fuse_mask:
+            mask_render = depth_out[:, 3]
         if not self.opts.use_depth:
             depth_out = depth_out.detach()
         depth_mask, depth_render = depth_out[:, 3], depth_out[:, 2].clone()

@@ -75,11 +75,38 @@ def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0,
                                        aggr_func_rgb, aggr_func_alpha, texture_type)
 
 
+class _SharedTopologyGather(Function):
+    """vertices[:, faces] for ONE face list shared by the batch.  Backward = incidence^T-matmul
+    (a [V, 3F] 0/1 matrix times the face gradients): deterministic and ~30x faster on the GPU than the
+    sorted index_put autograd emits for an advanced-index gather."""
+    _incidence = {}
+
+    @staticmethod
+    def forward(ctx, vertices, faces1):
+        ctx.save_for_backward(faces1)
+        ctx.nv = vertices.shape[1]
+        return vertices[:, faces1]
+
+    @staticmethod
+    def backward(ctx, grad):
+        faces1, = ctx.saved_tensors
+        key = (faces1.data_ptr(), faces1.shape[0], ctx.nv, str(grad.device), faces1._version)
+        inc = _SharedTopologyGather._incidence.get(key)
+        if inc is None:
+            inc = torch.zeros(ctx.nv, faces1.numel(), dtype=grad.dtype, device=grad.device)
+            inc[faces1.reshape(-1), torch.arange(faces1.numel(), device=grad.device)] = 1
+            _SharedTopologyGather._incidence = {key: inc}
+        nb = grad.shape[0]
+        return torch.matmul(inc, grad.reshape(nb, -1, grad.shape[-1])), None
+
+
 def face_vertices(vertices, faces):
-    """[B,V,C], [B,F,3] -> [B,F,3,C]; backward is an index_put accumulate (autograd)."""
+    """[B,V,C], [B,F,3] -> [B,F,3,C]"""
     assert vertices.dim() == 3 and faces.dim() == 3 and vertices.shape[0] == faces.shape[0]
     assert vertices.shape[2] == 3 and faces.shape[2] == 3
     nb, nv = vertices.shape[:2]
+    if faces.stride(0) == 0 and vertices.is_cuda:        # one topology expanded over the batch (the trainer's case)
+        return _SharedTopologyGather.apply(vertices, faces[0].long())
     flat = faces.long() + (torch.arange(nb, device=vertices.device) * nv)[:, None, None]
     return vertices.reshape(nb * nv, 3)[flat]
 
