@@ -36,6 +36,19 @@ class GradientAllReducer:
         for p in self.params:
             dist.broadcast(p.data, src, group=self.group)
 
+    def all_reduce_flat(self, flat, chunk_bytes=32 << 20):
+        """average an already flattened gradient buffer in place: a few large asynchronous all-reduces
+        (xGMI ring all-reduce is per-link bound -> large messages), waited together.  Ranks must pass
+        buffers of equal length (parameters without a gradient on some rank: use all_reduce())."""
+        if self.world == 1:
+            return flat
+        n = max(1, chunk_bytes // flat.element_size())
+        work = [dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for c in flat.split(n)]
+        for w in work:
+            w.wait()
+        flat.div_(self.world)
+        return flat
+
     def all_reduce(self):
         if self.world == 1:
             return

@@ -63,20 +63,44 @@ class Trainer:
                 to("idx"), None)
 
     def collect_grad(self):
-        """per-group clipping of trainer.py:132-150; a non-finite gradient anywhere drops the step
-        (all gradients zeroed) without a host round trip"""
-        grads = [p.grad for p in self._trainable if p.grad is not None]
-        finite = torch.stack([g.isfinite().all() for g in grads]).all() if grads else None
-        norms = []
+        """All-reduce (data parallel), per-group clipping (trainer.py:132-150: mean_v 1.0, shapenerf 1.0,
+        pose_predictor 0.1) and NaN guard (a non-finite gradient anywhere zeroes every gradient, like
+        the reference's zero_grad()) on ONE flat copy of the gradients: ~10 launches and no host round
+        trip, instead of one isnan().sum() > 0 sync per parameter."""
+        params = [p for p in self._trainable if p.grad is not None]
+        if not params:
+            z = torch.zeros((), device=self.device)
+            return z, z, z
+        grads = [p.grad for p in params]
+        sizes = [g.numel() for g in grads]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        if self.reducer is not None:
+            self.reducer.all_reduce_flat(flat)
+        finite = torch.isfinite(flat).all()
+        flat = torch.where(finite, flat, torch.zeros((), dtype=flat.dtype, device=flat.device))
+        views = list(flat.split(sizes))
+        offsets, off = {}, 0
+        for p, n in zip(params, sizes):
+            offsets[id(p)] = (off, n)
+            off += n
+        out = []
         for group, max_norm in ((self._mean_v, 1.), (self._shapenerf, 1.), (self._pose, 0.1)):
-            ps = [p for p in group if p.grad is not None]
-            norms.append(torch.nn.utils.clip_grad_norm_(ps, max_norm) if ps else torch.zeros((), device=self.device))
-        if finite is not None:
-            keep = finite.to(grads[0].dtype)
-            torch._foreach_mul_(grads, keep)
-            for g in grads:   # 0 * nan = nan: scrub
-                torch.nan_to_num_(g, nan=0.0, posinf=0.0, neginf=0.0)
-        return tuple(norms)
+            spans = sorted(offsets[id(p)] for p in group if id(p) in offsets)
+            if not spans:
+                out.append(torch.zeros((), device=self.device))
+                continue
+            lo, hi = spans[0][0], spans[-1][0] + spans[-1][1]
+            if hi - lo == sum(n for _, n in spans):          # the group is one contiguous range
+                seg = [flat[lo:hi]]
+            else:
+                seg = [flat[o:o + n] for o, n in spans]
+            total = seg[0].norm(2) if len(seg) == 1 else torch.stack([t.norm(2) for t in seg]).norm(2)
+            coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)           # clip_grad_norm_'s coefficient
+            for t in seg:
+                t.mul_(coef)
+            out.append(total)
+        torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(views, grads)])
+        return tuple(out)
 
     def step(self, data):
         """one training iteration on an already device-resident 12-tuple; returns (total_loss, aux, grad norms)"""
@@ -84,8 +108,6 @@ class Trainer:
         self.optim.zero_grad()
         total_loss, aux_output = self.model(data)
         total_loss.mean().backward()
-        if self.reducer is not None:
-            self.reducer.all_reduce()
         grad = self.collect_grad()
         self.optim.step(self.iteration)
         self.iteration += 1

@@ -1,0 +1,82 @@
+"""Host logic of the training step (scp_amd/trainer.py, optimizers.py, flags.py) on CPU."""
+import math
+
+import pytest
+import torch
+
+import scenes
+
+
+@pytest.fixture(scope="module")
+def trainer():
+    import scp_amd.dino as dino
+    from scp_amd.flags import Options
+    from scp_amd.trainer import Trainer
+    dino.ALLOW_RANDOM_INIT = True
+    opts = Options("laptop_wild6d", batch_size=1, repeat=2, train=True, total_iters=50, img_size=128, corr_h=32,
+                   corr_w=32, pretrain_k=40)
+    torch.manual_seed(0)
+    return Trainer(opts, prior=scenes.bottle_like(2), device="cpu")
+
+
+def _fill(tr, fn):
+    for i, p in enumerate(tr._trainable):
+        p.grad = fn(i, p)
+
+
+def test_collect_grad_clips_per_group_like_the_reference(trainer):
+    """trainer.py:132-150: mean_v clipped to 1, shapenerf params to 1 (jointly), pose_predictor to 0.1"""
+    tr = trainer
+    _fill(tr, lambda i, p: torch.full_like(p, 0.5))
+    expect = {}
+    for name, group, mx in (("mean_v", tr._mean_v, 1.), ("shapenerf", tr._shapenerf, 1.), ("pose", tr._pose, 0.1)):
+        total = math.sqrt(sum(0.25 * p.numel() for p in group))
+        expect[name] = (total, min(1.0, mx / (total + 1e-6)))
+    norms = tr.collect_grad()
+    for (name, (total, coef)), got in zip(expect.items(), norms):
+        assert abs(float(got) - total) <= 1e-4 * total
+    for group, key in ((tr._mean_v, "mean_v"), (tr._shapenerf, "shapenerf"), (tr._pose, "pose")):
+        for p in group:
+            torch.testing.assert_close(p.grad, torch.full_like(p, 0.5 * expect[key][1]), rtol=1e-5, atol=0)
+    other = [p for p in tr._trainable if all(p is not q for g in (tr._mean_v, tr._shapenerf, tr._pose) for q in g)]
+    assert other and all(torch.equal(p.grad, torch.full_like(p, 0.5)) for p in other)   # backbone/featnet untouched
+
+
+def test_collect_grad_drops_the_step_on_nan(trainer):
+    tr = trainer
+    _fill(tr, lambda i, p: torch.ones_like(p))
+    tr._trainable[7].grad.view(-1)[0] = float("nan")
+    tr._trainable[9].grad.view(-1)[0] = float("inf")
+    tr.collect_grad()
+    assert all((p.grad == 0).all() for p in tr._trainable)
+
+
+def test_optimizer_groups_and_onecycle(trainer):
+    """optimizers.py:16-73: five name-based groups with vert/cam lr ratios, OneCycle (pct 0.05, div 25)"""
+    tr = trainer
+    groups = tr.optim.optimizer.param_groups
+    assert len(groups) == 5 and len(groups[0]["params"]) == 1            # mean_v
+    lr = tr.opts.learning_rate
+    for g, ratio in zip(groups, (tr.opts.vert_lr_ratio, tr.opts.cam_lr_ratio, 1, 1, 1)):
+        assert abs(g["initial_lr"] - ratio * lr / 25) < 1e-12 and g["weight_decay"] == 1e-4
+    n_opt = sum(len(g["params"]) for g in groups)
+    # frozen DINO is left out; mesh.faces / mesh.symm_rots match no group (the reference prints
+    # "*found unknown params" for them, optimizers.py:35)
+    n_named = sum(1 for n, p in tr.model.named_parameters()
+                  if "pretrain_corr_net" not in n and n not in ("mesh.faces", "mesh.symm_rots"))
+    assert n_opt == n_named
+
+
+def test_flagfile_parser(tmp_path):
+    from scp_amd.flags import PRESETS, load_flagfile
+    text = "--category=laptop\n--batch_size=8\n--repeat=4\n--depth_offset=5\n--use_depth=True\n" \
+           "--rotation_offset=0.2,0.0,0.0,0.0,-0.2,0.2\n--divide_fn=both\n--pretrain_k=200\n--symmetry_idx=1\n"
+    f = tmp_path / "base_config.txt"
+    f.write_text(text)
+    o = load_flagfile(str(f), train=True)
+    assert o.batch_size == 8 and o.repeat == 4 and o.depth_offset == 5.0 and o.use_depth is True
+    assert o.rotation_offset == [0.2, 0.0, 0.0, 0.0, -0.2, 0.2] and o.divide_fn == "both" and o.train
+    assert PRESETS["laptop_wild6d"]["pretrain_k"] == o.pretrain_k
+    with pytest.raises(AttributeError):
+        (tmp_path / "bad.txt").write_text("--no_such_flag=1\n")
+        load_flagfile(str(tmp_path / "bad.txt"))
