@@ -315,11 +315,79 @@ def gen_corr():
          grad_src_feat=src_feat.grad.numpy(), grad_tgt_feat=tgt_feat.grad.numpy())
 
 
+def gen_losses():
+    """G6: the reference's image-space losses / regularisers (model/util/loss_utils.py:38-47,63-97,
+    236-252,273-284,317-345) on small random inputs, values and gradients; plus the eval-mode
+    confidence branch of Correspondence.match (correspondence.py:58-69)."""
+    flags = ref_harness.install()
+    import config  # noqa: F401
+    import model.util.loss_utils as lu
+    g = torch.Generator().manual_seed(21)
+    B, S = 4, 32
+    img = torch.rand(B, 3, S, S, generator=g)
+    mask = (torch.rand(B, S, S, generator=g) > 0.4).float()
+    mask_pred = torch.rand(B, S, S, generator=g).requires_grad_(True)
+    tex_pred = torch.rand(B, 3, S, S, generator=g).requires_grad_(True)
+    tex_mask = torch.rand(B, S, S, generator=g).requires_grad_(True)
+    depth = mask * (2 + torch.rand(B, S, S, generator=g)) * (torch.rand(B, S, S, generator=g) > 0.1)
+    depth_pred = (1 + torch.rand(B, S, S, generator=g)).requires_grad_(True)
+    depth_mask = (torch.rand(B, S, S, generator=g) > 0.3).float()
+    match = torch.randn(B, 3, S, S, generator=g).requires_grad_(True)
+    match_gt = torch.randn(B, 3, S, S, generator=g)
+    match_mask = torch.rand(B, S, S, generator=g) - 0.3
+    imatch = torch.randn(B, 2, 50, generator=g).requires_grad_(True)
+    imatch_gt = torch.randn(B, 2, 50, generator=g)
+    dw = torch.rand(B, 50, generator=g)
+    out = {}
+    m = lu.compute_mask_loss(img, mask, mask_pred)
+    t = lu.compute_texture_loss(img, mask, tex_pred, tex_mask)
+    dl, ddiff = lu.compute_depth_loss(depth.clone(), depth_pred, depth_mask, mask)
+    ml = lu.compute_match_loss(match, match_gt, match_mask, mask)
+    il = lu.compute_imatch_loss(imatch, imatch_gt, dw)
+    (m.sum() + t.sum() + dl.sum() + ml.sum() + il.sum()).backward()
+    v, f = scenes.icosphere(1)
+    lap = lu.LaplacianLoss(torch.tensor(v, dtype=torch.float32), torch.tensor(f), average=True)
+    pv = torch.randn(B, v.shape[0], 3, generator=g)
+    x = torch.arange(8 * 5, dtype=torch.float32).reshape(8, 5)
+    sb, tb = lu.divide_by_both(x, 2, 4)
+    sf, tf = lu.divide_by_frame(x, 2, 4)
+    si, ti = lu.divide_by_instance(x, 2, 4)
+    verts = torch.randn(B, 7, 3, generator=g) + torch.tensor([0., 0., 5.])
+    pp, foc = torch.randn(B, 2, generator=g) * 0.1, 5 + torch.rand(B, 2, generator=g)
+    cam = lu.pinhole_cam(verts.clone(), pp, foc)
+    save("losses_small", img=img.numpy(), mask=mask.numpy(), mask_pred=mask_pred.detach().numpy(),
+         tex_pred=tex_pred.detach().numpy(), tex_mask=tex_mask.detach().numpy(), depth=depth.numpy(),
+         depth_pred=depth_pred.detach().numpy(), depth_mask=depth_mask.numpy(), match=match.detach().numpy(),
+         match_gt=match_gt.numpy(), match_mask=match_mask.numpy(), imatch=imatch.detach().numpy(),
+         imatch_gt=imatch_gt.numpy(), depth_weight=dw.numpy(),
+         mask_loss=m.detach().numpy(), texture_loss=t.detach().numpy(), depth_loss=dl.detach().numpy(),
+         depth_diff=ddiff.detach().numpy(), match_loss=ml.detach().numpy(), imatch_loss=il.detach().numpy(),
+         g_mask_pred=mask_pred.grad.numpy(), g_tex_pred=tex_pred.grad.numpy(), g_tex_mask=tex_mask.grad.numpy(),
+         g_depth_pred=depth_pred.grad.numpy(), g_match=match.grad.numpy(), g_imatch=imatch.grad.numpy(),
+         lap_verts=v.astype(np.float32), lap_faces=f, lap_in=pv.numpy(), lap_out=np.float64(lap(pv).item()),
+         div_x=x.numpy(), div_both_src=sb.numpy(), div_both_tgt=tb.numpy(), div_frame_tgt=tf.numpy(),
+         div_inst_tgt=ti.numpy(), cam_verts=verts.numpy(), cam_pp=pp.numpy(), cam_foc=foc.numpy(), cam_out=cam.numpy())
+
+    # eval-mode confidence (correspondence.py:58-69)
+    from model.module.correspondence import Correspondence
+    flags.corr_h = flags.corr_w = 16
+    flags.n_corr_feat, flags.train, flags.tau_img, flags.tau_mesh = 16, False, 10., 10.
+    B, C, V, P = 2, 16, 162, 256
+    img_feat = F_normalize(torch.randn(B, C, P, generator=g), 1)
+    mesh_feat = F_normalize(torch.randn(B, V, C, generator=g), 2)
+    pred_v = torch.randn(B, V, 3, generator=g) * 0.5
+    mask2 = (torch.rand(B, 64, 64, generator=g) > 0.35).float()
+    with torch.no_grad():
+        _, match_e, imatch_e, conf = Correspondence(flags).match(img_feat, mesh_feat, mask2, pred_v)
+    save("corr_eval_conf_b2", img_feat=img_feat.numpy(), mesh_feat=mesh_feat.numpy(), pred_v=pred_v.numpy(),
+         mask=mask2.numpy(), match=match_e.numpy(), imatch=imatch_e.numpy(), match_conf=conf.numpy())
+
+
 def F_normalize(x, dim):
     return torch.nn.functional.normalize(x, 2, dim)
 
 
-GENERATORS = {"softras": gen_softras, "step": gen_step, "corr": gen_corr}
+GENERATORS = {"softras": gen_softras, "step": gen_step, "corr": gen_corr, "losses": gen_losses}
 
 
 if __name__ == "__main__":
