@@ -13,11 +13,13 @@ ImageNet / DINO checkpoints).  Weak scaling: every rank processes its own 32 ima
 32-image iterations completed by all ranks per second.
 
 Extra JSON objects (tier contract):
-  roofline      the dominant hand-written kernel of the step (SoftRas backward of the sigma=1e-3
-                texture pass).  `achieved` = algorithmic HBM bytes of one launch / its mean duration
-                measured with HIP events on the launch stream inside the timed region.  The kernel
-                is fp32-VALU bound on active (pixel,face) pairs, not HBM bound, so the
-                pair rate is reported beside it under "valu".
+  roofline      the dominant hand-written kernel of the step = the fp32-MFMA flash attention of the
+                DINO ViT (9 launches, ~5.5 ms of a step; csrc/vit_attn.hip).  bound "mfma":
+                `achieved` = algorithmic flops of one launch (4 N^2 d per image and head) / its mean
+                duration measured with HIP events on the launch stream inside the timed region; peak
+                = 157.3 TFLOP/s (fp32 matrix = fp32 vector peak).  The second hand-written hot kernel,
+                the SoftRas backward of the sigma=1e-3 texture pass, is reported under "raster_backward"
+                (fp32-VALU bound on active (pixel,face) pairs; HBM figure for the record).
   cpu_baseline  the same step on the host CPU cores (torch CPU + the C oracle rasteriser), rank 0,
                 N=1 only, on a bounded sample (one B=4 iteration), scaled to 32-image iterations/s.
 """
@@ -141,20 +143,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # dominant hand-written kernel: backward of the sigma=1e-3 softmax texture pass
+    # hand-written hot kernels timed live: ViT attention (dominant) and the sigma=1e-3 raster backward
+    import scp_amd.dino as dino_mod
     is_softtex = lambda *a: abs(a[12] - 1e-3) < 1e-9   # sigma_val of backward_soft_rasterize(...)
-    with KernelTimer(native, "backward_soft_rasterize", is_softtex) as kt:
+    with KernelTimer(native, "backward_soft_rasterize", is_softtex) as kt, \
+            KernelTimer(dino_mod, "fused_attention", lambda *a: True) as at:
         for _ in range(args.warmup):
             tr.step(data)
         sync()
-        kt.enabled = True
+        kt.enabled = at.enabled = True
         t0 = time.perf_counter()
         for _ in range(args.steps):
             tr.step(data)
         sync()
         elapsed = time.perf_counter() - t0
-        kt.enabled = False
+        kt.enabled = at.enabled = False
         kernel_ms = kt.mean_ms()
+        attn_ms = at.mean_ms()
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
@@ -167,6 +172,7 @@ def main():
         # faces_info in, soft_colors + aggrs_info + grad_soft_colors in, grad_faces + grad_textures out
         alg_bytes = 4.0 * B * (n_faces * (9 + 9 + 27) + S * S * (4 + 2 + 4) + n_faces * (9 + 9))
         roofline = None
+        raster = None
         if kernel_ms:
             fv = None
             pairs = None
@@ -183,15 +189,26 @@ def main():
             except Exception as e:  # instrumentation only
                 pairs = None
             achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-            roofline = {"kernel": "raster_backward_kernel<softmax,vertex> (sigma=1e-3 texture pass)",
+            raster = {"kernel": "raster_backward_kernel<softmax,vertex> (sigma=1e-3 texture pass)",
                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                         "avg_launch_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes}
             if pairs:
                 tf = pairs * FLOP_PER_PAIR_BWD / (kernel_ms * 1e-3) / 1e12
-                roofline["valu"] = {"pairs_active": pairs, "flop_per_pair": FLOP_PER_PAIR_BWD,
+                raster["valu"] = {"pairs_active": pairs, "flop_per_pair": FLOP_PER_PAIR_BWD,
                                     "achieved_TFLOPs": tf, "peak_TFLOPs": FP32_VALU_PEAK_TF,
                                     "frac": tf / FP32_VALU_PEAK_TF}
+        if attn_ms:
+            n_tok, heads, hd = (S // 8) ** 2 + 1, 6, 64
+            flops = 4.0 * B * heads * n_tok * n_tok * hd
+            tf = flops / (attn_ms * 1e-3) / 1e12
+            roofline = {"kernel": "vit_attention_kernel (fp32 MFMA flash attention, N=%d, 6x64, B=%d)" % (n_tok, B),
+                        "bound": "mfma", "achieved": tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": tf / FP32_VALU_PEAK_TF, "traffic": None, "avg_launch_ms": attn_ms,
+                        "algorithmic_flops_per_launch": flops, "launches_per_step": 9,
+                        "raster_backward": raster}
+        else:
+            roofline = raster
         out = {
             "metric": "train iters/sec (batch=32, 256x256, 1280-face/642-vert mesh)",
             "value": world * args.steps / elapsed, "unit": "iters/sec", "n_gpus": world, "steps": args.steps,

@@ -30,21 +30,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int HD = 64;        // head dim (fixed: ViT-S)
 constexpr int KT = 32;        // keys per tile
-constexpr int KSTRIDE = 68;   // floats per K row in LDS (64 + 4 pad: 16-B aligned, bank-conflict free for b128)
+constexpr float RESCALE_THR = 16.f;   // log2 units
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void vit_attention_kernel(const float* __restrict__ qkv,
-                                                                   float* __restrict__ out, int N, int H,
-                                                                   float scale_log2e) {
-    // K/V are staged SUB x 32 keys at a time (one barrier pair per SUB*64 MFMAs of every wavefront)
-    constexpr int SUB = 2;
-    __shared__ __attribute__((aligned(16))) float k_lds[SUB * KT * KSTRIDE];
-    __shared__ __attribute__((aligned(16))) float v_lds[SUB * KT * HD];
-    constexpr int THREADS = WAVES * 64;
+#define SCP_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define SCP_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// K/V tiles arrive by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wavefront instruction, no staging
+// VGPRs), double buffered: tile t+1 is in flight while tile t is consumed, one barrier per tile.
+// The DMA destination is lane-linear, so the K image is made bank-conflict free by permuting the
+// SOURCE address: 16-byte chunk c of key row r is stored in slot c ^ (r & 15) (and read back through
+// the same XOR); V rows are read along d and need no swizzle.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const float* __restrict__ qkv,
+                                                                   float* __restrict__ out, int N, int H,
+                                                                   float scale_log2e, int dbg) {
+    __shared__ __attribute__((aligned(16))) float k_lds[2][KT * HD];
+    __shared__ __attribute__((aligned(16))) float v_lds[2][KT * HD];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int q0 = (blockIdx.x * WAVES + wave) * 32;
@@ -52,6 +58,21 @@ __global__ __launch_bounds__(WAVES * 64) void vit_attention_kernel(const float* 
     const float* base = qkv + (size_t)b * N * row_stride + (size_t)h * HD;
     const float* kbase = base + (size_t)H * HD;
     const float* vbase = base + (size_t)2 * H * HD;
+
+    auto issue_tile = [&](int kt, int buf) {
+        const int r4 = lane >> 4, slot = lane & 15;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (j % WAVES != wave) continue;          // wavefront-uniform
+            const bool is_v = j >= 8;
+            const int jj = j & 7, r = 4 * jj + r4;
+            const int key = min(kt * KT + r, N - 1);
+            const int chunk = is_v ? slot : (slot ^ (r & 15));
+            const float* src = (is_v ? vbase : kbase) + (size_t)key * row_stride + 4 * chunk;
+            float* dst = (is_v ? v_lds[buf] : k_lds[buf]) + jj * 256;
+            __builtin_amdgcn_global_load_lds(SCP_GLOBAL_PTR(src), SCP_LDS_PTR(dst), 16, 0, 0);
+        }
+    };
 
     // Q fragment: qreg[s] = Q[q][s + 32*half] * scale*log2(e)
     float qreg[32];
@@ -70,67 +91,95 @@ __global__ __launch_bounds__(WAVES * 64) void vit_attention_kernel(const float* 
     for (int r = 0; r < 16; r++) { o_lo[r] = 0.f; o_hi[r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int nstage = (N + SUB * KT - 1) / (SUB * KT);
-    for (int st = 0; st < nstage; st++) {
-        __syncthreads();
-        for (int i = tid; i < SUB * KT * (HD / 4); i += THREADS) {
-            const int r = i >> 4, c4 = i & 15;
-            const int key = min(st * SUB * KT + r, N - 1);
-            const float4 kv = reinterpret_cast<const float4*>(kbase + (size_t)key * row_stride)[c4];
-            const float4 vv = reinterpret_cast<const float4*>(vbase + (size_t)key * row_stride)[c4];
-            *reinterpret_cast<float4*>(k_lds + r * KSTRIDE + 4 * c4) = kv;
-            *reinterpret_cast<float4*>(v_lds + r * HD + 4 * c4) = vv;
+    const int ntiles = (N + KT - 1) / KT;
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int kslot0 = (8 * half) ^ (l31 & 15);
+    for (int kt = 0; kt < ntiles; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < ntiles && !(dbg & 8)) issue_tile(kt + 1, buf ^ 1);
+
+        // ---- S^T = K Q^T : 32 k-steps of (d, d+32)
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[r] = 0.f;
+        {
+            const float* krow = k_lds[buf] + l31 * HD;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (dbg & 1) break;
+                const float4 kk = *reinterpret_cast<const float4*>(krow + 4 * (kslot0 ^ i));
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.x, qreg[4 * i + 0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.y, qreg[4 * i + 1], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.z, qreg[4 * i + 2], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.w, qreg[4 * i + 3], s, 0, 0, 0);
+            }
         }
-        __syncthreads();
+        // V operands of the first 8 P.V k-steps: fetched now, their LDS latency hides under the
+        // softmax VALU work; the other 8 are fetched while the first 16 MFMAs run
+        float va[8], vb[8];
 #pragma unroll
-        for (int sub = 0; sub < SUB; sub++) {
-            const int key_base = (st * SUB + sub) * KT;
-            if (key_base >= N) break;   // uniform
-            // ---- S^T = K Q^T : 32 k-steps of (d, d+32)
-            f32x16 s;
+        for (int r = 0; r < 8; r++) {
+            const float* vrow = v_lds[buf] + acc_row(r, half) * HD + l31;
+            va[r] = vrow[0];
+            vb[r] = vrow[32];
+        }
+        // ---- online softmax (lane owns 16 keys of its query; partner lane^32 owns the other 16)
+        const int key_base = kt * KT;
+        float m_tile = -INFINITY;
+        if (key_base + KT > N) {   // ragged last tile: wavefront-uniform branch
 #pragma unroll
-            for (int r = 0; r < 16; r++) s[r] = 0.f;
-            {
-                const float4* kp = reinterpret_cast<const float4*>(k_lds + (sub * KT + l31) * KSTRIDE + 32 * half);
+            for (int r = 0; r < 16; r++)
+                if (key_base + acc_row(r, half) >= N) s[r] = -INFINITY;
+        }
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float4 kk = kp[i];
-                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.x, qreg[4 * i + 0], s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.y, qreg[4 * i + 1], s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.z, qreg[4 * i + 2], s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.w, qreg[4 * i + 3], s, 0, 0, 0);
-                }
-            }
-            // ---- online softmax (lane owns 16 keys of its query; partner lane^32 owns the other 16)
-            float m_tile = -INFINITY;
-            if (key_base + KT > N) {   // ragged last tile: wavefront-uniform branch
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    if (key_base + acc_row(r, half) >= N) s[r] = -INFINITY;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++) m_tile = fmaxf(m_tile, s[r]);
-            m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        for (int r = 0; r < 16; r++) m_tile = fmaxf(m_tile, s[r]);
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        // Deferred rescale: the running maximum is only raised (and O, l rescaled -- 96 accumulator
+        // moves + 32 multiplies) when some query's tile maximum exceeds it by more than 2^RESCALE_THR;
+        // otherwise the probabilities are taken against the old maximum (bounded by 2^RESCALE_THR,
+        // harmless in fp32).  The decision is wavefront-uniform; O, l and the current P always share
+        // one scale, so the final O / l is the exact softmax.
+        if (__any(m_tile > m_run + RESCALE_THR)) {
             const float m_new = fmaxf(m_run, m_tile);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
-            float psum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
-                psum += s[r];
-            }
-            l_run = l_run * alpha + psum;
+            l_run *= alpha;
             m_run = m_new;
 #pragma unroll
             for (int r = 0; r < 16; r++) { o_lo[r] *= alpha; o_hi[r] *= alpha; }
-            // ---- O^T += V^T P^T : k-step r pairs key acc_row(r,0) with acc_row(r,1)
+        }
+        float psum = 0.f;
+        if (!(dbg & 2)) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const float* vrow = v_lds + (sub * KT + acc_row(r, half)) * HD + l31;
-                o_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], s[r], o_lo, 0, 0, 0);
-                o_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], s[r], o_hi, 0, 0, 0);
+                s[r] = __builtin_amdgcn_exp2f(s[r] - m_run);
+                psum += s[r];
             }
         }
+        l_run += psum;
+        // ---- O^T += V^T P^T : k-step r pairs key acc_row(r,0) with acc_row(r,1)
+        float vc[8], vd[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const float* vrow = v_lds[buf] + acc_row(r + 8, half) * HD + l31;
+            vc[r] = vrow[0];
+            vd[r] = vrow[32];
+        }
+        if (!(dbg & 4)) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            o_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(va[r], s[r], o_lo, 0, 0, 0);
+            o_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[r], s[r], o_hi, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            o_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[r], s[r + 8], o_lo, 0, 0, 0);
+            o_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(vd[r], s[r + 8], o_hi, 0, 0, 0);
+        }
+        } else { o_lo[0] += va[0] + vc[1] + s[3]; o_hi[1] += vb[2] + vd[3] + s[9]; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's DMA pieces have landed
+        if (!(dbg & 16)) __syncthreads();                     // ... everybody's; and nobody still reads `buf`
     }
 
     // ---- normalise and store: lane holds O[q = l31][d = acc_row(r, half) (+32)]
@@ -150,6 +199,10 @@ __global__ __launch_bounds__(WAVES * 64) void vit_attention_kernel(const float* 
 
 }  // namespace
 
+extern int g_scp_attn_dbg;
+int g_scp_attn_dbg = 0;
+extern "C" void scpdbg_set_attn_flags(int f) { g_scp_attn_dbg = f; }
+
 extern "C" int scp_vit_attention_forward(const float* qkv, float* out, int B, int N, int H, int head_dim,
                                          float scale, void* stream) {
     if (B <= 0 || N <= 0 || H <= 0) return scp::fail(hipErrorInvalidValue, "vit_attention: empty problem");
@@ -159,9 +212,9 @@ extern "C" int scp_vit_attention_forward(const float* qkv, float* out, int B, in
     const int qtiles = (N + 31) / 32;
     // 3 wavefronts per workgroup when that leaves no idle wavefront (1025 tokens = 33 tiles = 11 x 3)
     if (qtiles % 3 == 0 && qtiles % 4 != 0) {
-        hipLaunchKernelGGL(vit_attention_kernel<3>, dim3(qtiles / 3, B * H), dim3(192), 0, st, qkv, out, N, H, sl);
+        hipLaunchKernelGGL(vit_attention_kernel<3>, dim3(qtiles / 3, B * H), dim3(192), 0, st, qkv, out, N, H, sl, g_scp_attn_dbg);
     } else {
-        hipLaunchKernelGGL(vit_attention_kernel<4>, dim3((qtiles + 3) / 4, B * H), dim3(256), 0, st, qkv, out, N, H, sl);
+        hipLaunchKernelGGL(vit_attention_kernel<4>, dim3((qtiles + 3) / 4, B * H), dim3(256), 0, st, qkv, out, N, H, sl, g_scp_attn_dbg);
     }
     return scp::check_launch("vit_attention");
 }

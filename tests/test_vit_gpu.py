@@ -34,6 +34,35 @@ def test_attention_peaked_softmax():
     assert (got - ref).abs().max() <= 1e-4 * ref.abs().max()
 
 
+def test_attention_deferred_rescale_branch():
+    """the kernel only rescales O / l when a tile maximum exceeds the running one by > 2^16; build
+    inputs where (a) scores grow slowly tile after tile (never rescaled after the first tile),
+    (b) a huge late key forces a rescale for SOME queries of a wavefront only, (c) every tile forces
+    one -- all must equal the materialised softmax"""
+    from scp_amd.dino import fused_attention
+    g = torch.Generator().manual_seed(9)
+    B, N, H = 1, 320, 1
+    for mode in ("slow_growth", "late_spike_some_queries", "always"):
+        q = torch.randn(N, 64, generator=g) * 0.3
+        k = torch.randn(N, 64, generator=g) * 0.3
+        v = torch.randn(N, 64, generator=g)
+        u = torch.nn.functional.normalize(torch.randn(64, generator=g), dim=0)
+        if mode == "slow_growth":
+            q = q + 6 * u
+            k = k + u * torch.linspace(0, 6, N)[:, None]          # score/0.125 grows ~0..36*8 over the keys... scaled below
+        elif mode == "late_spike_some_queries":
+            q[::3] = q[::3] + 20 * u                               # every third query aligns with the spike key
+            k[300] = 40 * u
+        else:
+            q = q + 10 * u
+            k = k + u * (torch.arange(N) // 32)[:, None] * 3.0     # every 32-key tile jumps by a lot
+        qkv = torch.stack((q, k, v), 1).reshape(1, N, 3 * 64)
+        ref = oracle.attention_oracle(qkv, H, 0.125)
+        got = fused_attention(qkv.cuda(), B, N, H, 64, 0.125).cpu()
+        d = (got - ref).abs()
+        assert (d <= 2e-5 + 1e-4 * ref.abs()).all(), "%s: max abs diff %.3e" % (mode, d.max())
+
+
 def test_dino_features_match_reference_fixture():
     import step_case
     model, data, d = step_case.build("cuda")
