@@ -123,11 +123,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    # SCP_DIST_BACKEND=gloo SCP_SINGLE_DEVICE=1 lets the N>1 launch path be smoke-tested on a 1-GPU box
+    # (all ranks on cuda:0, gradients averaged over gloo); the real multi-GPU run uses RCCL ("nccl").
+    if os.environ.get("SCP_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
+        dist.init_process_group(os.environ.get("SCP_DIST_BACKEND", "nccl"), init_method="env://",
+                                world_size=world, rank=rank)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     import synth

@@ -130,7 +130,7 @@ def _stats(t):
     return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
 
 
-def gen_step():
+def gen_step(tag="step_laptopflags_bottle_b2x2", prior="bottle", batch_size=2, repeat=2):
     """G7 (+G5): one full reference MeshNet.forward/backward (model/model.py:61-152) on the synthetic
     batch of SURVEY 8(d): B = batch_size 2 x repeat 2, 256^2, bottle prior (642 v / 1280 f), laptop
     flags, recipe weights (tests/recipe.py), jitter = identity, rotation angle pinned to 90 degrees,
@@ -158,12 +158,12 @@ def gen_step():
     from model.model import MeshNet
     for k, v in PRESETS["laptop_wild6d"].items():
         setattr(flags, k, v)
-    bottle = ref_harness.REF + "/config/bottle_wild6d/bottle.obj"
+    bottle = ref_harness.REF + "/config/%s_wild6d/%s.obj" % (prior, prior)
     flags.shape_prior_path = bottle
-    flags.batch_size, flags.repeat, flags.train, flags.vis_freq = 2, 2, True, 10 ** 9
+    flags.batch_size, flags.repeat, flags.train, flags.vis_freq = batch_size, repeat, True, 10 ** 9
     ref_harness.PINNED_ANGLE[0] = 90.0
 
-    bsz = 4
+    bsz = batch_size * repeat
     torch.manual_seed(0)
     model = MeshNet(flags)
     missing, unexpected = model.load_state_dict(recipe.recipe_state_dict(model), strict=False)
@@ -177,7 +177,7 @@ def gen_step():
     hook = sys.modules["pytorch3d.ops"].sample_points_from_meshes
     type(hook).face_idx, type(hook).bary = fi, bary
 
-    data = synth.make_batch(2, 2, 256, seed=0)
+    data = synth.make_batch(batch_size, repeat, 256, seed=0)
     cap = {}
     enc_fwd = model.encoder.forward
 
@@ -237,7 +237,7 @@ def gen_step():
      depth_weight) = cap["render"]
     neg_dist, topk_idx = cap["topk"][0]
     with torch.no_grad():
-        dino_feat = dino_fwd(data[0][:2])
+        dino_feat = dino_fwd(data[0][:min(2, bsz)])
     out = {("aux_" + k): np.float64(v.item()) for k, v in aux.items()}
     params = dict(model.named_parameters())
     grads = {
@@ -249,7 +249,7 @@ def gen_step():
         "grad_mesh_stn_fc": params["encoder.featnet_mesh.stn.fc.weight"].grad,
     }
     v_raw, f_raw = ref_harness.read_obj(bottle)
-    save("step_laptopflags_bottle_b2x2",
+    save(tag, batch_size=batch_size, repeat=repeat,
          prior_verts=v_raw.astype(np.float32), prior_faces=f_raw.astype(np.int64),
          input_stats=np.stack([_stats(data[0]), _stats(data[1]), _stats(data[2]), _stats(data[7]), _stats(data[9])]),
          rotation=rotation.detach().numpy(), translation=translation.detach().numpy(),
@@ -387,7 +387,20 @@ def F_normalize(x, dim):
     return torch.nn.functional.normalize(x, 2, dim)
 
 
-GENERATORS = {"softras": gen_softras, "step": gen_step, "corr": gen_corr, "losses": gen_losses}
+def gen_step_laptop():
+    """BASELINE configs[1] geometry: the 995-vertex / 1986-face laptop prior, B = 2 x 2"""
+    gen_step("step_laptopflags_laptop_b2x2", "laptop", 2, 2)
+
+
+def gen_step_single():
+    """BASELINE configs[0]: ONE 256x256 image (batch_size 1 x repeat 1), 642 v / 1280 f prior.  With one
+    image divide_by_both pairs it with itself: every cycle distance ties at 0 (SURVEY F16 at its worst),
+    the recorded top-k / argmax selections are what pins cycle_loss_pretrain."""
+    gen_step("step_laptopflags_bottle_b1x1", "bottle", 1, 1)
+
+
+GENERATORS = {"softras": gen_softras, "step": gen_step, "corr": gen_corr, "losses": gen_losses,
+              "step_laptop": gen_step_laptop, "step_single": gen_step_single}
 
 
 if __name__ == "__main__":

@@ -14,21 +14,22 @@ def build(device="cpu", case="step_laptopflags_bottle_b2x2"):
     from scp_amd.model import MeshNet
     d = golden_io.load(case)
     dino.ALLOW_RANDOM_INIT = True
-    opts = Options("laptop_wild6d", batch_size=2, repeat=2, train=True, vis_freq=10 ** 9)
+    bs, rep = int(d.get("batch_size", 2)), int(d.get("repeat", 2))
+    opts = Options("laptop_wild6d", batch_size=bs, repeat=rep, train=True, vis_freq=10 ** 9)
     torch.manual_seed(0)
     model = MeshNet(opts, prior=(d["prior_verts"], d["prior_faces"]))
     recipe.load_recipe(model)
     model.encoder.random_jitter = torch.nn.Identity()      # golden runs: jitter off on both sides
     model.rotation_angle = 90.0                            # ... and the rotation-cycle angle pinned
     k = model.mesh.symm_rots.shape[0]
-    fi, bary = recipe.symmetry_sample(k * 4, 10000, model.mesh.num_faces)
+    fi, bary = recipe.symmetry_sample(k * bs * rep, 10000, model.mesh.num_faces)
     model = model.to(device).train()
     model.mesh.sample_override = (fi.to(device), bary.to(device))
     model.pretrain_corr_net.topk_override = torch.tensor(d["topk_indices"].astype(np.int64), device=device)
     model.pretrain_corr_net.nn_override = (torch.tensor(d["nn_bw"].astype(np.int64), device=device),
                                            torch.tensor(d["nn_fw"].astype(np.int64), device=device))
     model.iters = 0
-    data = synth.make_batch(2, 2, 256, seed=0, device=device)
+    data = synth.make_batch(bs, rep, 256, seed=0, device=device)
     return model, data, d
 
 

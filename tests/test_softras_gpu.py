@@ -111,6 +111,21 @@ def test_hip_matches_oracle_fresh_scenes(pname, size, subdiv, n):
     assert_grad_close(got, ref, "grad_textures")
 
 
+def test_high_res_dense_mesh_against_oracle():
+    """BASELINE configs[4] geometry: 512x512, icosphere-4 topology (2562 verts / 5120 faces), one image,
+    the sigma=1e-3 texture pass forward + backward (5120 faces > LIST_CAP exercises the chunked binning)"""
+    v, f = scenes.bottle_like(4)
+    assert v.shape[0] == 2562 and f.shape[0] == 5120
+    fv, ftex = scenes.raster_inputs(v, f, 1, seed=77, tex="rand")
+    grad = np.random.default_rng(5).standard_normal((1, 4, 512, 512)).astype(np.float32)
+    kw = dict(image_size=512, dist_func="euclidean", aggr_func_alpha="prod", **PASSES["softtex"])
+    ref = oracle.render(fv, ftex, grad_soft_colors=grad, **kw)
+    got = hip_render(fv, ftex, grad, **kw)
+    assert_forward_close(got, ref)
+    assert_grad_close(got, ref, "grad_faces")
+    assert_grad_close(got, ref, "grad_textures")
+
+
 def test_ragged_and_empty_inputs():
     from scp_amd.soft_renderer import functional as srf
     # a single off-screen triangle: background everywhere, alpha exactly 0, zero gradients

@@ -3,6 +3,7 @@
 encoder, correspondence, losses, ...) runs as shipped, the SoftRas kernels are replaced by the CPU
 oracle through monkeypatch.  The GPU edition (HIP kernels) is tests/test_step_gpu.py."""
 import numpy as np
+import pytest
 import torch
 
 import golden_io
@@ -10,9 +11,15 @@ import oracle_backend
 import step_case
 
 
-def test_full_step_matches_reference(monkeypatch):
+CASES = ["step_laptopflags_bottle_b2x2",    # 642 v / 1280 f prior, B = 2 x 2
+         "step_laptopflags_laptop_b2x2",    # BASELINE configs[1] geometry: 995 v / 1986 f
+         "step_laptopflags_bottle_b1x1"]    # BASELINE configs[0]: a single image
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_full_step_matches_reference(case, monkeypatch):
     oracle_backend.install(monkeypatch)
-    model, data, d = step_case.build("cpu")
+    model, data, d = step_case.build("cpu", case)
     report = step_case.run_and_compare(model, data, d)
     assert "total_loss" in report
 

@@ -16,11 +16,13 @@ import step_case
 pytestmark = pytest.mark.gpu
 
 
-def test_full_step_matches_reference_on_gpu():
+@pytest.mark.parametrize("case", ["step_laptopflags_bottle_b2x2", "step_laptopflags_laptop_b2x2",
+                                  "step_laptopflags_bottle_b1x1"])
+def test_full_step_matches_reference_on_gpu(case):
     """strict: encoder geometry pinned to the reference's values (see step_case.pin_encoder_geometry),
     everything downstream -- correspondence, 4 render passes, DINO cycle, all losses, backward --
     runs on the HIP kernels; every loss within north_star's 1e-4 relative"""
-    model, data, d = step_case.build("cuda")
+    model, data, d = step_case.build("cuda", case)
     from scp_amd.soft_renderer.cuda import soft_rasterize as native
     assert native.forward_soft_rasterize.__module__.startswith("scp_amd"), "HIP path must be the one that runs"
     step_case.pin_encoder_geometry(model, d)
