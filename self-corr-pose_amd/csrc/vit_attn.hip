@@ -59,12 +59,13 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
     const float* kbase = base + (size_t)H * HD;
     const float* vbase = base + (size_t)2 * H * HD;
 
-    auto issue_tile = [&](int kt, int buf) {
+    auto issue_tile = [&](int kt, int buf, bool do_k, bool do_v) {
         const int r4 = lane >> 4, slot = lane & 15;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             if (j % WAVES != wave) continue;          // wavefront-uniform
             const bool is_v = j >= 8;
+            if (is_v ? !do_v : !do_k) continue;
             const int jj = j & 7, r = 4 * jj + r4;
             const int key = min(kt * KT + r, N - 1);
             const int chunk = is_v ? slot : (slot ^ (r & 15));
@@ -91,41 +92,54 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
     for (int r = 0; r < 16; r++) { o_lo[r] = 0.f; o_hi[r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
+    // Software pipeline inside the wavefront: the Q.K^T MFMAs of tile t+1 are issued BEFORE the
+    // exponentials of tile t, so that those VALU/transcendental instructions execute in the shadow of the
+    // matrix pipe (identical wavefronts on a SIMD run in lock-step, so cross-wavefront overlap alone
+    // leaves the pipe idle during every softmax phase: measured 0.45 ms MFMA + 0.15 ms VALU, additive).
+    // LDS rings: K(t+1) is read in iteration t from k_lds[(t+1)&1], V(t) from v_lds[t&1]; K(t+2) and
+    // V(t+1) are in flight (LDS-DMA) meanwhile; one barrier per tile.
     const int ntiles = (N + KT - 1) / KT;
-    issue_tile(0, 0);
+    const int kslot0 = (8 * half) ^ (l31 & 15);
+    auto qk_tile = [&](int kbuf) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        const float* krow = k_lds[kbuf] + l31 * HD;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float4 kk = *reinterpret_cast<const float4*>(krow + 4 * (kslot0 ^ i));
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.x, qreg[4 * i + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.y, qreg[4 * i + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.z, qreg[4 * i + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.w, qreg[4 * i + 3], acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    issue_tile(0, 0, true, true);
+    if (ntiles > 1) issue_tile(1, 1, true, false);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int kslot0 = (8 * half) ^ (l31 & 15);
+    f32x16 s = qk_tile(0);
+    __syncthreads();   // K(0) has been read by every wavefront before iteration 0 refills k_lds[0] with K(2)
     for (int kt = 0; kt < ntiles; kt++) {
         const int buf = kt & 1;
-        if (kt + 1 < ntiles && !(dbg & 8)) issue_tile(kt + 1, buf ^ 1);
-
-        // ---- S^T = K Q^T : 32 k-steps of (d, d+32)
-        f32x16 s;
-#pragma unroll
-        for (int r = 0; r < 16; r++) s[r] = 0.f;
-        {
-            const float* krow = k_lds[buf] + l31 * HD;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if (dbg & 1) break;
-                const float4 kk = *reinterpret_cast<const float4*>(krow + 4 * (kslot0 ^ i));
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.x, qreg[4 * i + 0], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.y, qreg[4 * i + 1], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.z, qreg[4 * i + 2], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.w, qreg[4 * i + 3], s, 0, 0, 0);
-            }
+        if (!(dbg & 8)) {
+            if (kt + 2 < ntiles) issue_tile(kt + 2, buf, true, false);        // K(t+2) -> k_lds[t&1]
+            if (kt + 1 < ntiles) issue_tile(kt + 1, buf ^ 1, false, true);    // V(t+1) -> v_lds[(t+1)&1]
         }
-        // V operands of the first 8 P.V k-steps: fetched now, their LDS latency hides under the
-        // softmax VALU work; the other 8 are fetched while the first 16 MFMAs run
-        float va[8], vb[8];
+        // V operands of tile t's P.V MFMAs: issued first so that their LDS latency is covered by the
+        // max / rescale work below (the empty asm pins the loads here; the compiler otherwise sinks each
+        // one to just before its MFMA and waits for it)
+        float va[16], vb[16];
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < 16; r++) {
             const float* vrow = v_lds[buf] + acc_row(r, half) * HD + l31;
             va[r] = vrow[0];
             vb[r] = vrow[32];
         }
-        // ---- online softmax (lane owns 16 keys of its query; partner lane^32 owns the other 16)
+#pragma unroll
+        for (int r = 0; r < 16; r++) asm volatile("" : "+v"(va[r]), "+v"(vb[r]));
+        // ---- running maximum of tile t (lane owns 16 keys of its query; partner lane^32 the other 16)
         const int key_base = kt * KT;
         float m_tile = -INFINITY;
         if (key_base + KT > N) {   // ragged last tile: wavefront-uniform branch
@@ -136,11 +150,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
 #pragma unroll
         for (int r = 0; r < 16; r++) m_tile = fmaxf(m_tile, s[r]);
         m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
-        // Deferred rescale: the running maximum is only raised (and O, l rescaled -- 96 accumulator
-        // moves + 32 multiplies) when some query's tile maximum exceeds it by more than 2^RESCALE_THR;
-        // otherwise the probabilities are taken against the old maximum (bounded by 2^RESCALE_THR,
-        // harmless in fp32).  The decision is wavefront-uniform; O, l and the current P always share
-        // one scale, so the final O / l is the exact softmax.
+        // Deferred rescale: the running maximum is only raised (and O, l rescaled) when some query's tile
+        // maximum exceeds it by more than 2^RESCALE_THR; otherwise the probabilities are taken against
+        // the old maximum (bounded by 2^RESCALE_THR, harmless in fp32).  Wavefront-uniform decision; O, l
+        // and the current P always share one scale, so the final O / l is the exact softmax.
         if (__any(m_tile > m_run + RESCALE_THR)) {
             const float m_new = fmaxf(m_run, m_tile);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
@@ -149,37 +162,31 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
 #pragma unroll
             for (int r = 0; r < 16; r++) { o_lo[r] *= alpha; o_hi[r] *= alpha; }
         }
+        // ---- one straight-line region: Q.K^T of tile t+1 (matrix pipe) with the exponentials of tile t
+        // in its shadow (VALU), then P.V of tile t.  (After the last tile the extra Q.K^T runs on a stale
+        // K slot and is discarded -- keeping it unconditional keeps the region branch-free.)
+        f32x16 s_next = qk_tile(buf ^ 1);
         float psum = 0.f;
-        if (!(dbg & 2)) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                s[r] = __builtin_amdgcn_exp2f(s[r] - m_run);
-                psum += s[r];
-            }
+        for (int r = 0; r < 16; r++) {
+            s[r] = __builtin_amdgcn_exp2f(s[r] - m_run);
+            psum += s[r];
         }
         l_run += psum;
-        // ---- O^T += V^T P^T : k-step r pairs key acc_row(r,0) with acc_row(r,1)
-        float vc[8], vd[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const float* vrow = v_lds[buf] + acc_row(r + 8, half) * HD + l31;
-            vc[r] = vrow[0];
-            vd[r] = vrow[32];
+        for (int g = 0; g < 16; g++) {   // 2 MFMA then 3 VALU (sub, exp, add), 16 times
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
         }
-        if (!(dbg & 4)) {
+        // ---- O^T += V^T P^T : k-step r pairs key acc_row(r,0) with acc_row(r,1)
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < 16; r++) {
             o_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(va[r], s[r], o_lo, 0, 0, 0);
             o_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[r], s[r], o_hi, 0, 0, 0);
         }
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            o_lo = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[r], s[r + 8], o_lo, 0, 0, 0);
-            o_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(vd[r], s[r + 8], o_hi, 0, 0, 0);
-        }
-        } else { o_lo[0] += va[0] + vc[1] + s[3]; o_hi[1] += vb[2] + vd[3] + s[9]; }
+        s = s_next;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's DMA pieces have landed
-        if (!(dbg & 16)) __syncthreads();                     // ... everybody's; and nobody still reads `buf`
+        __syncthreads();                                      // ... everybody's; ring slots may be reused
     }
 
     // ---- normalise and store: lane holds O[q = l31][d = acc_row(r, half) (+32)]

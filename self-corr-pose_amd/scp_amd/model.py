@@ -49,6 +49,8 @@ class MeshNet(nn.Module):
         mean_v = self.mesh.mean_v[None].expand(bsz, -1, -1)
         faces = self.mesh.faces[None].expand(bsz, -1, -1)
 
+        if opts.train and getattr(self, "overlap_dino", True):
+            self.pretrain_corr_net.prefetch_features(img)
         img_feat, mesh_feat, pred_v, rotation, translation, scale = self.encoder(img, mean_v, pp_crop, foc_crop)
         pointcorr, match, imatch, match_conf = self.corr_net.match(img_feat, mesh_feat, mask, pred_v)
         tex = self.mesh.get_texture(pred_v, faces, imatch, img)

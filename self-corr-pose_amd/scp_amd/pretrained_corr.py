@@ -77,6 +77,28 @@ class PretrainedCorrespondence(nn.Module):
         indices_match = torch.gather(bw, -1, indices)
         return match, grid_k, indices_match, indices, match_mask
 
+    def prefetch_features(self, img):
+        """Start the frozen DINO ViT on a side HIP stream (it depends on nothing but the input images);
+        the encoder / correspondence / render work of the main stream overlaps with it and
+        compute_cycle_loss joins the stream right before it needs the features."""
+        if not img.is_cuda:
+            return
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=img.device)
+        self._side_stream.wait_stream(torch.cuda.current_stream(img.device))
+        with torch.cuda.stream(self._side_stream):
+            feats = self.net(img)
+        img.record_stream(self._side_stream)
+        self._prefetched = (img, feats)
+
+    def _features(self, img):
+        pre = getattr(self, "_prefetched", None)
+        self._prefetched = None
+        if pre is not None and pre[0] is img:
+            torch.cuda.current_stream(img.device).wait_stream(self._side_stream)
+            return pre[1]
+        return self.net(img)
+
     def compute_cycle_loss(self, img, mask, depth_weight, pointcorr):
         num_verts = pointcorr.shape[-1]
         src_idx, tgt_idx = pair_indices(self.divide_kind, self.opts.batch_size, self.opts.repeat, img.device)
@@ -84,7 +106,7 @@ class PretrainedCorrespondence(nn.Module):
         hh, wh = self.hf // 2, self.wf // 2
         grid = self.half_grid(n)
 
-        feats = self.net(img)                                                    # once per unique image
+        feats = self._features(img)                                              # once per unique image
         pts_src, pts_tgt, indices_src, indices_tgt, mask_k = self.match_features(
             feats[src_idx], feats[tgt_idx], mask[src_idx], mask[tgt_idx], grid)
 

@@ -76,3 +76,7 @@ rows = prof.key_averages(group_by_input_shape=True)
 rows = sorted(rows, key=lambda r: -r.device_time_total)[:130]
 for r in rows:
     print("%9.3f ms  x%-4d %-60s %s" % (r.device_time_total / 1e3, r.count, r.key[:60], str(r.input_shapes)[:110]))
+print("---- per-op totals (self device time) ----")
+rows = sorted(prof.key_averages(), key=lambda r: -r.self_device_time_total)[:60]
+for r in rows:
+    print("%9.3f ms  x%-5d %s" % (r.self_device_time_total / 1e3, r.count, r.key[:90]))
