@@ -52,6 +52,22 @@ class MeshNet(nn.Module):
         if opts.train and getattr(self, "overlap_dino", True):
             self.pretrain_corr_net.prefetch_features(img)
         img_feat, mesh_feat, pred_v, rotation, translation, scale = self.encoder(img, mean_v, pp_crop, foc_crop)
+        # The rotation-cycle branch (a second, independent encoder pass over the rotated images) only
+        # needs img / mask / img_feat: it runs on a side HIP stream next to the correspondence + render +
+        # loss work of the main stream (many small, latency-bound kernels); autograd replays each
+        # backward node on its forward stream, so the two backward halves overlap as well.
+        cycle_side = None
+        if opts.train and img.is_cuda and getattr(self, "overlap_rotation_cycle", True):
+            if getattr(self, "_cycle_stream", None) is None:
+                self._cycle_stream = torch.cuda.Stream(device=img.device)
+            main = torch.cuda.current_stream(img.device)
+            self._cycle_stream.wait_stream(main)
+            with torch.cuda.stream(self._cycle_stream):
+                cycle_side = self.corr_net.compute_rotation_cycle_loss(img, mask, img_feat, self.encoder,
+                                                                       angle=self.rotation_angle)[0]
+            for t in (img, mask, img_feat):
+                t.record_stream(self._cycle_stream)
+
         pointcorr, match, imatch, match_conf = self.corr_net.match(img_feat, mesh_feat, mask, pred_v)
         tex = self.mesh.get_texture(pred_v, faces, imatch, img)
         if not opts.train:
@@ -79,8 +95,12 @@ class MeshNet(nn.Module):
         deform_loss = wts.deform_wt * F.smooth_l1_loss(pred_v, mean_v, reduction="mean")
 
         cycle_loss_pt = self.pretrain_corr_net.compute_cycle_loss(img, mask, depth_weight, pointcorr)[0] * wts.cycle_loss_pt_wt
-        cycle_loss = self.corr_net.compute_rotation_cycle_loss(img, mask, img_feat, self.encoder,
-                                                               angle=self.rotation_angle)[0] * wts.cycle_loss_wt
+        if cycle_side is not None:
+            torch.cuda.current_stream(img.device).wait_stream(self._cycle_stream)
+            cycle_loss = cycle_side * wts.cycle_loss_wt
+        else:
+            cycle_loss = self.corr_net.compute_rotation_cycle_loss(img, mask, img_feat, self.encoder,
+                                                                   angle=self.rotation_angle)[0] * wts.cycle_loss_wt
 
         total_loss = (mask_loss + symmetry_loss + triangle_loss + deform_loss + pullfar_loss + texture_loss +
                       match_loss + imatch_loss + cycle_loss_pt + cycle_loss)

@@ -83,6 +83,9 @@ class PretrainedCorrespondence(nn.Module):
         compute_cycle_loss joins the stream right before it needs the features."""
         if not img.is_cuda:
             return
+        pre = getattr(self, "_prefetched", None)
+        if pre is not None and pre[0] is img:
+            return                      # already in flight (e.g. started during the previous step's backward)
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream(device=img.device)
         self._side_stream.wait_stream(torch.cuda.current_stream(img.device))

@@ -102,11 +102,17 @@ class Trainer:
         torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(views, grads)])
         return tuple(out)
 
-    def step(self, data):
-        """one training iteration on an already device-resident 12-tuple; returns (total_loss, aux, grad norms)"""
+    def step(self, data, next_data=None):
+        """one training iteration on an already device-resident 12-tuple; returns (total_loss, aux, grad norms).
+        `next_data` (optional): the following batch, if the input pipeline already has it on the device.
+        Its frozen-DINO features depend on nothing but the images, so their computation is enqueued on the
+        side stream before this step's backward and overlaps with it (software pipelining across
+        iterations; the next step finds them ready).  Per-step work is unchanged."""
         self.model.iters = self.iteration
         self.optim.zero_grad()
         total_loss, aux_output = self.model(data)
+        if next_data is not None:
+            self.model.pretrain_corr_net.prefetch_features(next_data[0])
         total_loss.mean().backward()
         grad = self.collect_grad()
         self.optim.step(self.iteration)
