@@ -130,6 +130,14 @@ size_t scp_nearest_point_workspace(int N, int P1);
 int scp_nearest_point(const float* x, const float* y, int N, int P1, int P2, long long* index,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- ViT residual-add + LayerNorm forward ------------------------------------------------------------
+ * Replaces `x = x + branch; y = norm(x)` between the sub-layers of a transformer block
+ * (vision_transformer_flexible.py:117-120,126-130; norm = nn.LayerNorm(C, eps=1e-6)):
+ *   sum_out[r,:] = x[r,:] + branch[r,:]   (branch may be NULL: sum = x; sum_out may be NULL or alias x)
+ *   y_out[r,:]   = (sum - mean) * rsqrt(var + eps) * gamma + beta        rows x C fp32, C even, <= 1024 */
+int scp_add_layernorm_forward(const float* x, const float* branch, const float* gamma, const float* beta,
+                              float eps, long rows, int C, float* sum_out, float* y_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

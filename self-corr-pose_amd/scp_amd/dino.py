@@ -81,6 +81,21 @@ def fused_attention(qkv, b, n, heads, head_dim, scale):
     return out
 
 
+def add_layernorm(x, branch, norm):
+    """(x + branch, LayerNorm(x + branch)) in one HBM pass (csrc/vit_norm.hip); branch may be None.
+    x is updated in place (the residual stream of a frozen, no-grad forward)."""
+    from . import capi
+    y = torch.empty_like(x)
+    rows, c = x.numel() // x.shape[-1], x.shape[-1]
+    code = capi.lib().scp_add_layernorm_forward(
+        capi.dev_ptr(x, "x"), capi.opt_ptr(branch, "branch"), capi.dev_ptr(norm.weight, "gamma"),
+        capi.dev_ptr(norm.bias, "beta"), float(norm.eps), rows, c,
+        capi.dev_ptr(x, "sum_out") if branch is not None else capi.opt_ptr(None, "sum_out"),
+        capi.dev_ptr(y, "y_out"), capi.current_stream())
+    capi.check(code, "scp_add_layernorm_forward")
+    return x, y
+
+
 class _Block(nn.Module):
     def __init__(self, dim, num_heads, mlp_ratio=4.):
         super().__init__()
@@ -147,6 +162,17 @@ class VisionTransformer(nn.Module):
     def key_features(self, x, layer=9):
         """keys of block `layer`: [b, heads, tokens, d]"""
         tok = self.prepare_tokens(x)
+        if tok.is_cuda and not torch.is_grad_enabled():
+            # frozen forward on the GPU: every residual add is fused into the LayerNorm that follows it
+            tok = tok.contiguous()
+            pending = None
+            for blk in self.blocks[:layer]:
+                tok, y = add_layernorm(tok, pending, blk.norm1)
+                tok, y = add_layernorm(tok, blk.attn(y), blk.norm2)
+                pending = blk.mlp(y)
+            blk = self.blocks[layer]
+            tok, y = add_layernorm(tok, pending, blk.norm1)
+            return blk.attn.keys(y)
         for blk in self.blocks[:layer]:
             tok = blk(tok)
         blk = self.blocks[layer]

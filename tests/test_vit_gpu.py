@@ -77,6 +77,25 @@ def test_attention_deferred_rescale_branch():
         assert (d <= 2e-5 + 1e-4 * ref.abs()).all(), "%s: max abs diff %.3e" % (mode, d.max())
 
 
+@pytest.mark.parametrize("rows,C", [(5, 384), (1025 * 3, 384), (7, 64), (33, 1024), (4, 130)])
+def test_add_layernorm_matches_torch(rows, C):
+    from scp_amd.dino import add_layernorm
+    g = torch.Generator().manual_seed(rows + C)
+    x, br = torch.randn(rows, C, generator=g) * 3 + 1, torch.randn(rows, C, generator=g)
+    norm = torch.nn.LayerNorm(C, eps=1e-6)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.1 * torch.randn(C, generator=g))
+        norm.bias.copy_(0.1 * torch.randn(C, generator=g))
+        ref_sum = x + br
+        ref_y, ref_y0 = norm(ref_sum), norm(x)
+        ncu = norm.cuda()
+        s, y = add_layernorm(x.clone().cuda(), br.cuda(), ncu)
+        _, y0 = add_layernorm(x.clone().cuda(), None, ncu)
+    torch.testing.assert_close(s.cpu(), ref_sum, rtol=0, atol=0)
+    torch.testing.assert_close(y.cpu(), ref_y, rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(y0.cpu(), ref_y0, rtol=1e-5, atol=2e-6)
+
+
 def test_dino_features_match_reference_fixture():
     import step_case
     model, data, d = step_case.build("cuda")
