@@ -85,15 +85,27 @@ def build_trainer(device, world, batch_size=8, repeat=4, seed=0):
 
 
 def cpu_baseline(sample_bs=2, sample_repeat=2):
-    """the step on the host cores: torch-CPU for the networks/correspondence, the C oracle for the
-    rasteriser (tests/oracle_backend.py).  Checker code, used here only as the thing being timed
-    for the baseline -- never on the product path."""
+    """the step on the host cores: torch-CPU for the stock networks, the CPU oracle (oracle/: C rasteriser,
+    torch restatements of the correspondence / ViT pieces) in place of every HIP kernel
+    (tests/oracle_backend.py).  Checker code, used here only as the thing being timed for the baseline --
+    the patches are undone before returning and never touch the GPU path."""
     import oracle_backend
     import synth
-    from scp_amd.soft_renderer.cuda import soft_rasterize as native
-    saved = (native.forward_soft_rasterize, native.backward_soft_rasterize)
-    native.forward_soft_rasterize = oracle_backend.forward_soft_rasterize
-    native.backward_soft_rasterize = oracle_backend.backward_soft_rasterize
+
+    class _Patch:
+        def __init__(self):
+            self.saved = []
+
+        def setattr(self, obj, name, value):
+            self.saved.append((obj, name, getattr(obj, name)))
+            setattr(obj, name, value)
+
+        def undo(self):
+            for obj, name, value in reversed(self.saved):
+                setattr(obj, name, value)
+
+    patch = _Patch()
+    oracle_backend.install(patch)
     try:
         threads = torch.get_num_threads()
         tr, _ = build_trainer("cpu", 1, sample_bs, sample_repeat)
@@ -103,7 +115,7 @@ def cpu_baseline(sample_bs=2, sample_repeat=2):
         tr.step(data)
         dt = time.perf_counter() - t0
     finally:
-        native.forward_soft_rasterize, native.backward_soft_rasterize = saved
+        patch.undo()
     n_img = sample_bs * sample_repeat
     return {"value": (n_img / 32.0) / dt, "unit": "train iters/sec (32-image iterations)", "cores": threads,
             "kind": "port", "sample": "1 full training step at B=%d (256x256, 642v/1280f), %.2f s, scaled by %d/32"

@@ -64,3 +64,22 @@ def bridge_cycle_oracle(pointcorr_src, pointcorr_tgt, dw_src, dw_tgt, grid, indi
     match = torch.gather(match, -1, indices_tgt[:, None].repeat(1, 2, 1))
     cycle_loss = ((match - pts_src).norm(2, 1) * mask).mean()
     return cycle_loss, match
+
+
+def cols_softargmax_oracle(scores, rowmask, colmask, grid, tau):
+    """grid @ softmax_P(tau * masked(scores)) with the reference's masking expression
+    (correspondence.py:44 / :106 / pretrained_corr.py:86): scores [N,P,Q], masks [N,P] / [N,Q] or None"""
+    keep = torch.ones_like(scores)
+    if rowmask is not None:
+        keep = keep * rowmask[:, :, None]
+    if colmask is not None:
+        keep = keep * colmask[:, None, :]
+    pc = scores * (keep > 0) - 1e5 * (keep == 0)
+    g = grid if grid.dim() == 3 else grid[None].repeat(scores.shape[0], 1, 1)
+    return g.bmm(torch.softmax(tau * pc, dim=1))
+
+
+def nearest_index_oracle(x, y):
+    """pytorch3d.ops.knn_points(x, y, K=1).idx[..., 0] (model/util/chamfer.py:135): exact squared
+    distances, lowest index on ties"""
+    return (x[:, :, None] - y[:, None]).pow(2).sum(-1).argmin(-1)

@@ -16,3 +16,9 @@ def attention_oracle(qkv_linear_out, num_heads, scale):
     attn = (q @ k.transpose(-2, -1)) * scale
     attn = attn.softmax(dim=-1)
     return (attn @ v).transpose(1, 2).reshape(B, N, C)
+
+
+def add_layernorm_oracle(x, branch, weight, bias, eps):
+    """x = x + drop_path(branch); y = norm(x)  (vision_transformer_flexible.py:117-120)"""
+    s = x if branch is None else x + branch
+    return s, torch.nn.functional.layer_norm(s, (s.shape[-1],), weight, bias, eps)

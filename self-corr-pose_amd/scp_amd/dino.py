@@ -49,12 +49,7 @@ class _Attention(nn.Module):
 
     def forward(self, x):
         b, n, c = x.shape
-        qkv = self.qkv(x)
-        if qkv.is_cuda and not torch.is_grad_enabled():
-            y = fused_attention(qkv, b, n, self.num_heads, c // self.num_heads, self.scale)   # HIP, [b,n,c]
-        else:
-            qkv = qkv.reshape(b, n, 3, self.num_heads, c // self.num_heads).permute(2, 0, 3, 1, 4)
-            y = attention(qkv[0], qkv[1], qkv[2], self.scale).transpose(1, 2).reshape(b, n, c)
+        y = fused_attention(self.qkv(x), b, n, self.num_heads, c // self.num_heads, self.scale)   # [b,n,c]
         return self.proj(y)
 
     def keys(self, x):
@@ -64,15 +59,13 @@ class _Attention(nn.Module):
         return k.reshape(b, n, self.num_heads, c // self.num_heads).permute(0, 2, 1, 3)
 
 
-def attention(q, k, v, scale):
-    """softmax(q k^T * scale) v over [b, h, n, d] (stock torch; non-GPU tensors / autograd)"""
-    return F.scaled_dot_product_attention(q, k, v, scale=scale)
-
-
 def fused_attention(qkv, b, n, heads, head_dim, scale):
     """HIP flash-style attention on the fp32 matrix cores (csrc/vit_attn.hip): qkv [b,n,3*heads*head_dim]
-    as produced by the qkv Linear -> [b, n, heads*head_dim], forward only (the ViT is frozen)"""
+    as produced by the qkv Linear -> [b, n, heads*head_dim].  Forward only (the DINO ViT is frozen and
+    always evaluated under no_grad); GPU tensors only, no CPU fallback."""
     from . import capi
+    if torch.is_grad_enabled() and qkv.requires_grad:
+        raise RuntimeError("scp_amd.dino.fused_attention is forward-only (frozen ViT)")
     qkv = qkv.contiguous()
     out = torch.empty(b, n, heads * head_dim, dtype=torch.float32, device=qkv.device)
     code = capi.lib().scp_vit_attention_forward(capi.dev_ptr(qkv, "qkv"), capi.dev_ptr(out, "out"), b, n, heads,
@@ -83,8 +76,10 @@ def fused_attention(qkv, b, n, heads, head_dim, scale):
 
 def add_layernorm(x, branch, norm):
     """(x + branch, LayerNorm(x + branch)) in one HBM pass (csrc/vit_norm.hip); branch may be None.
-    x is updated in place (the residual stream of a frozen, no-grad forward)."""
+    x is updated in place (the residual stream of a frozen, no-grad forward).  GPU tensors only."""
     from . import capi
+    if torch.is_grad_enabled() and (x.requires_grad or norm.weight.requires_grad):
+        raise RuntimeError("scp_amd.dino.add_layernorm is forward-only (frozen ViT)")
     y = torch.empty_like(x)
     rows, c = x.numel() // x.shape[-1], x.shape[-1]
     code = capi.lib().scp_add_layernorm_forward(
@@ -104,9 +99,12 @@ class _Block(nn.Module):
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
 
-    def forward(self, x):
-        x = x + self.attn(self.norm1(x))
-        return x + self.mlp(self.norm2(x))
+    def forward(self, x, pending=None):
+        """x: residual stream, pending: output of the previous block's MLP not yet added to it.
+        Returns (x, pending') -- every residual add is fused into the LayerNorm that follows it."""
+        x, y = add_layernorm(x, pending, self.norm1)
+        x, y = add_layernorm(x, self.attn(y), self.norm2)
+        return x, self.mlp(y)
 
 
 class _PatchEmbed(nn.Module):
@@ -161,28 +159,20 @@ class VisionTransformer(nn.Module):
 
     def key_features(self, x, layer=9):
         """keys of block `layer`: [b, heads, tokens, d]"""
-        tok = self.prepare_tokens(x)
-        if tok.is_cuda and not torch.is_grad_enabled():
-            # frozen forward on the GPU: every residual add is fused into the LayerNorm that follows it
-            tok = tok.contiguous()
-            pending = None
-            for blk in self.blocks[:layer]:
-                tok, y = add_layernorm(tok, pending, blk.norm1)
-                tok, y = add_layernorm(tok, blk.attn(y), blk.norm2)
-                pending = blk.mlp(y)
-            blk = self.blocks[layer]
-            tok, y = add_layernorm(tok, pending, blk.norm1)
-            return blk.attn.keys(y)
+        tok, pending = self.prepare_tokens(x).contiguous(), None
         for blk in self.blocks[:layer]:
-            tok = blk(tok)
+            tok, pending = blk(tok, pending)
         blk = self.blocks[layer]
-        return blk.attn.keys(blk.norm1(tok))
+        tok, y = add_layernorm(tok, pending, blk.norm1)
+        return blk.attn.keys(y)
 
+    @torch.no_grad()
     def forward(self, x):
-        tok = self.prepare_tokens(x)
+        """class-token embedding of the full 12-block ViT (not used by the training step)"""
+        tok, pending = self.prepare_tokens(x).contiguous(), None
         for blk in self.blocks:
-            tok = blk(tok)
-        return self.norm(tok)[:, 0]
+            tok, pending = blk(tok, pending)
+        return add_layernorm(tok, pending, self.norm)[1][:, 0]
 
 
 def vit_small(patch_size=8):

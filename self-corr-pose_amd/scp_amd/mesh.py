@@ -58,26 +58,19 @@ def sample_points_from_meshes(verts, faces, num_samples, sample_override=None):
     return (corners * bary[..., None]).sum(2)
 
 
-def nearest_sq_dist(x, y, chunk_bytes=2 << 30):
+def nearest_sq_dist(x, y):
     """for every x[n,i] the squared distance to its nearest y[n,j]; gradients flow to x and to the
-    selected y (pytorch3d knn_points K=1 semantics)"""
-    n, p1, _ = x.shape
-    p2 = y.shape[1]
-    if x.is_cuda:
-        idx = _nearest_index_hip(x.detach(), y.detach())
-        y_nn = torch.gather(y, 1, idx[..., None].expand(-1, -1, 3))
-        return (x - y_nn).pow(2).sum(-1)
-    per_item = p1 * p2 * 4
-    step = max(1, int(chunk_bytes // max(per_item, 1)))
-    idx = []
-    with torch.no_grad():
-        for s in range(0, n, step):
-            xs, ys = x[s:s + step], y[s:s + step]
-            d = xs.pow(2).sum(-1)[:, :, None] - 2 * xs.bmm(ys.transpose(1, 2)) + ys.pow(2).sum(-1)[:, None, :]
-            idx.append(d.argmin(-1))
-    idx = torch.cat(idx, 0)
+    selected y (pytorch3d knn_points K=1 semantics).  The search runs on the HIP kernel (csrc/nearest.hip);
+    GPU tensors only."""
+    idx = nearest_index(x.detach(), y.detach())
     y_nn = torch.gather(y, 1, idx[..., None].expand(-1, -1, 3))
     return (x - y_nn).pow(2).sum(-1)
+
+
+def nearest_index(x, y):
+    if not x.is_cuda:
+        raise RuntimeError("scp_amd.mesh.nearest_index runs on the HIP kernel only (no CPU fallback)")
+    return _nearest_index_hip(x, y)
 
 
 def _nearest_index_hip(x, y):

@@ -1,9 +1,11 @@
 """scp_amd/ops.py -- the dense correspondence operators of the step, behind one small interface.
 
 Each function states its tensor contract once; Correspondence / PretrainedCorrespondence call these
-and nothing else for all-pairs work.  GPU tensors run the hand-written HIP kernels (csrc/corr.hip via
-scp_amd.corr_ops); non-GPU tensors evaluate the plain-torch definition written next to it (host-logic
-tests on machines without a GPU; this is stock PyTorch, not the oracle).
+and nothing else for all-pairs work.  The reductions that have hand-written HIP kernels
+(cols_softargmax, feature_vertex_match; csrc/corr.hip via scp_amd.corr_ops) accept GPU tensors ONLY and
+raise otherwise -- there is no CPU fallback in the product; CPU tests substitute the oracle
+(oracle/corr.py) for them with monkeypatch (tests/oracle_backend.py).  The remaining functions are
+compositions of stock PyTorch ops (library GEMMs, argmax, gather) and run on any device.
 
 Reference call sites: model/module/correspondence.py:42-53 (feature_vertex_match), :58-60
 (nearest_vertex), :105-110 (pixel_pixel_softargmax); model/module/pretrained_corr.py:85-102
@@ -14,6 +16,11 @@ import torch
 from . import corr_ops
 
 
+def _require_gpu(t, name):
+    if not t.is_cuda:
+        raise RuntimeError("scp_amd.ops.%s runs on the HIP kernels only (got a %s tensor; no CPU fallback)" % (name, t.device))
+
+
 def _masked(pc, keep):
     """pc * [m>0] - 1e5 * [m==0]  (correspondence.py:44, pretrained_corr.py:86)"""
     return torch.where(keep, pc, torch.full_like(pc, -1e5))
@@ -22,30 +29,16 @@ def _masked(pc, keep):
 def cols_softargmax(scores, rowmask, colmask, grid, tau):
     """scores [N,P,Q]; rowmask [N,P] / colmask [N,Q] or None (entry masked to -1e5 where a mask is 0);
     grid [2,P] or [N,2,P]  ->  [N,2,Q] = grid @ softmax_P(tau * masked(scores))"""
-    if scores.is_cuda:
-        return corr_ops.ColsSoftArgmax.apply(scores, rowmask, colmask, grid, tau)
-    keep = torch.ones_like(scores, dtype=torch.bool)
-    if rowmask is not None:
-        keep = keep & (rowmask > 0)[:, :, None]
-    if colmask is not None:
-        keep = keep & (colmask > 0)[:, None, :]
-    g = grid if grid.dim() == 3 else grid[None].expand(scores.shape[0], -1, -1)
-    return g.bmm(torch.softmax(tau * _masked(scores, keep), dim=1))
+    _require_gpu(scores, "cols_softargmax")
+    return corr_ops.ColsSoftArgmax.apply(scores, rowmask, colmask, grid, tau)
 
 
 def feature_vertex_match(img_feat, mesh_feat, mask_down, verts, grid, tau_img, tau_mesh):
     """img_feat [B,C,P], mesh_feat [B,V,C], mask_down [B,P], verts [B,V,3] (no grad), grid [2,P]
     -> pointcorr [B,P,V] (masked scores), match [B,P,3] = softmax_V(tau_img*pc) @ verts,
        imatch [B,2,V] = grid @ softmax_P(tau_mesh*pc)"""
-    if img_feat.is_cuda:
-        return corr_ops.FeatureVertexMatch.apply(img_feat, mesh_feat, mask_down, verts, grid, tau_img, tau_mesh)
-    pc = mesh_feat.bmm(img_feat).permute(0, 2, 1)
-    pc = _masked(pc, (mask_down > 0)[:, :, None])
-    p_mesh = torch.softmax(tau_mesh * pc, dim=1)
-    p_img = torch.softmax(tau_img * pc, dim=2)
-    imatch = grid[None].expand(pc.shape[0], -1, -1).bmm(p_mesh)
-    match = p_img.bmm(verts)
-    return pc, match, imatch
+    _require_gpu(img_feat, "feature_vertex_match")
+    return corr_ops.FeatureVertexMatch.apply(img_feat, mesh_feat, mask_down, verts, grid, tau_img, tau_mesh)
 
 
 def nearest_vertex(points, verts):
@@ -73,15 +66,11 @@ def pool2x2_scores(pc, hf, wf):
     """pc [B, hf*wf, V] -> [B, (hf/2)*(wf/2), V]: 2x2 spatial mean of every vertex' score map.
     The reference reaches it through a bilinear F.interpolate to half resolution of the permuted
     [B,V,hf,wf] view (pretrained_corr.py:120-123), which for an exact factor 2 with
-    align_corners=False is this mean, evaluated in the same order (0.5*(0.5a+0.5b)+0.5*(0.5c+0.5d))."""
+    align_corners=False is this mean."""
     b, _, v = pc.shape
-    x = pc.reshape(b, hf // 2, 2, wf // 2, 2, v)
-    if pc.is_cuda:
-        # one reduction kernel forward, one broadcast backward (the indexed form below costs four
-        # select_backward + three accumulate passes over the 0.34 GB gradient); same value up to the
-        # order of the four additions
-        return (x.sum((2, 4)) * 0.25).reshape(b, -1, v)
-    return ((x[:, :, 0, :, 0] + x[:, :, 0, :, 1]) * 0.5 * 0.5 + (x[:, :, 1, :, 0] + x[:, :, 1, :, 1]) * 0.5 * 0.5).reshape(b, -1, v)
+    # one reduction forward, one broadcast backward; equals the bilinear form up to the order of the four
+    # additions (last ulp)
+    return (pc.reshape(b, hf // 2, 2, wf // 2, 2, v).sum((2, 4)) * 0.25).reshape(b, -1, v)
 
 
 def vertex_bridge_match(pooled, src_idx, tgt_idx, tgt_pixels, keep, grid_half, tau_img, tau_mesh):

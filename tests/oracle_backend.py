@@ -1,10 +1,13 @@
 """tests/oracle_backend.py -- lets CPU tests drive the product's HOST logic (autograd glue,
-SoftRenderer, model code) with the CPU oracle standing in for the HIP kernels.  Test-only: the
-product never imports this; tests install it with pytest's monkeypatch."""
+SoftRenderer, model code) with the CPU oracle standing in for EVERY HIP kernel (rasteriser,
+correspondence reductions, ViT attention / LayerNorm, nearest neighbour).  Test-only: the product never
+imports this; tests install it with pytest's monkeypatch.  Without it the product raises on CPU tensors."""
 import numpy as np
 import torch
 
+from oracle import corr as oracle_corr
 from oracle import softras as oracle
+from oracle import vit as oracle_vit
 
 
 def _np(t):
@@ -31,7 +34,27 @@ def backward_soft_rasterize(faces, textures, soft_colors, faces_info, aggrs_info
     return [grad_faces, grad_textures]
 
 
+def feature_vertex_match(img_feat, mesh_feat, mask_down, verts, grid, tau_img, tau_mesh):
+    return oracle_corr.match_oracle(img_feat, mesh_feat, mask_down, verts, grid, tau_img, tau_mesh)
+
+
+def fused_attention(qkv, b, n, heads, head_dim, scale):
+    return oracle_vit.attention_oracle(qkv, heads, scale)
+
+
+def add_layernorm(x, branch, norm):
+    return oracle_vit.add_layernorm_oracle(x, branch, norm.weight, norm.bias, norm.eps)
+
+
 def install(monkeypatch):
+    import scp_amd.dino as dino
+    import scp_amd.mesh as mesh
+    import scp_amd.ops as ops
     from scp_amd.soft_renderer.cuda import soft_rasterize as native
     monkeypatch.setattr(native, "forward_soft_rasterize", forward_soft_rasterize)
     monkeypatch.setattr(native, "backward_soft_rasterize", backward_soft_rasterize)
+    monkeypatch.setattr(ops, "feature_vertex_match", feature_vertex_match)
+    monkeypatch.setattr(ops, "cols_softargmax", oracle_corr.cols_softargmax_oracle)
+    monkeypatch.setattr(dino, "fused_attention", fused_attention)
+    monkeypatch.setattr(dino, "add_layernorm", add_layernorm)
+    monkeypatch.setattr(mesh, "nearest_index", oracle_corr.nearest_index_oracle)

@@ -44,6 +44,19 @@ def test_product_path_fails_loudly_without_gpu_tensors():
         pytest.skip("CPU-only check")
     with pytest.raises(RuntimeError):
         srf.soft_rasterize(fv, tex, 32, texture_type="vertex")
+    # ... and so does every other HIP-backed operator of the step
+    from scp_amd import dino, mesh, ops
+    with pytest.raises(RuntimeError):
+        ops.cols_softargmax(torch.rand(1, 4, 5), None, None, torch.rand(2, 4), 10.)
+    with pytest.raises(RuntimeError):
+        ops.feature_vertex_match(torch.rand(1, 3, 4), torch.rand(1, 5, 3), torch.ones(1, 4), torch.rand(1, 5, 3),
+                                 torch.rand(2, 4), 10., 10.)
+    with pytest.raises(RuntimeError):
+        dino.fused_attention(torch.rand(1, 8, 192), 1, 8, 1, 64, 0.125)
+    with pytest.raises(RuntimeError):
+        dino.add_layernorm(torch.rand(4, 8), None, torch.nn.LayerNorm(8))
+    with pytest.raises(RuntimeError):
+        mesh.nearest_sq_dist(torch.rand(1, 4, 3), torch.rand(1, 6, 3))
 
 
 def test_product_does_not_reference_the_oracle():

@@ -71,7 +71,9 @@ def _run_product_match(dev):
     _grad_close(mesh_feat.grad, d["grad_mesh_feat"])
 
 
-def test_host_match_reproduces_reference():
+def test_host_match_reproduces_reference(monkeypatch):
+    import oracle_backend
+    oracle_backend.install(monkeypatch)
     _run_product_match("cpu")
 
 
@@ -100,12 +102,16 @@ def _run_rotation_cycle(dev, monkeypatch_rotate=None):
     _grad_close(tgt_feat.grad, d["grad_tgt_feat"])
 
 
-def test_host_rotation_cycle_reproduces_reference():
+def test_host_rotation_cycle_reproduces_reference(monkeypatch):
+    import oracle_backend
+    oracle_backend.install(monkeypatch)
     _run_rotation_cycle("cpu")
 
 
-def test_reassociated_bridge_equals_reference_formulation():
+def test_reassociated_bridge_equals_reference_formulation(monkeypatch):
     """ops.vertex_bridge_match (no [N,P,P] matrix) == the reference's corr-matrix formulation"""
+    import oracle_backend
+    oracle_backend.install(monkeypatch)
     from scp_amd import ops
     g = torch.Generator().manual_seed(5)
     B, hf, V, K = 4, 8, 37, 9
@@ -187,7 +193,13 @@ def test_hip_cols_softargmax_masks_and_batched_grid():
         (out * w.to(dev)).sum().backward()
         return out, x.grad
 
-    (o_ref, g_ref), (o_hip, g_hip) = run("cpu"), run("cuda")
+    def run_ref():
+        x = s.detach().clone().requires_grad_(True)
+        out = oracle.cols_softargmax_oracle(x, rm, cm, grid, 10.)
+        (out * w).sum().backward()
+        return out, x.grad
+
+    (o_ref, g_ref), (o_hip, g_hip) = run_ref(), run("cuda")
     _close(o_hip, o_ref.detach().numpy())
     _grad_close(g_hip, g_ref.numpy())
 

@@ -47,7 +47,9 @@ def test_regularisers_and_pairing_match_reference():
     np.testing.assert_allclose(L.pinhole_cam(_t(d["cam_verts"]), _t(d["cam_pp"]), _t(d["cam_foc"])).numpy(), d["cam_out"], rtol=1e-6)
 
 
-def test_eval_mode_confidence_matches_reference():
+def test_eval_mode_confidence_matches_reference(monkeypatch):
+    import oracle_backend
+    oracle_backend.install(monkeypatch)
     from scp_amd.correspondence import Correspondence
     from scp_amd.flags import Options
     d = golden_io.load("corr_eval_conf_b2")

@@ -24,7 +24,8 @@ def test_full_step_matches_reference(case, monkeypatch):
     assert "total_loss" in report
 
 
-def test_dino_key_features_match_reference():
+def test_dino_key_features_match_reference(monkeypatch):
+    oracle_backend.install(monkeypatch)
     model, data, d = step_case.build("cpu")
     feat = model.pretrain_corr_net.net(data[0][:2])
     assert feat.shape == (2, 384, 32, 32)
