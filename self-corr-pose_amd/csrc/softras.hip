@@ -52,7 +52,6 @@ struct RasterArgs {
     const float* faces;
     const float* textures;
     const float* faces_info;
-    float* faces_info_out;
     float* aggrs_info;
     float* soft_colors;
     const float* soft_colors_in;
@@ -791,7 +790,7 @@ extern "C" int scp_soft_rasterize_forward(const float* faces, const float* textu
     if (int e = fill_args(a, p)) return e;
     if (a.B == 0 || a.total_tiles == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    a.faces = faces; a.textures = textures; a.faces_info = faces_info; a.faces_info_out = faces_info;
+    a.faces = faces; a.textures = textures; a.faces_info = faces_info;
     a.aggrs_info = aggrs_info; a.soft_colors = soft_colors;
     const int nf = a.B * a.F;
     if (nf > 0) {

@@ -30,6 +30,10 @@ class Trainer:
         # MIOpen solver search, as the reference does (train.py:21 cudnn.benchmark = True); without
         # it MIOpen's immediate mode falls back to naive fp32 convolutions for several layers
         torch.backends.cudnn.benchmark = True
+        # the rotation-cycle branch runs on a side stream (model.py); its parameters' AccumulateGrad nodes
+        # then see gradients from two streams, which autograd synchronises correctly but warns about
+        if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         self.model = MeshNet(opts, prior)
         if opts.model_path:
             self.model.load_network(opts.model_path)
