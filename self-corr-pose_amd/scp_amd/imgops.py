@@ -12,6 +12,7 @@ import math
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from .hostconst import small_tensor
 
 
 class Normalize(nn.Module):
@@ -106,7 +107,7 @@ def rotate(img, angle, interpolation="nearest"):
     a = math.radians(angle)
     # output pixel (x, y), centred, y down -> source location: rotate by +a in image coordinates
     cos, sin = math.cos(a), math.sin(a)
-    theta = torch.tensor([[cos, -sin * h / w, 0.0], [sin * w / h, cos, 0.0]], dtype=img.dtype, device=img.device)
+    theta = small_tensor([[cos, -sin * h / w, 0.0], [sin * w / h, cos, 0.0]], img.dtype, img.device)
     grid = F.affine_grid(theta[None].expand(n, -1, -1), (n, 1, h, w), align_corners=False)
     out = F.grid_sample(img, grid, mode="bilinear" if interpolation == "bilinear" else "nearest",
                         padding_mode="zeros", align_corners=False)

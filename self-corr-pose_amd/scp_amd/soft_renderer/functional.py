@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from .cuda import soft_rasterize as _native
+from ..hostconst import const_tensor
 
 DIST_IDS = {"hard": 0, "barycentric": 1, "euclidean": 2}
 RGB_IDS = {"hard": 0, "softmax": 1}
@@ -123,7 +124,7 @@ def vertex_normals(vertices, faces):
 
 
 def _as_rows(x, nb, device):
-    x = torch.as_tensor(x, dtype=torch.float32, device=device)
+    x = const_tensor(x, torch.float32, device)
     return x[None].repeat(nb, 1) if x.dim() == 1 else x
 
 
@@ -154,12 +155,12 @@ def perspective(vertices, angle=30.):
 
 
 def ambient_lighting(light, light_intensity=0.5, light_color=(1, 1, 1)):
-    color = torch.as_tensor(light_color, dtype=torch.float32, device=light.device).reshape(1, 1, 3)
+    color = const_tensor(light_color, torch.float32, light.device).reshape(1, 1, 3)
     return light + light_intensity * color
 
 
 def directional_lighting(light, normals, light_intensity=0.5, light_color=(1, 1, 1), light_direction=(0, 1, 0)):
-    color = torch.as_tensor(light_color, dtype=torch.float32, device=light.device).reshape(1, 1, 3)
-    direction = torch.as_tensor(light_direction, dtype=torch.float32, device=light.device).reshape(1, 1, 3)
+    color = const_tensor(light_color, torch.float32, light.device).reshape(1, 1, 3)
+    direction = const_tensor(light_direction, torch.float32, light.device).reshape(1, 1, 3)
     cosine = F.relu(torch.sum(normals * direction, dim=2))
     return light + light_intensity * (color * cosine[:, :, None])
