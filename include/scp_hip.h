@@ -138,6 +138,20 @@ int scp_nearest_point(const float* x, const float* y, int N, int P1, int P2, lon
 int scp_add_layernorm_forward(const float* x, const float* branch, const float* gamma, const float* beta,
                               float eps, long rows, int C, float* sum_out, float* y_out, void* stream);
 
+/* ---- encoder input transform: ColorJitter + Normalize in one pass ------------------------------------
+ * Replaces `self.resnet_transform(self.random_jitter(img))` of model/module/encoder.py:18-19,31
+ * (torchvision 0.11 `ColorJitter(0.2,0.2,0.2,0.05)` + `Normalize`, tensor backend, un-vendored):
+ *   img [N,3,H,W] fp32 in [0,1];  order[4] = this call's permutation of op ids
+ *   (0 brightness, 1 contrast, 2 saturation, 3 hue; -1 = op disabled);  ratio[k] / one_minus[k] = the
+ *   blend factor of op k and (1 - factor) as the host computed it in double;  hue_shift in [-0.5,0.5];
+ *   out = (jittered - mean) / std, laid out [N,H,W,3] when out_nhwc != 0, else [N,3,H,W].
+ *   The contrast anchor is the per-image mean of the grey image at contrast's position in the chain.
+ *   workspace >= scp_color_jitter_workspace(N) bytes (only read when contrast is enabled). */
+size_t scp_color_jitter_workspace(int N);
+int scp_color_jitter_normalize(const float* img, int N, int H, int W, const int* order, const float* ratio,
+                               const float* one_minus, float hue_shift, const float* mean, const float* stdv,
+                               int out_nhwc, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

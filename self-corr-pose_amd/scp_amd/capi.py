@@ -43,6 +43,8 @@ SYMBOLS = {
     "scp_softmax_rows_weighted_forward": (ctypes.c_int, [_P, _P, _I, _F, _I, _I, _I, _P, _P, _P]),
     "scp_nearest_point_workspace": (ctypes.c_size_t, [_I, _I]),
     "scp_nearest_point": (ctypes.c_int, [_P, _P, _I, _I, _I, _P, _P, ctypes.c_size_t, _P]),
+    "scp_color_jitter_workspace": (ctypes.c_size_t, [_I]),
+    "scp_color_jitter_normalize": (ctypes.c_int, [_P, _I, _I, _I, _P, _P, _P, _F, _P, _P, _I, _P, _P, ctypes.c_size_t, _P]),
     "scp_add_layernorm_forward": (ctypes.c_int, [_P, _P, _P, _P, _F, ctypes.c_long, _I, _P, _P, _P]),
     "scp_vit_attention_forward": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "scp_dual_softmax_backward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _F,

@@ -25,7 +25,7 @@ class Encoder(nn.Module):
         self.pose_predictor = PosePredictor(opts, 512)
 
     def encode_img(self, img):
-        x = self.resnet_transform(self.random_jitter(img))
+        x = imgops.jitter_normalize(img, self.random_jitter, self.resnet_transform)
         if x.is_cuda:
             # NHWC end to end: MIOpen's fp32 implicit-GEMM kernels and PyTorch's NHWC bilinear
             # upsampling are ~2x faster on gfx950 than the NCHW paths for these shapes (measured,

@@ -7,6 +7,7 @@ the jitter by identity and use angles that are multiples of 90 degrees, where `r
 (the same substitution is made on the reference side, tests/golden/ref_harness.py).
 Call sites in the reference: model/module/encoder.py:18-19,31 and correspondence.py:87-89.
 """
+import ctypes
 import math
 
 import torch
@@ -18,6 +19,7 @@ from .hostconst import small_tensor
 class Normalize(nn.Module):
     def __init__(self, mean, std):
         super().__init__()
+        self.host_mean, self.host_std = [float(m) for m in mean], [float(v) for v in std]
         self.register_buffer("mean", torch.tensor(mean, dtype=torch.float32).view(1, -1, 1, 1), persistent=False)
         self.register_buffer("std", torch.tensor(std, dtype=torch.float32).view(1, -1, 1, 1), persistent=False)
 
@@ -75,22 +77,58 @@ class ColorJitter(nn.Module):
         super().__init__()
         self.brightness, self.contrast, self.saturation, self.hue = brightness, contrast, saturation, hue
 
-    def forward(self, img):
+    def draw(self):
+        """this call's op order and factors: (order, [brightness, contrast, saturation factor], hue shift).
+        Host RNG, no device sync."""
         order = torch.randperm(4).tolist()
-        rnd = torch.empty(4).uniform_(-1, 1).tolist()  # host RNG, no device sync
+        rnd = torch.empty(4).uniform_(-1, 1).tolist()
+        amount = (self.brightness, self.contrast, self.saturation)
+        order = [op for op in order if (amount[op] if op < 3 else self.hue) > 0]
+        return order, [1.0 + amount[k] * rnd[k] for k in range(3)], self.hue * rnd[3]
+
+    def forward(self, img):
+        return self.apply_ops(img, *self.draw())
+
+    @staticmethod
+    def apply_ops(img, order, ratio, hue_shift):
         for op in order:
-            if op == 0 and self.brightness > 0:
-                img = _blend(img, torch.zeros_like(img), 1.0 + self.brightness * rnd[0])
-            elif op == 1 and self.contrast > 0:
+            if op == 0:
+                img = _blend(img, torch.zeros_like(img), ratio[0])
+            elif op == 1:
                 mean = _gray(img).mean((-3, -2, -1), keepdim=True)
-                img = _blend(img, mean, 1.0 + self.contrast * rnd[1])
-            elif op == 2 and self.saturation > 0:
-                img = _blend(img, _gray(img), 1.0 + self.saturation * rnd[2])
-            elif op == 3 and self.hue > 0:
+                img = _blend(img, mean, ratio[1])
+            elif op == 2:
+                img = _blend(img, _gray(img), ratio[2])
+            elif op == 3:
                 hsv = _rgb_to_hsv(img)
-                h = (hsv[..., 0:1, :, :] + self.hue * rnd[3]) % 1.0
+                h = (hsv[..., 0:1, :, :] + hue_shift) % 1.0
                 img = _hsv_to_rgb(torch.cat((h, hsv[..., 1:, :, :]), -3))
         return img
+
+
+def jitter_normalize(img, jitter, normalize):
+    """`normalize(jitter(img))` for the encoder.  CUDA: ONE fused HIP pass that also lands the result in
+    channels_last storage (csrc/imgops.hip; no fallback -- capi raises without the library).  CPU (golden
+    runs, CPU baseline): the torch composition above."""
+    if not img.is_cuda or not isinstance(jitter, ColorJitter):
+        return normalize(jitter(img))
+    from . import capi
+    order, ratio, hue_shift = jitter.draw()
+    n, c, h, w = img.shape
+    if c != 3:
+        raise ValueError("jitter_normalize expects RGB images [N,3,H,W]")
+    img = img.contiguous().float()
+    out = torch.empty((n, 3, h, w), dtype=torch.float32, device=img.device, memory_format=torch.channels_last)
+    L = capi.lib()
+    ws = torch.empty(max(1, L.scp_color_jitter_workspace(n) // 4), dtype=torch.float32, device=img.device)
+    i4, f3 = ctypes.c_int * 4, ctypes.c_float * 3
+    slots = list(order) + [-1] * (4 - len(order))
+    capi.check(L.scp_color_jitter_normalize(
+        capi.dev_ptr(img, "img"), n, h, w, i4(*slots), f3(*ratio), f3(*[1.0 - r for r in ratio]),
+        float(hue_shift), f3(*normalize.host_mean),
+        f3(*normalize.host_std), 1, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+        ws.numel() * 4, capi.current_stream()), "color_jitter_normalize")
+    return out
 
 
 def rotate(img, angle, interpolation="nearest"):
