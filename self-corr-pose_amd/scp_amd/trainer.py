@@ -8,6 +8,9 @@ The reference has no `step()`; its loop body is model/trainer.py:118-125 (zero_g
 Data-parallel operation: scp_amd.parallel.GradientAllReducer averages gradients over RCCL before
 the clip (the reference constructs DDP but bypasses it).
 """
+import os
+import tempfile
+
 import torch
 
 from .model import MeshNet
@@ -23,6 +26,27 @@ def freeze_batchnorm_affine(model):
                 p.requires_grad = False
 
 
+TUNED_GEMMS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tuning", "gemm_gfx950.csv")
+
+
+def enable_gemm_tuning():
+    """The GEMM-side twin of cudnn.benchmark: PyTorch's TunableOp times the rocBLAS / hipBLASLt solutions
+    for every GEMM shape the step issues and keeps the fastest (the ViT-S linears go from 0.41/0.38/0.32 ms
+    to 0.23/0.30/0.28 ms per launch on MI355X, -2.2 ms per step).  Selections recorded on an MI355X are shipped in
+    tuning/gemm_gfx950.csv so that a fresh process starts tuned (TunableOp ignores the file if its
+    library-version validators do not match, and tunes online during the first steps instead).
+    SCP_GEMM_TUNING=0 disables it.  New results go to a scratch file, never back into the package."""
+    if os.environ.get("SCP_GEMM_TUNING", "1") == "0":
+        return
+    tun = torch.cuda.tunable
+    tun.enable(True)
+    tun.set_filename(os.path.join(tempfile.gettempdir(), "scp_tunableop_%d.csv" % os.getpid()), False)
+    tun.set_max_tuning_duration(30)
+    tun.tuning_enable(True)
+    if os.path.exists(TUNED_GEMMS):
+        tun.read_file(TUNED_GEMMS)
+
+
 class Trainer:
     def __init__(self, opts, prior=None, device=None, process_group=None, sync_bn=False):
         self.opts = opts
@@ -30,6 +54,8 @@ class Trainer:
         # MIOpen solver search, as the reference does (train.py:21 cudnn.benchmark = True); without
         # it MIOpen's immediate mode falls back to naive fp32 convolutions for several layers
         torch.backends.cudnn.benchmark = True
+        if self.device.type == "cuda":
+            enable_gemm_tuning()
         # the rotation-cycle branch runs on a side stream (model.py); its parameters' AccumulateGrad nodes
         # then see gradients from two streams, which autograd synchronises correctly but warns about
         if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):

@@ -17,7 +17,8 @@ torch.backends.cudnn.benchmark = "bench" in variant
 opts = Options("laptop_wild6d", batch_size=8, repeat=4, train=True)
 torch.manual_seed(0)
 enc = Encoder(opts).cuda().train()
-x = torch.rand(32, 3, 256, 256, device="cuda")
+NB = int(os.environ.get("NB", "32"))
+x = torch.rand(NB, 3, 256, 256, device="cuda")
 if "cl" in variant:
     enc = enc.to(memory_format=torch.channels_last)
     x = x.contiguous(memory_format=torch.channels_last)
@@ -36,7 +37,7 @@ t = time.perf_counter()
 for _ in range(5):
     step()
 torch.cuda.synchronize()
-print("%-16s encoder fwd+bwd B=32: %.2f ms" % (variant, (time.perf_counter() - t) / 5 * 1e3))
+print("%-16s encoder fwd+bwd B=%d: %.2f ms" % (variant, NB, (time.perf_counter() - t) / 5 * 1e3))
 if "prof" in variant:
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
