@@ -152,6 +152,28 @@ int scp_color_jitter_normalize(const float* img, int N, int H, int W, const int*
                                const float* one_minus, float hue_shift, const float* mean, const float* stdv,
                                int out_nhwc, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- BatchNorm2d (+ residual add) (+ ReLU), NHWC fp32, forward / backward ----------------------------
+ * Replaces `relu(bn(x))`, `bn(x)` and `relu(bn(x) + skip)` of torchvision's resnet BasicBlock as run by
+ * model/module/network/image_encoder.py:119-139 (nn.BatchNorm2d semantics: biased batch variance for
+ * normalisation, unbiased for the running estimate, momentum blend, eps inside the sqrt).
+ *   x, skip, y, dy, dx, dskip: [R = N*H*W, C] row-major (channels_last storage), C a power of two in [16,1024]
+ *   training != 0: batch statistics, running_mean/var/batches_tracked updated in place (each may be NULL);
+ *   training == 0: running statistics.  gamma / beta may be NULL (1 / 0).
+ *   save_{mean,invstd,scale,shift} [C]: written by forward, consumed by backward.
+ *   backward: relu/has_skip as in forward; y (the forward output) and dskip are required when both are set
+ *   (dskip receives the ReLU-masked gradient; otherwise the skip gradient is dy itself and dskip is unused);
+ *   dgamma / dbeta may be NULL.  workspace >= scp_batchnorm_workspace(R, C) bytes. */
+size_t scp_batchnorm_workspace(long R, int C);
+int scp_batchnorm_act_forward(const float* x, const float* skip, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, long long* batches_tracked, float momentum,
+                              float eps, long R, int C, int relu, int training, float* y, float* save_mean,
+                              float* save_invstd, float* save_scale, float* save_shift, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int scp_batchnorm_act_backward(const float* dy, const float* x, const float* y, const float* save_mean,
+                               const float* save_invstd, const float* save_scale, const float* save_shift, long R,
+                               int C, int relu, int has_skip, int training, float* dx, float* dskip, float* dgamma,
+                               float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

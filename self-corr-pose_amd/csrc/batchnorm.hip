@@ -1,0 +1,338 @@
+// self-corr-pose_amd/csrc/batchnorm.hip -- BatchNorm2d (+ residual add) (+ ReLU) for the ResNet18 trunk of the
+// image encoder, NHWC fp32, forward and backward.
+//
+// Replaces the `relu(bn(conv(x)))` / `relu(bn(conv(y)) + skip)` chains of torchvision's BasicBlock as used
+// by model/module/network/image_encoder.py:119-139 (called twice per step: encoder.py:31 and
+// correspondence.py:91).  Through PyTorch these are MIOpen's three-kernel spatial BN + an in-place ReLU
+// + an add in forward and threshold_backward + two BN kernels in backward: 5 (8 with the residual) passes
+// over the activation forward and 8 backward.  All of it is HBM-bound streaming, so the budget here is
+// passes over the activation [R = N*H*W rows, C channels]:
+//     forward : stats (1 read) + apply (1 read [+1 skip], 1 write)                       = 3 (4)
+//     backward: reduce (dy, x [, y] reads [, g write]) + dx (dy|g, x reads, 1 write)     = 5 (7)
+// The ReLU mask is recomputed from x in the plain case (same expression as the forward, bit-identical), so
+// the output never has to be re-read; with a residual the saved output gives the mask and the masked
+// gradient g is written once (it is also the gradient of the skip branch).
+// Statistics: fp32 partial sums per (block, channel) over <= a few hundred rows, folded in fp64.
+#include <hip/hip_runtime.h>
+
+#include "scp_common.h"
+#include "scp_hip.h"
+
+namespace {
+
+constexpr int BN_THREADS = 256;
+constexpr int BN_MAX_BLOCKS = 1024;
+
+struct Geometry {
+    int tc;              // threads across channels = C/4
+    int ri;              // row lanes per block = 256 / tc
+    int rows_per_block;  // multiple of ri
+    int blocks;
+};
+
+Geometry geometry(long R, int C) {
+    Geometry g;
+    g.tc = C / 4;
+    g.ri = BN_THREADS / g.tc;
+    long rows = (long)g.ri * 16;  // >= 16 float4 loads per thread
+    long blocks = (R + rows - 1) / rows;
+    if (blocks > BN_MAX_BLOCKS) {
+        rows = ((R + BN_MAX_BLOCKS - 1) / BN_MAX_BLOCKS + g.ri - 1) / g.ri * g.ri;
+        blocks = (R + rows - 1) / rows;
+    }
+    g.rows_per_block = (int)rows;
+    g.blocks = (int)blocks;
+    return g;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float bn_apply(float x, float scale, float shift) { return fmaf(x, scale, shift); }
+
+// folds the row lanes of a block in a fixed order and stores the block's partial for 4 channels
+__device__ __forceinline__ void fold_rows(float4 a, float4 b, int tc_n, int ri_n, float* pa, float* pb, int C,
+                                          float4* lds) {
+    const int tc = threadIdx.x % tc_n, ri = threadIdx.x / tc_n;
+    lds[threadIdx.x] = a;
+    lds[BN_THREADS + threadIdx.x] = b;
+    __syncthreads();
+    if (ri == 0) {
+        float4 sa = lds[tc], sb = lds[BN_THREADS + tc];
+        for (int k = 1; k < ri_n; k++) {
+            const float4 u = lds[k * tc_n + tc], v = lds[BN_THREADS + k * tc_n + tc];
+            sa.x += u.x; sa.y += u.y; sa.z += u.z; sa.w += u.w;
+            sb.x += v.x; sb.y += v.y; sb.z += v.z; sb.w += v.w;
+        }
+        st4(pa + (size_t)blockIdx.x * C + 4 * tc, sa);
+        st4(pb + (size_t)blockIdx.x * C + 4 * tc, sb);
+    }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const float* __restrict__ x, long R, int C, int tc_n,
+                                                              int rows_per_block, float* __restrict__ psum,
+                                                              float* __restrict__ psq) {
+    __shared__ float4 lds[2 * BN_THREADS];
+    const int ri_n = BN_THREADS / tc_n;
+    const int tc = threadIdx.x % tc_n, ri = threadIdx.x / tc_n;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(r0 + rows_per_block, R);
+    float4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+    for (long r = r0 + ri; r < r1; r += ri_n) {
+        const float4 v = ld4(x + r * C + 4 * tc);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
+    }
+    fold_rows(s, q, tc_n, ri_n, psum, psq, C, lds);
+}
+
+// Folds the per-block partials of two quantities for FIN_CH channels per workgroup: FIN_LANES lanes per
+// channel stride over the blocks in fp64, then lane 0 adds the lanes in a fixed order (deterministic).
+constexpr int FIN_CH = 16, FIN_LANES = 16;
+
+__device__ __forceinline__ bool fold_blocks(const float* __restrict__ pa, const float* __restrict__ pb, int blocks,
+                                            int C, double& sa, double& sb, int& c) {
+    __shared__ double lds[2][FIN_LANES][FIN_CH];
+    const int ch = threadIdx.x % FIN_CH, lane = threadIdx.x / FIN_CH;
+    c = blockIdx.x * FIN_CH + ch;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int k = lane; k < blocks; k += FIN_LANES) {
+            a += (double)pa[(size_t)k * C + c];
+            b += (double)pb[(size_t)k * C + c];
+        }
+    lds[0][lane][ch] = a;
+    lds[1][lane][ch] = b;
+    __syncthreads();
+    if (lane != 0 || c >= C) return false;
+    sa = 0.0; sb = 0.0;
+    for (int k = 0; k < FIN_LANES; k++) { sa += lds[0][k][ch]; sb += lds[1][k][ch]; }
+    return true;
+}
+
+// per channel: batch statistics -> (mean, invstd, scale, shift) and the running-stat update
+__global__ void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int blocks, long R,
+                                   int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   long long* __restrict__ batches_tracked, float momentum, float eps, int training,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && training && batches_tracked) *batches_tracked += 1;
+    int c;
+    double s = 0.0, q = 0.0;
+    if (!fold_blocks(psum, psq, training ? blocks : 0, C, s, q, c)) return;
+    float mean, invstd;
+    if (training) {
+        const double m = s / (double)R;
+        double var = q / (double)R - m * m;
+        if (var < 0.0) var = 0.0;
+        mean = (float)m;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        if (running_var) {
+            const double unbiased = R > 1 ? var * ((double)R / (double)(R - 1)) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    } else {
+        mean = running_mean[c];
+        invstd = 1.f / sqrtf(running_var[c] + eps);
+    }
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float scale = g * invstd;
+    mean_out[c] = mean;
+    invstd_out[c] = invstd;
+    scale_out[c] = scale;
+    shift_out[c] = b - mean * scale;
+}
+
+template <bool SKIP, bool RELU>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ skip, long quads, int tc_n,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              float* __restrict__ y) {
+    const long i = (long)blockIdx.x * BN_THREADS + threadIdx.x;
+    if (i >= quads) return;
+    const int tc = (int)(i % tc_n);
+    const float4 sc = ld4(scale + 4 * tc), sh = ld4(shift + 4 * tc);
+    const float4 v = ld4(x + 4 * i);
+    float4 o = {bn_apply(v.x, sc.x, sh.x), bn_apply(v.y, sc.y, sh.y), bn_apply(v.z, sc.z, sh.z),
+                bn_apply(v.w, sc.w, sh.w)};
+    if (SKIP) {
+        const float4 k = ld4(skip + 4 * i);
+        o.x += k.x; o.y += k.y; o.z += k.z; o.w += k.w;
+    }
+    if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    st4(y + 4 * i, o);
+}
+
+// MODE 0: no activation; 1: ReLU, mask recomputed from x; 2: ReLU, mask from the saved output (residual), g written
+template <int MODE>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y, long R, int C, int tc_n,
+    int rows_per_block, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ g_out,
+    float* __restrict__ pg, float* __restrict__ pgx) {
+    __shared__ float4 lds[2 * BN_THREADS];
+    const int ri_n = BN_THREADS / tc_n;
+    const int tc = threadIdx.x % tc_n, ri = threadIdx.x / tc_n;
+    const float4 mu = ld4(mean + 4 * tc), is = ld4(invstd + 4 * tc);
+    float4 sc = {0, 0, 0, 0}, sh = {0, 0, 0, 0};
+    if (MODE == 1) { sc = ld4(scale + 4 * tc); sh = ld4(shift + 4 * tc); }
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(r0 + rows_per_block, R);
+    float4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+    for (long r = r0 + ri; r < r1; r += ri_n) {
+        const size_t o = r * C + 4 * tc;
+        float4 g = ld4(dy + o);
+        const float4 v = ld4(x + o);
+        if (MODE == 1) {
+            if (!(bn_apply(v.x, sc.x, sh.x) > 0.f)) g.x = 0.f;
+            if (!(bn_apply(v.y, sc.y, sh.y) > 0.f)) g.y = 0.f;
+            if (!(bn_apply(v.z, sc.z, sh.z) > 0.f)) g.z = 0.f;
+            if (!(bn_apply(v.w, sc.w, sh.w) > 0.f)) g.w = 0.f;
+        } else if (MODE == 2) {
+            const float4 out = ld4(y + o);
+            if (!(out.x > 0.f)) g.x = 0.f;
+            if (!(out.y > 0.f)) g.y = 0.f;
+            if (!(out.z > 0.f)) g.z = 0.f;
+            if (!(out.w > 0.f)) g.w = 0.f;
+            st4(g_out + o, g);
+        }
+        s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+        q.x = fmaf(g.x, (v.x - mu.x) * is.x, q.x);
+        q.y = fmaf(g.y, (v.y - mu.y) * is.y, q.y);
+        q.z = fmaf(g.z, (v.z - mu.z) * is.z, q.z);
+        q.w = fmaf(g.w, (v.w - mu.w) * is.w, q.w);
+    }
+    fold_rows(s, q, tc_n, ri_n, pg, pgx, C, lds);
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ pg, const float* __restrict__ pgx, int blocks, long R,
+                                       int C, int training, float* __restrict__ c1, float* __restrict__ c2,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    int c;
+    double s = 0.0, q = 0.0;
+    if (!fold_blocks(pg, pgx, blocks, C, s, q, c)) return;
+    if (dgamma) dgamma[c] = (float)q;
+    if (dbeta) dbeta[c] = (float)s;
+    // eval mode: the statistics are constants, dx = scale * g
+    c1[c] = training ? (float)(s / (double)R) : 0.f;
+    c2[c] = training ? (float)(q / (double)R) : 0.f;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const float* __restrict__ dy,
+                                                               const float* __restrict__ x, long quads, int tc_n,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ c1,
+                                                               const float* __restrict__ c2, float* __restrict__ dx) {
+    const long i = (long)blockIdx.x * BN_THREADS + threadIdx.x;
+    if (i >= quads) return;
+    const int tc = (int)(i % tc_n);
+    const float4 mu = ld4(mean + 4 * tc), is = ld4(invstd + 4 * tc), sc = ld4(scale + 4 * tc);
+    const float4 a = ld4(c1 + 4 * tc), b = ld4(c2 + 4 * tc);
+    float4 g = ld4(dy + 4 * i);
+    const float4 v = ld4(x + 4 * i);
+    if (MODE == 1) {
+        const float4 sh = ld4(shift + 4 * tc);
+        if (!(bn_apply(v.x, sc.x, sh.x) > 0.f)) g.x = 0.f;
+        if (!(bn_apply(v.y, sc.y, sh.y) > 0.f)) g.y = 0.f;
+        if (!(bn_apply(v.z, sc.z, sh.z) > 0.f)) g.z = 0.f;
+        if (!(bn_apply(v.w, sc.w, sh.w) > 0.f)) g.w = 0.f;
+    }
+    float4 o;
+    o.x = sc.x * (g.x - a.x - (v.x - mu.x) * is.x * b.x);
+    o.y = sc.y * (g.y - a.y - (v.y - mu.y) * is.y * b.y);
+    o.z = sc.z * (g.z - a.z - (v.z - mu.z) * is.z * b.z);
+    o.w = sc.w * (g.w - a.w - (v.w - mu.w) * is.w * b.w);
+    st4(dx + 4 * i, o);
+}
+
+bool bad_shape(long R, int C) { return R <= 0 || C < 16 || C > 1024 || (C & (C - 1)) != 0; }
+
+}  // namespace
+
+extern "C" size_t scp_batchnorm_workspace(long R, int C) {
+    if (bad_shape(R, C)) return 0;
+    return ((size_t)2 * geometry(R, C).blocks * C + (size_t)4 * C) * sizeof(float);
+}
+
+extern "C" int scp_batchnorm_act_forward(const float* x, const float* skip, const float* gamma, const float* beta,
+                                         float* running_mean, float* running_var, long long* batches_tracked,
+                                         float momentum, float eps, long R, int C, int relu, int training, float* y,
+                                         float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    if (bad_shape(R, C)) return scp::fail(hipErrorInvalidValue, "batchnorm: C must be a power of two in [16,1024], R > 0");
+    if (!x || !y || !save_mean || !save_invstd || !save_scale || !save_shift)
+        return scp::fail(hipErrorInvalidValue, "batchnorm: null argument");
+    if (!training && (!running_mean || !running_var))
+        return scp::fail(hipErrorInvalidValue, "batchnorm: eval mode needs running statistics");
+    if (workspace_bytes < scp_batchnorm_workspace(R, C)) return scp::fail(hipErrorInvalidValue, "batchnorm: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Geometry g = geometry(R, C);
+    float* psum = static_cast<float*>(workspace);
+    float* psq = psum + (size_t)g.blocks * C;
+    if (training) {
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(g.blocks), dim3(BN_THREADS), 0, st, x, R, C, g.tc, g.rows_per_block,
+                           psum, psq);
+        if (int e = scp::check_launch("batchnorm stats")) return e;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, psum, psq, g.blocks, R, C, gamma, beta,
+                       running_mean, running_var, batches_tracked, momentum, eps, training, save_mean, save_invstd,
+                       save_scale, save_shift);
+    if (int e = scp::check_launch("batchnorm finalize")) return e;
+    const long quads = R * C / 4;
+    const dim3 grid((unsigned)((quads + BN_THREADS - 1) / BN_THREADS));
+#define SCP_BN_APPLY(S, A) \
+    hipLaunchKernelGGL((bn_apply_kernel<S, A>), grid, dim3(BN_THREADS), 0, st, x, skip, quads, g.tc, save_scale, save_shift, y)
+    if (skip && relu) SCP_BN_APPLY(true, true);
+    else if (skip) SCP_BN_APPLY(true, false);
+    else if (relu) SCP_BN_APPLY(false, true);
+    else SCP_BN_APPLY(false, false);
+#undef SCP_BN_APPLY
+    return scp::check_launch("batchnorm apply");
+}
+
+extern "C" int scp_batchnorm_act_backward(const float* dy, const float* x, const float* y, const float* save_mean,
+                                          const float* save_invstd, const float* save_scale, const float* save_shift,
+                                          long R, int C, int relu, int has_skip, int training, float* dx, float* dskip,
+                                          float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+    if (bad_shape(R, C)) return scp::fail(hipErrorInvalidValue, "batchnorm: C must be a power of two in [16,1024], R > 0");
+    if (!dy || !x || !dx || !save_mean || !save_invstd || !save_scale || !save_shift)
+        return scp::fail(hipErrorInvalidValue, "batchnorm backward: null argument");
+    const int mode = !relu ? 0 : (has_skip ? 2 : 1);
+    if (mode == 2 && (!y || !dskip)) return scp::fail(hipErrorInvalidValue, "batchnorm backward: residual form needs y and dskip");
+    if (workspace_bytes < scp_batchnorm_workspace(R, C)) return scp::fail(hipErrorInvalidValue, "batchnorm: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Geometry g = geometry(R, C);
+    float* pg = static_cast<float*>(workspace);
+    float* pgx = pg + (size_t)g.blocks * C;
+    float* c1 = pgx + (size_t)g.blocks * C;
+    float* c2 = c1 + C;
+#define SCP_BN_REDUCE(M) \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<M>), dim3(g.blocks), dim3(BN_THREADS), 0, st, dy, x, y, R, C, g.tc, \
+                       g.rows_per_block, save_mean, save_invstd, save_scale, save_shift, dskip, pg, pgx)
+    if (mode == 0) SCP_BN_REDUCE(0);
+    else if (mode == 1) SCP_BN_REDUCE(1);
+    else SCP_BN_REDUCE(2);
+#undef SCP_BN_REDUCE
+    if (int e = scp::check_launch("batchnorm backward reduce")) return e;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, pg, pgx, g.blocks, R, C, training,
+                       c1, c2, dgamma, dbeta);
+    if (int e = scp::check_launch("batchnorm backward finalize")) return e;
+    const long quads = R * C / 4;
+    const dim3 grid((unsigned)((quads + BN_THREADS - 1) / BN_THREADS));
+    // with a residual the masked gradient was written to dskip by the reduce pass: read that, no mask work
+    const float* gsrc = mode == 2 ? dskip : dy;
+    if (mode == 1)
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<1>), grid, dim3(BN_THREADS), 0, st, gsrc, x, quads, g.tc, save_mean,
+                           save_invstd, save_scale, save_shift, c1, c2, dx);
+    else
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<0>), grid, dim3(BN_THREADS), 0, st, gsrc, x, quads, g.tc, save_mean,
+                           save_invstd, save_scale, save_shift, c1, c2, dx);
+    return scp::check_launch("batchnorm backward dx");
+}

@@ -45,6 +45,11 @@ SYMBOLS = {
     "scp_nearest_point": (ctypes.c_int, [_P, _P, _I, _I, _I, _P, _P, ctypes.c_size_t, _P]),
     "scp_color_jitter_workspace": (ctypes.c_size_t, [_I]),
     "scp_color_jitter_normalize": (ctypes.c_int, [_P, _I, _I, _I, _P, _P, _P, _F, _P, _P, _I, _P, _P, ctypes.c_size_t, _P]),
+    "scp_batchnorm_workspace": (ctypes.c_size_t, [ctypes.c_long, _I]),
+    "scp_batchnorm_act_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _F, ctypes.c_long, _I, _I, _I, _P, _P, _P,
+                                                _P, _P, _P, ctypes.c_size_t, _P]),
+    "scp_batchnorm_act_backward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _I, _P, _P, _P, _P,
+                                                 _P, ctypes.c_size_t, _P]),
     "scp_add_layernorm_forward": (ctypes.c_int, [_P, _P, _P, _P, _F, ctypes.c_long, _I, _P, _P, _P]),
     "scp_vit_attention_forward": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "scp_dual_softmax_backward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _F,

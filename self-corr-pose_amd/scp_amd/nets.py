@@ -16,6 +16,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .fused_bn import bn_act
+
 
 # ------------------------------------------------------------------------------------------------
 # ResNet18 trunk (torchvision key names: conv1, bn1, layer{1..4}.{0,1}.{conv1,bn1,conv2,bn2,downsample})
@@ -33,9 +35,9 @@ class _BasicBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
     def forward(self, x):
-        skip = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        return self.relu(self.bn2(self.conv2(y)) + skip)
+        skip = x if self.downsample is None else bn_act(self.downsample[0](x), self.downsample[1])
+        y = bn_act(self.conv1(x), self.bn1, relu=True)
+        return bn_act(self.conv2(y), self.bn2, skip=skip, relu=True)
 
 
 class ResNet18Trunk(nn.Module):
@@ -66,7 +68,7 @@ class ResNet_Encoder(nn.Module):
 
     def forward(self, x):
         r = self.resnet
-        x = r.maxpool(r.relu(r.bn1(r.conv1(x))))
+        x = r.maxpool(bn_act(r.conv1(x), r.bn1, relu=True))
         c2 = r.layer1(x)
         c3 = r.layer2(c2)
         c4 = r.layer3(c3)

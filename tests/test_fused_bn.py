@@ -1,0 +1,99 @@
+"""BatchNorm(+skip)(+ReLU) HIP op vs the stock torch composition evaluated in float64 on the CPU (the plain
+PyTorch reference for this floating-point kernel), forward, running statistics and every gradient."""
+import copy
+
+import pytest
+import torch
+import torch.nn as nn
+
+from scp_amd import fused_bn
+
+
+def _case(n, c, h, w, skip, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, c, h, w, generator=g) * 1.7 + 0.4
+    x = x + torch.linspace(-1, 1, c).view(1, c, 1, 1)            # channel-dependent mean
+    s = torch.randn(n, c, h, w, generator=g) if skip else None
+    bn = nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * torch.randn(c, generator=g))
+        bn.bias.copy_(0.2 * torch.randn(c, generator=g))
+        bn.running_mean.copy_(0.1 * torch.randn(c, generator=g))
+        bn.running_var.copy_(1 + 0.2 * torch.rand(c, generator=g))
+    dy = torch.randn(n, c, h, w, generator=g)
+    return x, s, bn, dy
+
+
+def _reference(x, s, bn, dy, relu, training):
+    bn = copy.deepcopy(bn).double().train(training)
+    x = x.double().requires_grad_(True)
+    s = None if s is None else s.double().requires_grad_(True)
+    y = fused_bn._composition(x, bn, s, relu)
+    y.backward(dy.double())
+    return y, x.grad, None if s is None else s.grad, bn.weight.grad, bn.bias.grad, bn
+
+
+def test_cpu_path_is_the_composition():
+    x, s, bn, _ = _case(2, 16, 4, 4, True, 0)
+    ref = fused_bn._composition(x, copy.deepcopy(bn), s, True)
+    assert torch.equal(fused_bn.bn_act(x, bn, s, relu=True), ref)
+
+
+SHAPES = [(4, 64, 16, 16), (2, 128, 9, 7), (3, 512, 2, 2), (8, 16, 5, 5), (1, 256, 1, 1), (5, 64, 33, 31)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("skip,relu", [(False, False), (False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_act_matches_float64_composition(shape, skip, relu, training):
+    if shape == (1, 256, 1, 1) and training:
+        pytest.skip("one value per channel: torch refuses to train BatchNorm on it")
+    x, s, bn, dy = _case(*shape, skip, seed=sum(shape))
+    y_ref, dx_ref, ds_ref, dw_ref, db_ref, bn_ref = _reference(x, s, bn, dy, relu, training)
+    dev = torch.device("cuda")
+    bn_g = copy.deepcopy(bn).to(dev).train(training)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    sg = None if s is None else s.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert fused_bn._fused_ok(xg, bn_g, sg)
+    y = fused_bn.bn_act(xg, bn_g, sg, relu=relu)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(dy.to(dev))
+
+    def close(a, b, what, tol=2e-5):
+        a, b = a.detach().double().cpu(), b.detach().double()
+        err = (a - b).abs().max().item()
+        assert err <= tol * (1 + b.abs().max().item()), "%s: %.3g" % (what, err)
+
+    close(y, y_ref, "y")
+    close(xg.grad, dx_ref, "dx")
+    if skip:
+        close(sg.grad, ds_ref, "dskip")
+    close(bn_g.weight.grad, dw_ref, "dgamma", 5e-5)
+    close(bn_g.bias.grad, db_ref, "dbeta", 5e-5)
+    close(bn_g.running_mean, bn_ref.running_mean, "running_mean")
+    close(bn_g.running_var, bn_ref.running_var, "running_var")
+    assert int(bn_g.num_batches_tracked) == int(bn_ref.num_batches_tracked)
+
+
+@pytest.mark.gpu
+def test_bn_act_full_size_vs_miopen():
+    """bench-size stem activation [32,64,128,128]: HIP op vs the MIOpen/ATen composition on the same device"""
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(32, 64, 128, 128, generator=g) * 2 + 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(32, 64, 128, 128, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    bn_a, bn_b = nn.BatchNorm2d(64).to(dev), nn.BatchNorm2d(64).to(dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = fused_bn.bn_act(xa, bn_a, relu=True)
+    yb = fused_bn._composition(xb, bn_b, None, True)
+    ya.backward(dy)
+    yb.backward(dy)
+    assert (ya - yb).abs().max().item() < 1e-5
+    assert (xa.grad - xb.grad).abs().max().item() < 1e-5
+    assert (bn_a.running_var - bn_b.running_var).abs().max().item() < 1e-6
+    # frozen affine parameters (trainer.py:54-58) get no gradient buffers
+    bn_a.weight.requires_grad_(False); bn_a.bias.requires_grad_(False)
+    xa.grad = None
+    fused_bn.bn_act(xa, bn_a, relu=True).backward(dy)
+    assert bn_a.weight.grad is not None and xa.grad is not None   # old .grad kept, new dx produced
