@@ -174,6 +174,29 @@ int scp_batchnorm_act_backward(const float* dy, const float* x, const float* y, 
                                int C, int relu, int has_skip, int training, float* dx, float* dskip, float* dgamma,
                                float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- test-time pose fitting: batched RANSAC + Umeyama similarity fit -----------------------------------
+ * Replaces model/util/umeyama.py (estimateSimilarityTransform :9-38, getRANSACInliers :97-121,
+ * evaluateModel :123-131, estimateSimilarityUmeyama :161-201) as called per image by Tester.pose_fitting
+ * (model/tester.py:346-384).  B problems side by side; problem b has counts[b] <= Nmax correspondences:
+ *   source, target [B,Nmax,3] fp32 (rows >= counts[b] ignored)
+ *   rand_idx [B,K,5] int32: the RandIdx of each RANSAC round (host RNG, umeyama.py:105)
+ *   transforms [B,K,12]: rows 0..2 of each round's OutTransform (row-major 3x4)
+ *   residual_sq [B,K] fp64: sum over all correspondences of |target - T source|^2 (Residual^2, :126);
+ *   inliers [B,K]: #(|target - T source| < pass_threshold[b])
+ *   fit: Umeyama over the inliers of `chosen` [B,12] -> scale [B] (ScaleFact), rotation [B,9] (the reference's
+ *   `Rotation`, row-major), translation [B,3], transform [B,16] (OutTransform), n_inliers [B]; fewer than two
+ *   inliers yields NaNs.  workspace >= scp_posefit_workspace(B, Nmax, K) bytes (K = 1 for the fit). */
+size_t scp_posefit_workspace(int B, int Nmax, int K);
+int scp_ransac_hypotheses(const float* source, const float* target, int B, int Nmax, const int* rand_idx, int K,
+                          float* transforms, void* stream);
+int scp_ransac_score(const float* source, const float* target, const int* counts, int B, int Nmax,
+                     const float* transforms, int K, const float* pass_threshold, double* residual_sq, int* inliers,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int scp_umeyama_fit_inliers(const float* source, const float* target, const int* counts, int B, int Nmax,
+                            const float* chosen, const float* pass_threshold, float* scale, float* rotation,
+                            float* translation, float* transform, int* n_inliers, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,197 @@
+"""scp_amd/pose_fit.py -- test-time pose fitting.
+
+Mirrors the reference's names:
+  estimateSimilarityTransform(source, target)   model/util/umeyama.py:9-38
+  PoseFitter.pose_fitting(...)                  Tester.pose_fitting, model/tester.py:324-427
+The reference fits image after image, each with up to 100 sequential RANSAC rounds of tiny launches and
+two host syncs per round.  Here every image of the batch and every round is evaluated at once by three HIP
+launches (csrc/posefit.hip); the host only (1) reads the per-image correspondence counts (the RNG needs them:
+`torch.randint(0, n, (5,))` on the global CPU generator, umeyama.py:105), (2) reads the [B,K] residual table and
+replays the reference's sequential selection (first strictly-better round wins; stop when the best residual
+drops under StopThreshold).  Random numbers are drawn in (K,5) blocks, which consume the generator exactly
+like K successive (5,) draws; if a problem stops early the generator is rewound and advanced by the rounds the
+reference would have run, and the problems after it are re-drawn -- so the RNG stream, the chosen rounds and
+the generator's final state equal the reference's.  GPU only: there is no CPU fallback."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import capi
+from .losses import pinhole_cam  # noqa: F401  (re-exported for callers that project the fitted vertices)
+
+MAX_ITERATIONS = 100          # nIter, umeyama.py:22
+last_report = {}              # rounds run / inliers / points per problem of the latest call (tests, logging)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _require_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError("scp_amd.pose_fit: %s must be a CUDA tensor (the RANSAC/Umeyama kernels are HIP-only)" % name)
+
+
+def _thresholds(source, target, counts_dev):
+    """PassT / StopT heuristics of umeyama.py:15-21 for padded [B,Nmax,3] problems"""
+    nmax = source.shape[1]
+    live = (torch.arange(nmax, device=source.device)[None] < counts_dev[:, None]).float()
+    cnt = counts_dev.float().clamp(min=1)
+    tn = (torch.linalg.norm(target, dim=2) * live).sum(1) / cnt
+    sn = (torch.linalg.norm(source, dim=2) * live).sum(1) / cnt
+    ts, st = tn / sn, sn / tn
+    pass_t = torch.where(st > ts, st, ts)
+    return pass_t.contiguous(), pass_t / 100
+
+
+def _select(res, stop_t):
+    """getRANSACInliers' sequential bookkeeping (umeyama.py:100-114) over a precomputed residual row:
+    returns (best round, rounds run)"""
+    best, best_res = -1, np.float32(1e10)
+    for k in range(res.shape[0]):
+        if res[k] < best_res:
+            best, best_res = k, res[k]
+        if best_res < stop_t:
+            return best, k + 1
+    return best, res.shape[0]
+
+
+def fit_padded(source, target, counts, max_iterations=MAX_ITERATIONS):
+    """B problems: source/target [B,Nmax,3] fp32 CUDA (rows >= counts[b] ignored), counts = python ints.
+    Returns scale [B], rotation [B,3,3], translation [B,3], transform [B,4,4], inlier ratio (list)."""
+    _require_cuda(source, "source")
+    L = capi.lib()
+    B, nmax, _ = source.shape
+    K = max_iterations
+    dev = source.device
+    source, target = source.contiguous().float(), target.contiguous().float()
+    counts = [int(c) for c in counts]
+    if min(counts) < 5:
+        # torch.randint would still draw, the 5-point covariance is then rank deficient: the reference produces
+        # NaN/garbage here; refuse loudly instead
+        raise RuntimeError("scp_amd.pose_fit: a problem has fewer than 5 correspondences (%s)" % counts)
+    counts_dev = torch.tensor(counts, dtype=torch.int32, device=dev)
+    pass_t, stop_t = _thresholds(source, target, counts_dev)
+    stop_host = None
+    ws_bytes = L.scp_posefit_workspace(B, nmax, K)
+    ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.float64, device=dev)
+    transforms = torch.empty(B, K, 12, dtype=torch.float32, device=dev)
+    res_sq = torch.empty(B, K, dtype=torch.float64, device=dev)
+    inl = torch.empty(B, K, dtype=torch.int32, device=dev)
+    chosen_round, rounds_run = [0] * B, [K] * B
+    chosen = torch.empty(B, 12, dtype=torch.float32, device=dev)
+    start = 0
+    while start < B:
+        states, blocks = [], []
+        for b in range(start, B):
+            states.append(torch.get_rng_state())
+            blocks.append(torch.randint(0, counts[b], (K, 5)))
+        idx = torch.zeros(B, K, 5, dtype=torch.int32)
+        idx[start:] = torch.stack(blocks).to(torch.int32)
+        idx = idx.pin_memory().to(dev, non_blocking=True)
+        stream = capi.current_stream()
+        capi.check(L.scp_ransac_hypotheses(_ptr(source), _ptr(target), B, nmax, _ptr(idx), K, _ptr(transforms), stream),
+                   "ransac_hypotheses")
+        capi.check(L.scp_ransac_score(_ptr(source), _ptr(target), _ptr(counts_dev), B, nmax, _ptr(transforms), K, _ptr(pass_t),
+                                      _ptr(res_sq), _ptr(inl), _ptr(ws), ws_bytes, stream), "ransac_score")
+        res = torch.sqrt(res_sq).float().cpu().numpy()           # Residual = norm(ResidualVec), fp32 (one sync)
+        if stop_host is None:
+            stop_host = stop_t.cpu().numpy()
+        redo = B
+        for b in range(start, B):
+            chosen_round[b], rounds_run[b] = _select(res[b], stop_host[b])
+            if rounds_run[b] < K:
+                # the reference consumed only rounds_run[b] draws for this problem: rewind and advance by exactly that
+                torch.set_rng_state(states[b - start])
+                torch.randint(0, counts[b], (rounds_run[b], 5))
+                redo = b + 1
+                break
+        # problems start..redo-1 are settled by THIS pass (a later pass recomputes `transforms` with new draws)
+        done = torch.arange(start, redo, device=dev)
+        chosen[start:redo] = transforms[done, torch.tensor(chosen_round[start:redo], device=dev)]
+        start = redo
+    scale = torch.empty(B, dtype=torch.float32, device=dev)
+    rotation = torch.empty(B, 3, 3, dtype=torch.float32, device=dev)
+    translation = torch.empty(B, 3, dtype=torch.float32, device=dev)
+    transform = torch.empty(B, 4, 4, dtype=torch.float32, device=dev)
+    n_in = torch.empty(B, dtype=torch.int32, device=dev)
+    capi.check(L.scp_umeyama_fit_inliers(_ptr(source), _ptr(target), _ptr(counts_dev), B, nmax, _ptr(chosen), _ptr(pass_t),
+                                         _ptr(scale), _ptr(rotation), _ptr(translation), _ptr(transform), _ptr(n_in), _ptr(ws),
+                                         ws_bytes, capi.current_stream()), "umeyama_fit_inliers")
+    n_in_host = n_in.cpu().tolist()
+    ratios = [n / c for n, c in zip(n_in_host, counts)]
+    last_report.update(rounds=rounds_run, n_inliers=n_in_host, n_points=counts, chosen=chosen_round)
+    return scale, rotation, translation, transform, ratios
+
+
+def estimateSimilarityTransform(source, target, verbose=False):
+    """source, target [n,3] -> (Scales [3], Rotation [3,3], Translation [3], OutTransform [4,4]); (None,)*4 when the
+    best round keeps fewer than 10 % inliers (umeyama.py:28-30)"""
+    scale, rotation, translation, transform, ratios = fit_padded(source[None], target[None], [source.shape[0]])
+    if ratios[0] < 0.1:
+        print("[ WARN ] - Something is wrong. Small BestInlierRatio: ", ratios[0])
+        return None, None, None, None
+    if verbose:
+        print("BestInlierRatio:", ratios[0])
+    return scale[0].reshape(-1).repeat(3), rotation[0], translation[0], transform[0]
+
+
+class PoseFitter:
+    """the part of Tester that pose_fitting needs: image size and the `base_rot` flag (tester.py:130-150)"""
+
+    def __init__(self, img_size, base_rot):
+        self.img_size = img_size
+        self.base_rot = base_rot.reshape(1, 3, 3).float()
+
+    def correspondences(self, depth, mask, match, match_conf, foc_crop, pp_crop):
+        """tester.py:326-367 for the whole batch: valid pixels (depth > 0, inside the mask, confident), their canonical
+        coordinate (source) and their back-projected camera point (target), compacted in pixel order into padded
+        [B,Nmax,3] arrays without per-image host round trips"""
+        bsz, h, w = depth.shape
+        dev = depth.device
+        ys, xs = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
+        u = ((xs.reshape(-1).float() + 0.5) / (w / 2) - 1)[None]
+        v = ((ys.reshape(-1).float() + 0.5) / (w / 2) - 1)[None]           # tester.py:135 divides both axes by w/2
+        valid = ((depth > 0)[:, None] * mask[:, None] * match_conf).reshape(bsz, -1) > 0
+        # intr_inv of [[fx,0,px],[0,fy,py],[0,0,1]] applied to (u,v,1); then pts = xyz * depth / xyz_z  (:365-367)
+        x = (u - pp_crop[:, 0:1]) / foc_crop[:, 0:1]
+        y = (v - pp_crop[:, 1:2]) / foc_crop[:, 1:2]
+        d = depth.reshape(bsz, -1)
+        target = torch.stack((x * d, y * d, d), -1)
+        source = match.reshape(bsz, 3, -1).permute(0, 2, 1)
+        pos = torch.cumsum(valid, 1) - 1
+        counts = (pos[:, -1] + 1).tolist()                                   # host sync #1: the RNG ranges
+        nmax = max(max(counts), 1)
+        dest = torch.where(valid, pos, torch.full_like(pos, nmax))[..., None].expand(-1, -1, 3)
+        src_c = torch.zeros(bsz, nmax + 1, 3, device=dev).scatter_(1, dest, source)[:, :nmax]
+        tgt_c = torch.zeros(bsz, nmax + 1, 3, device=dev).scatter_(1, dest, target)[:, :nmax]
+        return src_c.contiguous(), tgt_c.contiguous(), counts
+
+    def pose_fitting(self, depth, mask, match, match_conf, foc_crop, pp_crop, pred_v):
+        """-> bbox [B,9,3], verts [B,V,3], rotation [B,3,3], translation [B,1,3]   (tester.py:386-427)"""
+        for t, name in ((depth, "depth"), (match, "match"), (pred_v, "pred_v")):
+            _require_cuda(t, name)
+        bsz = depth.shape[0]
+        source, target, counts = self.correspondences(depth.float(), mask.float(), match.float(), match_conf.float(),
+                                                      foc_crop.float(), pp_crop.float())
+        scale, rotation, translation, _, ratios = fit_padded(source, target, counts)
+        bad = [i for i, r in enumerate(ratios) if r < 0.1]
+        if bad:
+            # the reference returns None here and then fails on `scale.reshape` (tester.py:383); same outcome, said plainly
+            raise RuntimeError("pose_fitting: best RANSAC round kept < 10%% inliers for images %s" % bad)
+        translation = (translation * 0.001).reshape(-1, 1, 3)
+        scale_fit = (scale[:, None].repeat(1, 3) * 0.001).reshape(-1, 1, 3)
+        base_rot = self.base_rot.to(pred_v.device).repeat(bsz, 1, 1)
+        pred_v = pred_v.bmm(base_rot.permute(0, 2, 1))
+        rotation = base_rot.bmm(rotation)
+        lo, hi = pred_v.min(1).values, pred_v.max(1).values
+        corners = [(lo + hi) / 2]
+        for sx in (lo, hi):
+            for sy in (lo, hi):
+                for sz in (lo, hi):
+                    corners.append(torch.stack((sx[:, 0], sy[:, 1], sz[:, 2]), -1))
+        bbox = torch.stack(corners, -2)
+        bbox = (bbox * scale_fit).bmm(rotation) + translation
+        verts = (pred_v * scale_fit).bmm(rotation) + translation
+        return bbox, verts, rotation, translation

@@ -1,0 +1,88 @@
+"""scp_amd/tester.py -- the test-time step: eval-mode forward, batched pose fitting, pose error.
+
+Mirrors model/tester.py: `define_model` (:76-94), `batch_reshape` (:96-123, same NDC conversion as the trainer),
+the loop body of `test` (:178-183: `pred = model(data)`, `pred_fit = pose_fitting(data, pred)`), `pose_fitting`
+(:324-427, scp_amd.pose_fit) and the degree / centimetre part of `eval_nocs` (:295-321 with
+model/util/eval_utils.py:182-199 get_best_deg_cm).  The 3-D box IoU of eval_nocs goes through the vendored
+objectron package (third-party/objectron, CPU numpy polytope clipping) and the visualisation through cv2 /
+matplotlib: evaluation-harness code outside the GPU path, not rebuilt here."""
+import numpy as np
+import torch
+
+from . import pose_fit
+from .model import MeshNet
+from .trainer import Trainer, enable_gemm_tuning, freeze_batchnorm_affine
+
+
+def get_base_rot(opts, device=None):
+    """model/util/base_rot.py:10-18"""
+    br = [float(x) for x in opts.base_rot]
+    return torch.tensor(br, dtype=torch.float32, device=device).reshape(1, 3, 3)
+
+
+def get_best_deg_cm(symmetry_idx, box_vertices, box_rotation, rot_gt, trans_gt, scale_gt):
+    """eval_utils.py:182-199.  box_vertices [9,3] (centre first, then the 8 corners in objectron order), box_rotation
+    [3,3] the fitted rotation; returns (angle error in degrees, translation error in cm)"""
+    trans_error = 100 * np.linalg.norm(box_vertices[0] - trans_gt)
+    if symmetry_idx == 0:
+        # objectron Box.from_transformation: unit-box corners scaled, rotated, translated; vertices[3]-vertices[1]
+        # is the box's y edge
+        y_gt = rot_gt @ (np.array([0.0, 1.0, 0.0]) * scale_gt)
+        y_pred = box_vertices[3] - box_vertices[1]
+        angle = np.arccos(y_pred.dot(y_gt) / (np.linalg.norm(y_pred) * np.linalg.norm(y_gt)))
+    else:
+        r = box_rotation @ rot_gt.transpose()
+        angle = np.arccos((np.trace(r) - 1) / 2)
+    return angle * 180 / np.pi, trans_error
+
+
+class Tester:
+    deg_cm_thresh = [[5, 2], [5, 5], [10, 2], [10, 5]]                       # tester.py:154
+
+    def __init__(self, opts, prior=None, device=None):
+        self.opts = opts
+        self.device = torch.device(device if device is not None else "cuda")
+        self.prior = prior
+        self.deg_cm_result = []
+
+    def define_model(self):
+        torch.backends.cudnn.benchmark = True
+        if self.device.type == "cuda":
+            enable_gemm_tuning()
+        self.model = MeshNet(self.opts, self.prior)
+        if self.opts.model_path:
+            self.model.load_network(self.opts.model_path)
+        freeze_batchnorm_affine(self.model)                                   # set_bn_eval, tester.py:67-73
+        self.model = self.model.to(self.device)
+        if self.device.type == "cuda":
+            self.model.encoder.backbone.to(memory_format=torch.channels_last)
+            self.model.encoder.featnet.to(memory_format=torch.channels_last)
+        self.model.eval()
+        self.fitter = pose_fit.PoseFitter(self.opts.img_size, get_base_rot(self.opts, self.device))
+        return self.model
+
+    batch_reshape = Trainer.batch_reshape
+
+    @torch.no_grad()
+    def predict(self, data):
+        """one test batch: (pred, pred_fit) as in tester.py:180-183"""
+        img, mask, depth, occ, center, length, foc, foc_crop, pp, pp_crop, indices, gt = data
+        pred = self.model(data)
+        pred_v, faces, tex, imatch, match, match_conf = pred[:6]
+        pred_fit = self.fitter.pose_fitting(depth, mask, match, match_conf, foc_crop, pp_crop, pred_v)
+        return pred, pred_fit
+
+    def eval_deg_cm(self, pred_fit, gt):
+        """tester.py:295-321 without the IoU rows: appends one [5deg2cm, 5deg5cm, 10deg2cm, 10deg5cm] hit list per image"""
+        bbox, verts, rotation, translation = pred_fit
+        rot_gt, trans_gt, scale_gt = (np.asarray(g.cpu() if torch.is_tensor(g) else g, np.float64) for g in gt)
+        bbox, rotation = bbox.cpu().numpy().astype(np.float64), rotation.cpu().numpy().astype(np.float64)
+        out = []
+        for i in range(bbox.shape[0]):
+            # objectron's Box(vertices).rotation is recovered from the vertices; for a box built as (corners * s) R + t in
+            # row-vector form that is R^T in its column-vector convention
+            ang, cm = get_best_deg_cm(self.opts.symmetry_idx, bbox[i], rotation[i].T, rot_gt[i], trans_gt[i], scale_gt[i])
+            hits = [bool(ang < d and cm < c) for d, c in self.deg_cm_thresh]
+            self.deg_cm_result.append(hits)
+            out.append((ang, cm))
+        return out

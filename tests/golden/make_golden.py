@@ -20,6 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import ref_harness  # noqa: E402
 import scenes  # noqa: E402
+from posefit_inputs import posefit_inputs, umeyama_case  # noqa: E402
 
 # the four SoftRenderer configurations of model/module/renderer.py:13-26
 RENDER_PASSES = {
@@ -399,8 +400,92 @@ def gen_step_single():
     gen_step("step_laptopflags_bottle_b1x1", "bottle", 1, 1)
 
 
+def gen_posefit():
+    """Tester.pose_fitting (model/tester.py:324-427) = per image RANSAC (100 x 5-point Umeyama,
+    model/util/umeyama.py:9-201) on (canonical coordinate, back-projected depth point) pairs, then the box.
+    Runs the reference method itself on seeded inputs; records the RandIdx stream it consumed."""
+    ref_harness.install()
+    import types
+    import model.tester as ref_tester
+    import model.util.umeyama as um
+
+    data, _ = posefit_inputs()
+    bsz, size = data["depth"].shape[0], data["depth"].shape[-1]
+    h = w = size
+    meshgrid = torch.Tensor(np.array(np.meshgrid(range(w), range(h)))).reshape(2, -1) + 0.5     # tester.py:134-137
+    meshgrid = (meshgrid / (w / 2) - 1).reshape(-1)
+    base_rot = torch.tensor([[0., 0., 1.], [0., 1., 0.], [-1., 0., 0.]])[None]                  # a non-trivial base_rot flag
+    fake = types.SimpleNamespace(opts=types.SimpleNamespace(img_size=size), meshgrid=meshgrid, base_rot=base_rot)
+    z = torch.zeros(bsz)
+    batch = (torch.zeros(bsz, 3, size, size), data["mask"], data["depth"], z, z, z, z, data["foc_crop"], z, data["pp_crop"], z)
+    pred = (data["pred_v"], None, None, None, data["match"], data["match_conf"])
+
+    drawn = []
+    real_randint = torch.randint
+
+    def spy_randint(*a, **k):
+        r = real_randint(*a, **k)
+        drawn.append(r.clone())
+        return r
+
+    um.torch.randint = spy_randint
+    fits = []
+    real_est = um.estimateSimilarityTransform
+
+    def spy_est(source, target, verbose=False):
+        out = real_est(source, target, verbose)
+        fits.append([o.clone() for o in out[:3]] + [torch.tensor(source.shape[0])])
+        return out
+
+    ref_tester.estimateSimilarityTransform = spy_est
+    torch.manual_seed(1234)
+    try:
+        bbox, verts, rotation, translation = ref_tester.Tester.pose_fitting(fake, batch, pred)
+    finally:
+        um.torch.randint = real_randint
+        ref_tester.estimateSimilarityTransform = real_est
+    per = len(drawn) // bsz
+    assert per * bsz == len(drawn)
+    save("posefit_b3_64",
+         **{k: v.numpy() for k, v in data.items()}, base_rot=base_rot.numpy(), seed=np.int64(1234),
+         rand_idx=torch.stack(drawn).reshape(bsz, per, 5).numpy(),
+         fit_scale=torch.stack([f[0].reshape(-1) for f in fits]).numpy(), fit_rotation=torch.stack([f[1] for f in fits]).numpy(),
+         fit_translation=torch.stack([f[2].reshape(-1) for f in fits]).numpy(), n_points=torch.stack([f[3] for f in fits]).numpy(),
+         bbox=bbox.numpy(), verts=verts.numpy(), rotation=rotation.numpy(), translation=translation.numpy())
+    print("  RANSAC iterations per image:", per, " points per image:", [int(f[3]) for f in fits])
+
+    # direct estimateSimilarityTransform cases at comparable source/target scale, where the pass threshold
+    # actually separates inliers from gross outliers (in pose_fitting's mm-vs-unit setting it never does)
+    arrays = {}
+    for ci, (n, out_frac, mirror) in enumerate([(500, 0.25, False), (300, 0.4, False), (64, 0.0, False), (400, 0.2, True)]):
+        src, tgt = umeyama_case(n, out_frac, mirror, seed=100 + ci)
+        drawn.clear()
+        inl = []
+        real_ransac = um.getRANSACInliers
+
+        def spy_ransac(*a, **k):
+            out = real_ransac(*a, **k)
+            inl.append((out[0].shape[1], out[2]))
+            return out
+
+        um.getRANSACInliers = spy_ransac
+        um.torch.randint = spy_randint
+        torch.manual_seed(77 + ci)
+        try:
+            sc, rot, tr, outt = um.estimateSimilarityTransform(src, tgt)
+        finally:
+            um.torch.randint = real_randint
+            um.getRANSACInliers = real_ransac
+        arrays.update({"c%d_source" % ci: src.numpy(), "c%d_target" % ci: tgt.numpy(), "c%d_seed" % ci: np.int64(77 + ci),
+                       "c%d_rand_idx" % ci: torch.stack(drawn).numpy(), "c%d_scale" % ci: sc.numpy(), "c%d_rotation" % ci: rot.numpy(),
+                       "c%d_translation" % ci: tr.reshape(-1).numpy(), "c%d_transform" % ci: outt.numpy(),
+                       "c%d_n_inliers" % ci: np.int64(inl[0][0])})
+        print("  case %d: n=%d inliers=%d iterations=%d scale=%.4f" % (ci, n, inl[0][0], len(drawn), float(sc[0])))
+    save("umeyama_cases", n_cases=np.int64(4), **arrays)
+
+
 GENERATORS = {"softras": gen_softras, "step": gen_step, "corr": gen_corr, "losses": gen_losses,
-              "step_laptop": gen_step_laptop, "step_single": gen_step_single}
+              "step_laptop": gen_step_laptop, "step_single": gen_step_single, "posefit": gen_posefit}
 
 
 if __name__ == "__main__":
