@@ -197,6 +197,22 @@ int scp_umeyama_fit_inliers(const float* source, const float* target, const int*
                             float* translation, float* transform, int* n_inliers, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* ---- training input transform: batched crop + resize ---------------------------------------------------
+ * Replaces `ToTensor(img)/255` + `resized_crop(..., BILINEAR)` for the image and `resized_crop(..., NEAREST)` for
+ * mask and depth in Wild6DDataset.__getitem__ (data/dataset_wild6d.py:160-171; torchvision tensor backend = zero
+ * padded crop + F.interpolate).  The host cuts the in-frame part of each crop box into `staging`:
+ *   img  uint8  [in_h,in_w,3] RGB at img_off;  mask uint8 [in_h,in_w] at mask_off (non-zero = object);
+ *   depth uint16 [in_h,in_w] at depth_off (2-byte aligned);  offsets in bytes.
+ *   The box itself is virt_h x virt_w with the stored part at (pad_top, pad_left); the rest reads as zero.
+ * Outputs (device): img_out [B,3,S,S] in [0,1], mask_out [B,1,S,S] in {0,1}, depth_out [B,1,S,S] raw depth units;
+ * mask_out / depth_out may be NULL.  `descs` is a device array of B descriptors. */
+typedef struct scp_crop_desc {
+    unsigned long long img_off, mask_off, depth_off;
+    int in_h, in_w, pad_top, pad_left, virt_h, virt_w;
+} scp_crop_desc;
+int scp_crop_resize_batch(const void* staging, const scp_crop_desc* descs, int B, int out_size, float* img_out,
+                          float* mask_out, float* depth_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

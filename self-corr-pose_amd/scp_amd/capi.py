@@ -26,6 +26,13 @@ class RasterParams(ctypes.Structure):
     ]
 
 
+class CropDesc(ctypes.Structure):
+    """struct scp_crop_desc"""
+    _fields_ = [("img_off", ctypes.c_ulonglong), ("mask_off", ctypes.c_ulonglong), ("depth_off", ctypes.c_ulonglong),
+                ("in_h", ctypes.c_int), ("in_w", ctypes.c_int), ("pad_top", ctypes.c_int), ("pad_left", ctypes.c_int),
+                ("virt_h", ctypes.c_int), ("virt_w", ctypes.c_int)]
+
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
@@ -54,6 +61,7 @@ SYMBOLS = {
     "scp_ransac_hypotheses": (ctypes.c_int, [_P, _P, _I, _I, _P, _I, _P, _P]),
     "scp_ransac_score": (ctypes.c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "scp_umeyama_fit_inliers": (ctypes.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "scp_crop_resize_batch": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _P, _P]),
     "scp_add_layernorm_forward": (ctypes.c_int, [_P, _P, _P, _P, _F, ctypes.c_long, _I, _P, _P, _P]),
     "scp_vit_attention_forward": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "scp_dual_softmax_backward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _F,

@@ -1,0 +1,2 @@
+"""scp_amd.data -- the training input pipeline: on-disk Wild6D layout -> device batches."""
+from .wild6d import GpuCollator, Wild6DDataset, data_loader  # noqa: F401

@@ -484,8 +484,81 @@ def gen_posefit():
     save("umeyama_cases", n_cases=np.int64(4), **arrays)
 
 
+def _install_image_io_stubs():
+    """cv2.imread and the two torchvision calls of data/dataset_wild6d.py, for the fixture run only.  Both packages
+    are un-vendored and absent here, so these follow their published behaviour (cv2: BGR uint8 / grayscale / unchanged;
+    torchvision 0.11 tensor backend: ToTensor = HWC ndarray -> CHW tensor, scaled only for uint8; resized_crop = crop
+    with zero padding outside the frame, then F.interpolate(align_corners=False for bilinear)).  What the fixture
+    pins is the reference's OWN logic around them: sampler, box, crop factors, intrinsics, dtypes."""
+    import sys as _sys
+    from PIL import Image
+    cv2 = _sys.modules["cv2"]
+    cv2.IMREAD_GRAYSCALE = 0
+
+    def imread(path, flag=1):
+        im = Image.open(path)
+        if flag == 0:
+            return np.array(im.convert("L"))
+        if flag == -1:
+            return np.array(im)
+        return np.array(im.convert("RGB"))[:, :, ::-1]
+
+    cv2.imread = imread
+    tvt = _sys.modules["torchvision.transforms"]
+
+    class ToTensor:
+        def __call__(self, pic):
+            t = torch.from_numpy(np.ascontiguousarray(pic.transpose(2, 0, 1)))
+            return t.float().div(255) if t.dtype == torch.uint8 else t
+
+    tvt.ToTensor = ToTensor
+
+    def resized_crop(img, top, left, height, width, size, interpolation="bilinear"):
+        h, w = img.shape[-2:]
+        right, bottom = left + width, top + height
+        if left < 0 or top < 0 or right > w or bottom > h:
+            pad = [max(-left, 0), max(right - w, 0), max(-top, 0), max(bottom - h, 0)]
+            img = torch.nn.functional.pad(img[..., max(top, 0):bottom, max(left, 0):right], pad)
+        else:
+            img = img[..., top:bottom, left:right]
+        kw = dict(align_corners=False) if interpolation == "bilinear" else {}
+        return torch.nn.functional.interpolate(img[None], size=list(size), mode=interpolation, **kw)[0]
+
+    tvt.functional.resized_crop = resized_crop
+
+
+def gen_data():
+    """the training input pipeline, data/dataset_wild6d.py:37-182 (sampler `reset`, `__getitem__`)
+    on the seeded synthetic dataset of tests/wild6d_synth.py."""
+    import tempfile
+    import types
+    import wild6d_synth
+    ref_harness.install()
+    _install_image_io_stubs()
+    import data.dataset_wild6d as ref_ds
+    work = tempfile.mkdtemp(prefix="scp_wild6d_")
+    root = os.path.join(work, "wild6d")
+    train_list = wild6d_synth.write_dataset(root, seed=0)
+    opts = types.SimpleNamespace(train_list=train_list, dataset_path=root, batch_size=2, repeat=3, ngpu=1, total_iters=4,
+                                 img_size=64, no_stretch=False, use_depth=True)
+    np.random.seed(11)
+    ds = ref_ds.Wild6DDataset(opts)
+    out = {"sample_list": np.array(ds.sample_list, dtype=np.int64), "n_items": np.int64(len(ds))}
+    np.random.seed(12)
+    for i in range(len(ds)):
+        e = ds[i]
+        for k, v in e.items():
+            if i >= 10 and k in ("img", "mask", "depth"):       # images for the first 10 items, scalars for all
+                continue
+            v = v.numpy()
+            out["i%02d_%s" % (i, k)] = v.astype(np.float32) if v.dtype == np.float64 else v
+        out["i%02d_img_dtype" % i] = np.array(str(e["img"].dtype))
+    save("wild6d_items", **out)
+    print("  items:", len(ds), " img", tuple(e["img"].shape), e["img"].dtype, " depth", e["depth"].dtype)
+
+
 GENERATORS = {"softras": gen_softras, "step": gen_step, "corr": gen_corr, "losses": gen_losses,
-              "step_laptop": gen_step_laptop, "step_single": gen_step_single, "posefit": gen_posefit}
+              "step_laptop": gen_step_laptop, "step_single": gen_step_single, "posefit": gen_posefit, "data": gen_data}
 
 
 if __name__ == "__main__":

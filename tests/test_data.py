@@ -1,0 +1,98 @@
+"""training input pipeline: host mirror vs vectors recorded from the reference's Wild6DDataset, device
+crop+resize vs both."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import wild6d_synth
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wild6d_items.npz"))
+
+
+def _opts(tmp_path, **over):
+    root = os.path.join(str(tmp_path), "wild6d")
+    train_list = wild6d_synth.write_dataset(root, seed=0)
+    o = dict(train_list=train_list, dataset_path=root, batch_size=2, repeat=3, ngpu=1, total_iters=4, img_size=64,
+             no_stretch=False, use_depth=True, local_rank=-1, num_workers=0)
+    o.update(over)
+    return types.SimpleNamespace(**o)
+
+
+def _dataset(tmp_path, **over):
+    from scp_amd.data import Wild6DDataset
+    np.random.seed(11)                               # the fixture run seeded the sampler like this
+    return Wild6DDataset(_opts(tmp_path, **over))
+
+
+SCALARS = ("center", "length", "foc", "foc_crop", "pp", "pp_crop", "idx", "frame_idx")
+
+
+def test_sampler_and_items_match_reference(tmp_path):
+    ds = _dataset(tmp_path)
+    assert len(ds) == int(GOLD["n_items"])
+    assert np.array_equal(np.array(ds.sample_list, dtype=np.int64), GOLD["sample_list"])
+    np.random.seed(12)
+    for i in range(len(ds)):
+        e = ds[i]
+        for k in SCALARS:
+            ref = GOLD["i%02d_%s" % (i, k)]
+            assert np.allclose(e[k].numpy().astype(np.float64), ref.astype(np.float64), rtol=1e-6, atol=0), (i, k)
+        assert str(e["img"].dtype) == str(GOLD["i%02d_img_dtype" % i])
+        if i < 10:
+            assert np.abs(e["img"].numpy() - GOLD["i%02d_img" % i]).max() < 1e-6
+            assert np.array_equal(e["mask"].numpy(), GOLD["i%02d_mask" % i])
+            assert np.array_equal(e["depth"].numpy(), GOLD["i%02d_depth" % i])
+
+
+def test_raw_items_describe_the_same_box(tmp_path):
+    ds = _dataset(tmp_path)
+    np.random.seed(12)
+    raws = [ds.raw_item(i) for i in range(len(ds))]
+    padded = 0
+    for i, r in enumerate(raws):
+        ih, iw, pt, pl, vh, vw = r["_crop"]["geom"]
+        length = GOLD["i%02d_length" % i]
+        assert (vh, vw) == (2 * int(length[1]), 2 * int(length[0]))
+        assert r["_crop"]["img"].shape == (ih, iw, 3) and r["_crop"]["depth"].dtype == np.uint16
+        assert 0 <= pt and 0 <= pl and pt + ih <= vh and pl + iw <= vw
+        padded += (ih, iw) != (vh, vw)
+    assert padded > 0, "the synthetic set is built so that some boxes leave the frame"
+
+
+@pytest.mark.gpu
+def test_device_batches_match_reference(tmp_path):
+    from scp_amd.data import GpuCollator
+    ds = _dataset(tmp_path)
+    np.random.seed(12)
+    raws = [ds.raw_item(i) for i in range(len(ds))]
+    np.random.seed(12)
+    cpu = [ds[i] for i in range(len(ds))]
+    batch = GpuCollator(64, "cuda", True)(raws)
+    img, mask, depth = batch["img"].cpu(), batch["mask"].cpu(), batch["depth"].cpu()
+    assert img.dtype == torch.float32 and img.shape == (len(ds), 3, 64, 64)
+    for i in range(len(ds)):
+        assert (img[i].double() - cpu[i]["img"]).abs().max() < 1e-6
+        assert torch.equal(mask[i], cpu[i]["mask"]) and torch.equal(depth[i], cpu[i]["depth"])
+        if i < 10:
+            assert np.abs(img[i].numpy() - GOLD["i%02d_img" % i]).max() < 1e-6
+            assert np.array_equal(mask[i].numpy(), GOLD["i%02d_mask" % i]) and np.array_equal(depth[i].numpy(), GOLD["i%02d_depth" % i])
+    for k in SCALARS:
+        assert torch.equal(batch[k], torch.stack([c[k] for c in cpu]))
+
+
+@pytest.mark.gpu
+def test_loader_feeds_the_trainer_batch_shape(tmp_path):
+    from scp_amd.data import data_loader
+    opts = _opts(tmp_path, num_workers=2, img_size=96)
+    np.random.seed(3)
+    loader, ds = data_loader(opts)
+    batches = list(loader)
+    assert len(batches) == opts.total_iters
+    b = batches[0]
+    n = opts.batch_size * opts.repeat
+    assert b["img"].shape == (n, 3, 96, 96) and b["img"].is_cuda and b["mask"].shape == (n, 1, 96, 96)
+    assert b["foc_crop"].shape == (n, 2) and b["idx"].shape == (n, 1)
+    assert 0 <= float(b["img"].min()) and float(b["img"].max()) <= 1 and set(b["mask"].unique().tolist()) <= {0.0, 1.0}
