@@ -122,13 +122,56 @@ def cpu_baseline(sample_bs=2, sample_repeat=2):
                                       % (n_img, dt, n_img)}
 
 
+def bench_posefit(args):
+    """SURVEY 8f #4 beside the headline: one step = Tester.pose_fitting over a batch of 32 images (256x256, 100 RANSAC
+    rounds each), inputs resident in HBM.  cpu_baseline = the numpy restatement of the reference's per-image loop
+    (oracle/posefit.py) on a 4-image sample of the same batch."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    from posefit_inputs import posefit_inputs
+    from scp_amd import pose_fit
+    B = 32
+    data, _ = posefit_inputs(bsz=B, size=256, n_verts=642, seed=3)
+    keys = ("depth", "mask", "match", "match_conf", "foc_crop", "pp_crop", "pred_v")
+    dev_in = [data[k].cuda() for k in keys]
+    fit = pose_fit.PoseFitter(img_size=256, base_rot=torch.eye(3)[None].cuda())
+    for _ in range(args.warmup):
+        fit.pose_fitting(*dev_in)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fit.pose_fitting(*dev_in)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    pts = pose_fit.last_report["n_points"]
+    out = {"metric": "pose fits/sec (256x256 images, 100 RANSAC rounds, ~%dk correspondences each)" % (sum(pts) // len(pts) // 1000),
+           "value": B * args.steps / elapsed, "unit": "fits/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic", "config": {"workload": "Tester.pose_fitting, B=32, 256x256"},
+           "roofline": None, "cpu_baseline": None}
+    if not args.no_cpu_baseline:
+        from oracle import posefit as oracle_posefit      # checker code, here only as the thing being timed
+        sample = 4
+        host_in = [data[k][:sample].numpy() for k in keys]
+        t0 = time.perf_counter()
+        oracle_posefit.pose_fitting_oracle(*host_in, torch.eye(3)[None].numpy(), lambda m: torch.randint(0, m, (5,)).numpy())
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": sample / dt, "unit": "fits/sec", "cores": 1, "kind": "port",
+                               "sample": "%d images of the same batch, %.2f s" % (sample, dt)}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["train", "posefit"], default="train",
+                    help="train = BASELINE.json's metric (default); posefit = the test-time pose-fitting path (SURVEY 8f #4)")
     args = ap.parse_args()
+    if args.workload == "posefit":
+        return bench_posefit(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -1,5 +1,5 @@
 """tests/posefit_inputs.py -- seeded synthetic inputs for the test-time pose-fitting path (pure torch; shared by
-the fixture generator tests/golden/make_golden.py, the tests and tools/posefit_bench.py)."""
+the fixture generator tests/golden/make_golden.py, the tests and bench.py --workload posefit)."""
 import torch
 
 

@@ -1,4 +1,4 @@
-"""tools/step_report.py -- prints every loss / pose / gradient deviation of the golden training step
+"""tests/step_report.py -- prints every loss / pose / gradient deviation of the golden training step
 on the current device (no asserts); used to read parity numbers off the GPU box."""
 import os
 import sys
@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root
 for p in (ROOT, os.path.join(ROOT, "self-corr-pose_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import step_case  # noqa: E402

@@ -49,7 +49,19 @@ def from_trace(path, marker, skip, top=45):
         a[1] += d
     total = sum(v[1] for v in agg.values())
     span = int(rows[-1]["End_Timestamp"]) - (t0 or int(rows[0]["Start_Timestamp"]))
+    # union of the kernel intervals = time during which at least one kernel was resident; the rest is device idle
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if t0 is None or int(r["Start_Timestamp"]) >= t0)
+    union, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+    for a, b in iv[1:]:
+        if a > cur_e:
+            union += cur_e - cur_s
+            cur_s, cur_e = a, b
+        else:
+            cur_e = max(cur_e, b)
+    union += cur_e - cur_s
     print("# kernels after the %d-th launch of *%s*: busy %.1f ms of a %.1f ms window" % (skip, marker, total / 1e6, span / 1e6))
+    print("# at least one kernel resident for %.1f ms (%.1f %% of the window); device idle %.1f ms" % (
+        union / 1e6, 100.0 * union / span, (span - union) / 1e6))
     print("kernel,calls,total_ms,avg_us,pct")
     items = sorted(agg.items(), key=lambda kv: -kv[1][1])
     for k, (c, t) in items[:top]:
@@ -59,8 +71,37 @@ def from_trace(path, marker, skip, top=45):
                                                   100.0 * sum(v[1] for _, v in rest) / total))
 
 
+def gaps(path, marker, skip, top=25):
+    """largest device-idle gaps of the window, with the kernels before and after each"""
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    seen, t0 = 0, int(rows[0]["Start_Timestamp"])
+    for r in rows:
+        if marker in r["Kernel_Name"]:
+            seen += 1
+            if seen == skip + 1:
+                t0 = int(r["Start_Timestamp"])
+                break
+    rows = [r for r in rows if int(r["Start_Timestamp"]) >= t0]
+    out, cur_e, last = [], int(rows[0]["End_Timestamp"]), rows[0]
+    hist = {}
+    for r in rows[1:]:
+        a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if a > cur_e:
+            out.append((a - cur_e, (cur_e - t0) / 1e6, short(last["Kernel_Name"])[:60], short(r["Kernel_Name"])[:60]))
+            bucket = min(int((a - cur_e) / 1e3) // 10 * 10, 200)
+            hist[bucket] = hist.get(bucket, 0) + (a - cur_e)
+        if b > cur_e:
+            cur_e, last = b, r
+    print("# idle by gap length (us bucket -> total ms): " + ", ".join("%d+: %.2f" % (k, v / 1e6) for k, v in sorted(hist.items())))
+    for g, at, before, after in sorted(out, reverse=True)[:top]:
+        print("%8.1f us idle at %8.2f ms   after %-60s before %s" % (g / 1e3, at, before, after))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "--trace":
+    if sys.argv[1] == "--gaps":
+        gaps(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 25)
+    elif sys.argv[1] == "--trace":
         from_trace(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 45)
     else:
         main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 45)
