@@ -213,6 +213,15 @@ typedef struct scp_crop_desc {
 int scp_crop_resize_batch(const void* staging, const scp_crop_desc* descs, int B, int out_size, float* img_out,
                           float* mask_out, float* depth_out, void* stream);
 
+/* ---- mutual nearest neighbours: row + column argmax of a masked score matrix ------------------------------
+ * Replaces pretrained_corr.py:85-89 (`pointcorr * (mask>0) - 1e5 * (mask==0)`, `.max(1).indices`, `.max(2).indices`):
+ *   scores [N,P,Q] fp32 (Q % 4 == 0); rowmask [N,P] / colmask [N,Q] or NULL; an entry counts as -1e5 where either mask is <= 0
+ *   col_index [N,Q] = argmax over rows, row_index [N,P] = argmax over columns, int64, lowest index on ties.
+ *   workspace >= scp_mutual_argmax_workspace(N, Q) bytes. */
+size_t scp_mutual_argmax_workspace(int N, int Q);
+int scp_mutual_argmax(const float* scores, const float* rowmask, const float* colmask, int N, int P, int Q,
+                      long long* col_index, long long* row_index, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

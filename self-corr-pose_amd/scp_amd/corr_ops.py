@@ -27,6 +27,25 @@ def cols_forward(scores, rowmask, colmask, grid, tau, masked_out=None):
     return out, stats
 
 
+def mutual_argmax(scores, rowmask, colmask):
+    """scores [N,P,Q] -> (col_index [N,Q] = argmax over rows, row_index [N,P] = argmax over columns) of the masked
+    matrix (entries with either mask <= 0 count as -1e5), lowest index on ties; no gradient"""
+    L = capi.lib()
+    n, p, q = scores.shape
+    scores = scores.detach().contiguous().float()
+    rm = None if rowmask is None else rowmask.contiguous().float()
+    cm = None if colmask is None else colmask.contiguous().float()
+    col = torch.empty(n, q, dtype=torch.int64, device=scores.device)
+    row = torch.empty(n, p, dtype=torch.int64, device=scores.device)
+    nbytes = L.scp_mutual_argmax_workspace(n, q)
+    ws = torch.empty(nbytes // 8, dtype=torch.int64, device=scores.device)
+    capi.check(L.scp_mutual_argmax(capi.dev_ptr(scores, "scores"), capi.opt_ptr(rm, "rowmask"), capi.opt_ptr(cm, "colmask"),
+                                   n, p, q, ctypes.c_void_p(col.data_ptr()), ctypes.c_void_p(row.data_ptr()),
+                                   ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(nbytes), capi.current_stream()),
+               "scp_mutual_argmax")
+    return col, row
+
+
 def rows_forward(scores, weights, tau):
     n, p, q = scores.shape
     w = weights.shape[-1]

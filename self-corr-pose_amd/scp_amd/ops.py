@@ -2,7 +2,7 @@
 
 Each function states its tensor contract once; Correspondence / PretrainedCorrespondence call these
 and nothing else for all-pairs work.  The reductions that have hand-written HIP kernels
-(cols_softargmax, feature_vertex_match; csrc/corr.hip via scp_amd.corr_ops) accept GPU tensors ONLY and
+(cols_softargmax, feature_vertex_match, mutual_nn; csrc/corr.hip, csrc/mutual_nn.hip via scp_amd.corr_ops) accept GPU tensors ONLY and
 raise otherwise -- there is no CPU fallback in the product; CPU tests substitute the oracle
 (oracle/corr.py) for them with monkeypatch (tests/oracle_backend.py).  The remaining functions are
 compositions of stock PyTorch ops (library GEMMs, argmax, gather) and run on any device.
@@ -56,10 +56,10 @@ def pixel_pixel_softargmax(src_feat, tgt_feat, src_mask, tgt_mask, grid, tau):
 
 def mutual_nn(src_feat, tgt_feat, src_mask, tgt_mask):
     """src/tgt_feat [N,C,P] -> (bw [N,P_tgt] = argmax over src, fw [N,P_src] = argmax over tgt) of the
-    masked score matrix; ties resolve to the lowest index on CPU, backend-defined elsewhere"""
+    masked score matrix; ties resolve to the lowest index.  One pass over the score tensor (csrc/mutual_nn.hip)."""
+    _require_gpu(src_feat, "mutual_nn")
     pc = src_feat.transpose(1, 2).bmm(tgt_feat)
-    pc = _masked(pc, (src_mask[:, :, None] * tgt_mask[:, None, :]) > 0)
-    return pc.max(1).indices, pc.max(2).indices
+    return corr_ops.mutual_argmax(pc, src_mask, tgt_mask)
 
 
 def pool2x2_scores(pc, hf, wf):

@@ -46,6 +46,11 @@ def add_layernorm(x, branch, norm):
     return oracle_vit.add_layernorm_oracle(x, branch, norm.weight, norm.bias, norm.eps)
 
 
+def mutual_nn(src_feat, tgt_feat, src_mask, tgt_mask):
+    bw, fw, _ = oracle_corr.mutual_nn_oracle(src_feat, tgt_feat, src_mask, tgt_mask)
+    return bw, fw
+
+
 def install(monkeypatch):
     import scp_amd.dino as dino
     import scp_amd.mesh as mesh
@@ -55,6 +60,7 @@ def install(monkeypatch):
     monkeypatch.setattr(native, "backward_soft_rasterize", backward_soft_rasterize)
     monkeypatch.setattr(ops, "feature_vertex_match", feature_vertex_match)
     monkeypatch.setattr(ops, "cols_softargmax", oracle_corr.cols_softargmax_oracle)
+    monkeypatch.setattr(ops, "mutual_nn", mutual_nn)
     monkeypatch.setattr(dino, "fused_attention", fused_attention)
     monkeypatch.setattr(dino, "add_layernorm", add_layernorm)
     monkeypatch.setattr(mesh, "nearest_index", oracle_corr.nearest_index_oracle)

@@ -249,3 +249,27 @@ def test_hip_nearest_point_matches_bruteforce():
     assert torch.equal(_nearest_index_hip(x.cuda(), y.cuda()).cpu(), ref_i)
     got.sum().backward()
     assert torch.isfinite(xg.grad).all() and yg.grad.abs().sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,P,Q", [(3, 16, 64, 64), (2, 8, 37, 20), (2, 384, 1024, 1024), (1, 4, 5, 2052)])
+def test_hip_mutual_argmax_vs_oracle(N, C, P, Q):
+    """one-pass row/column argmax of the masked score matrix vs pretrained_corr.py:85-89 restated (oracle/corr.py),
+    including exact ties (duplicated feature columns), fully masked rows/columns and a ragged row count"""
+    from scp_amd import corr_ops
+    g = torch.Generator().manual_seed(N * 1000 + P)
+    src = torch.nn.functional.normalize(torch.randn(N, C, P, generator=g), dim=1)
+    tgt = torch.nn.functional.normalize(torch.randn(N, C, Q, generator=g), dim=1)
+    src[:, :, 3] = src[:, :, 1]                      # ties along rows
+    tgt[:, :, min(7, Q - 1)] = tgt[:, :, 0]          # ties along columns
+    sm = (torch.rand(N, P, generator=g) > 0.3).float()
+    tm = (torch.rand(N, Q, generator=g) > 0.3).float()
+    sm[0, :] = 0 if N > 2 else sm[0, :]              # a pair with nothing to match
+    pc = src.transpose(1, 2).bmm(tgt)
+    bw_ref, fw_ref, masked = oracle.mutual_nn_oracle(src, tgt, sm, tm)
+    bw, fw = corr_ops.mutual_argmax(pc.cuda(), sm.cuda(), tm.cuda())
+    bw, fw = bw.cpu(), fw.cpu()
+    # same GEMM result on both sides (computed once on the CPU), so indices must agree exactly
+    assert torch.equal(bw, bw_ref) and torch.equal(fw, fw_ref)
+    bw2, fw2 = corr_ops.mutual_argmax(pc.cuda(), None, None)
+    assert torch.equal(bw2.cpu(), pc.max(1).indices) and torch.equal(fw2.cpu(), pc.max(2).indices)
