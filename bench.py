@@ -73,6 +73,9 @@ class KernelTimer:
         return float(np.mean([a.elapsed_time(b) for a, b in self.events])) if self.events else None
 
 
+ATTN_TRAFFIC_BYTES = (76188 * 2 + 49200) * 1000.0   # KB as reported by rocprofv3
+
+
 def build_trainer(device, world, batch_size=8, repeat=4, seed=0):
     import scenes
     import scp_amd.dino as dino
@@ -264,7 +267,11 @@ def main():
             tf = flops / (attn_ms * 1e-3) / 1e12
             roofline = {"kernel": "vit_attention_kernel (fp32 MFMA flash attention, N=%d, 6x64, B=%d)" % (n_tok, B),
                         "bound": "mfma", "achieved": tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": tf / FP32_VALU_PEAK_TF, "traffic": None, "avg_launch_ms": attn_ms,
+                        "frac": tf / FP32_VALU_PEAK_TF,
+                        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
+                        # measured offline at this exact problem size: profiles/r01_pmc_attention.txt
+                        "traffic": ATTN_TRAFFIC_BYTES if (n_tok, heads, B) == (1025, 6, 32) else None,
+                        "traffic_source": "profiles/r01_pmc_attention.txt", "avg_launch_ms": attn_ms,
                         "algorithmic_flops_per_launch": flops, "launches_per_step": 9,
                         "raster_backward": raster}
         else:

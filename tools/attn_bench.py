@@ -40,7 +40,7 @@ print("hip attention %.3f ms = %.1f TFLOP/s (%.1f%% of 157.3)   torch sdpa %.3f 
 if "--ablate" in sys.argv:
     from scp_amd import capi
     lib = capi.lib()
-    for flags, what in ((0, "full"), (32, "no priority stagger"), (1, "no QK mfma"), (4, "no PV mfma"), (5, "no mfma at all"), (2, "no exp"),
+    for flags, what in ((0, "full"), (64, "no XCD-aware placement"), (32, "no priority stagger"), (1, "no QK mfma"), (4, "no PV mfma"), (5, "no mfma at all"), (2, "no exp"),
                         (8, "no DMA"), (16, "no barrier"), (24, "no DMA, no barrier"), (31, "nothing but loop")):
         lib.scpdbg_set_attn_flags(flags)
         print("  flags=%2d %-22s %.3f ms" % (flags, what, timeit(lambda: fused_attention(qkv, B, N, H, 64, 0.125))))
