@@ -195,8 +195,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
             o_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[r], s[r], o_hi, 0, 0, 0);
         }
         s = s_next;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's DMA pieces have landed
-        __syncthreads();                                      // ... everybody's; ring slots may be reused
+        if (!(dbg & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's DMA pieces have landed
+        if (!(dbg & 16)) __syncthreads();                                     // ... everybody's; ring slots may be reused
     }
 
     // ---- normalise and store: lane holds O[q = l31][d = acc_row(r, half) (+32)]

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "self-corr-pose_amd"))
 from scp_amd.dino import fused_attention  # noqa: E402
 
-B, N, H = 32, 1025, 6
+B, N, H = int(os.environ.get("B", "32")), int(os.environ.get("N", "1025")), 6
 qkv = torch.randn(B, N, 3 * H * 64, device="cuda")
 
 
@@ -38,10 +38,4 @@ print("hip attention %.3f ms = %.1f TFLOP/s (%.1f%% of 157.3)   torch sdpa %.3f 
     (fused_attention(qkv, B, N, H, 64, 0.125) - sdpa()).abs().max().item()))
 
 if "--ablate" in sys.argv:
-    from scp_amd import capi
-    lib = capi.lib()
-    for flags, what in ((0, "full"), (64, "no XCD-aware placement"), (32, "no priority stagger"), (1, "no QK mfma"), (4, "no PV mfma"), (5, "no mfma at all"), (2, "no exp"),
-                        (8, "no DMA"), (16, "no barrier"), (24, "no DMA, no barrier"), (31, "nothing but loop")):
-        lib.scpdbg_set_attn_flags(flags)
-        print("  flags=%2d %-22s %.3f ms" % (flags, what, timeit(lambda: fused_attention(qkv, B, N, H, 64, 0.125))))
-    lib.scpdbg_set_attn_flags(0)
+    print("see tools/attn_probe.py (interleaved timing under the kernel's debug switches)")
