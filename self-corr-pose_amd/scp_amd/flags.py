@@ -56,6 +56,16 @@ PRESETS = {
     "bottle_wild6d": dict(_WILD6D_COMMON, category="bottle", symmetry_idx=0, cycle_loss_wt=0.02,
                           cycle_loss_pretrain_wt=0.05, vert_lr_ratio=0.1,
                           rotation_offset=[0.1, 0.0, 0.0, 0.0, 0.1, -0.1], base_rot=[1, 0, 0, 0, 1, 0, 0, 0, 1]),
+    # config/{bowl,camera,mug}_wild6d/base_config.txt
+    "bowl_wild6d": dict(_WILD6D_COMMON, category="bowl", symmetry_idx=0, cycle_loss_wt=0.02,
+                        cycle_loss_pretrain_wt=0.005, vert_lr_ratio=0.1, cam_lr_ratio=0.2,
+                        rotation_offset=[0.2, 0.0, 0.0, 0.0, -0.2, 0.2], base_rot=[1, 0, 0, 0, -1, 0, 0, 0, 1]),
+    "camera_wild6d": dict(_WILD6D_COMMON, category="camera", symmetry_idx=-1, cycle_loss_wt=0.02,
+                          cycle_loss_pretrain_wt=0.005, vert_lr_ratio=0.1,
+                          rotation_offset=[0.2, 0.0, -0.1, 0.0, -0.2, 0.2], base_rot=[1, 0, 0, 0, -1, 0, 0, 0, 1]),
+    "mug_wild6d": dict(_WILD6D_COMMON, category="mug", symmetry_idx=1, cycle_loss_wt=0.01,
+                       cycle_loss_pretrain_wt=0.02, vert_lr_ratio=0.01,
+                       rotation_offset=[0.1, 0.0, 0.0, 0.0, -0.1, 0.1], base_rot=[1, 0, 0, 0, -1, 0, 0, 0, 1]),
 }
 
 

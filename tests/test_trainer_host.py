@@ -80,3 +80,26 @@ def test_flagfile_parser(tmp_path):
     with pytest.raises(AttributeError):
         (tmp_path / "bad.txt").write_text("--no_such_flag=1\n")
         load_flagfile(str(tmp_path / "bad.txt"))
+
+
+def test_category_presets_equal_the_shipped_flag_sets():
+    """the five Wild6D presets restate config/<category>_wild6d/base_config.txt (values recorded here so the check runs
+    without the reference): the fields that differ between categories"""
+    from scp_amd.flags import Options
+    expect = {
+        "bottle": dict(symmetry_idx=0, cycle_loss_wt=0.02, cycle_loss_pretrain_wt=0.05, vert_lr_ratio=0.1, cam_lr_ratio=0.1,
+                       rotation_offset=[0.1, 0.0, 0.0, 0.0, 0.1, -0.1], base_rot=[1, 0, 0, 0, 1, 0, 0, 0, 1]),
+        "bowl": dict(symmetry_idx=0, cycle_loss_wt=0.02, cycle_loss_pretrain_wt=0.005, vert_lr_ratio=0.1, cam_lr_ratio=0.2,
+                     rotation_offset=[0.2, 0.0, 0.0, 0.0, -0.2, 0.2], base_rot=[1, 0, 0, 0, -1, 0, 0, 0, 1]),
+        "camera": dict(symmetry_idx=-1, cycle_loss_wt=0.02, cycle_loss_pretrain_wt=0.005, vert_lr_ratio=0.1, cam_lr_ratio=0.1,
+                       rotation_offset=[0.2, 0.0, -0.1, 0.0, -0.2, 0.2], base_rot=[1, 0, 0, 0, -1, 0, 0, 0, 1]),
+        "laptop": dict(symmetry_idx=1, cycle_loss_wt=0.01, cycle_loss_pretrain_wt=0.02, vert_lr_ratio=0.01, cam_lr_ratio=0.1,
+                       rotation_offset=[0.2, 0.0, 0.0, 0.0, -0.2, 0.2], base_rot=[0, 0, 1, 0, -1, 0, -1, 0, 0]),
+        "mug": dict(symmetry_idx=1, cycle_loss_wt=0.01, cycle_loss_pretrain_wt=0.02, vert_lr_ratio=0.01, cam_lr_ratio=0.1,
+                    rotation_offset=[0.1, 0.0, 0.0, 0.0, -0.1, 0.1], base_rot=[1, 0, 0, 0, -1, 0, 0, 0, 1]),
+    }
+    for cat, fields in expect.items():
+        o = Options(cat + "_wild6d")
+        assert o.category == cat and o.batch_size == 8 and o.repeat == 4 and o.pretrain_k == 200 and o.divide_fn == "both"
+        for k, v in fields.items():
+            assert getattr(o, k) == v, (cat, k)
