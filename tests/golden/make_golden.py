@@ -454,6 +454,29 @@ def gen_posefit():
          bbox=bbox.numpy(), verts=verts.numpy(), rotation=rotation.numpy(), translation=translation.numpy())
     print("  RANSAC iterations per image:", per, " points per image:", [int(f[3]) for f in fits])
 
+    # pose-error metric of eval_nocs (tester.py:295-321) on the fitted boxes against seeded ground truths, through the
+    # reference's own get_best_deg_cm and the vendored objectron Box (third-party/objectron/dataset/box.py)
+    import model.util.eval_utils as ref_eval
+    from objectron.dataset import box as ref_box
+    g = torch.Generator().manual_seed(5)
+    metric = {}
+    bb = bbox.numpy()
+    for i in range(bsz):
+        q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+        if torch.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        rot_gt = (rotation[i].T @ q @ torch.linalg.matrix_exp(0.05 * (lambda a: a - a.T)(torch.randn(3, 3, generator=g)))).numpy() if i else rotation[i].T.numpy()
+        if i == 1:
+            rot_gt = (rotation[i].T @ torch.linalg.matrix_exp(0.08 * (lambda a: a - a.T)(torch.randn(3, 3, generator=g)))).numpy()
+        trans_gt = (translation[i, 0] + 0.01 * torch.randn(3, generator=g)).numpy()
+        scale_gt = (0.2 + 0.1 * torch.rand(3, generator=g)).numpy()
+        metric["gt%d_rot" % i], metric["gt%d_trans" % i], metric["gt%d_scale" % i] = rot_gt, trans_gt, scale_gt
+        for sym in (0, 1):
+            ang, cm = ref_eval.get_best_deg_cm(sym, ref_box.Box(bb[i]), rot_gt, trans_gt, scale_gt)
+            metric["gt%d_sym%d" % (i, sym)] = np.array([ang, cm])
+        print("  deg/cm image %d:" % i, metric["gt%d_sym0" % i], metric["gt%d_sym1" % i])
+    save("posefit_metric", n=np.int64(bsz), bbox=bb, rotation=rotation.numpy(), **metric)
+
     # direct estimateSimilarityTransform cases at comparable source/target scale, where the pass threshold
     # actually separates inliers from gross outliers (in pose_fitting's mm-vs-unit setting it never does)
     arrays = {}

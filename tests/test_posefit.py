@@ -192,3 +192,19 @@ def test_tester_predict_end_to_end():
     out = t.eval_deg_cm((bbox, verts, rot, tr), (rot.transpose(1, 2).cpu(), bbox[:, 0].cpu(), torch.ones(bsz, 3)))
     # identical poses: the reference's unclipped arccos((tr - 1) / 2) sits at the edge of its domain, NaN allowed
     assert len(out) == bsz and all((np.isnan(a) or a < 0.1) and c < 1e-3 for a, c in out)
+
+
+def test_deg_cm_metric_matches_reference():
+    """scp_amd.tester.get_best_deg_cm vs eval_utils.get_best_deg_cm + the vendored objectron Box, recorded on the fitted
+    boxes of the pose-fitting fixture (tests/golden/posefit_metric.npz)"""
+    from scp_amd.tester import get_best_deg_cm
+    d = np.load(os.path.join(GOLD, "posefit_metric.npz"))
+    for i in range(int(d["n"])):
+        for sym in (0, 1):
+            ang, cm = get_best_deg_cm(sym, d["bbox"][i].astype(np.float64), d["rotation"][i].T.astype(np.float64),
+                                      d["gt%d_rot" % i].astype(np.float64), d["gt%d_trans" % i].astype(np.float64),
+                                      d["gt%d_scale" % i].astype(np.float64))
+            ref = d["gt%d_sym%d" % (i, sym)]
+            assert abs(cm - ref[1]) < 1e-6 * (1 + ref[1])
+            # near 0 the unclipped arccos turns 1e-7 of rounding in the matrix into ~0.01 degrees (thresholds are 5 / 10)
+            assert abs(ang - ref[0]) < 2e-2 + 1e-4 * ref[0], (i, sym, ang, ref[0])
