@@ -27,6 +27,18 @@ import torch.nn.functional as F
 # the reference cannot be constructed without the checkpoint file (dino.py:40-44); synthetic-weight
 # runs (bench, tests) flip this on explicitly
 ALLOW_RANDOM_INIT = False
+# BASELINE configs[4] (mixed bf16): the six linear layers of every block run on the bf16 matrix cores (fp32
+# accumulate); residual stream, LayerNorm, attention scores / softmax / P.V stay fp32.  Set from opts.mixed_bf16.
+MIXED_BF16 = False
+
+
+def _linear(layer_or_w, x, bias=None):
+    """Linear with fp32 output; under MIXED_BF16 the GEMM itself takes bf16 operands"""
+    w, b = (layer_or_w.weight, layer_or_w.bias) if isinstance(layer_or_w, nn.Linear) else (layer_or_w, bias)
+    if MIXED_BF16 and x.is_cuda:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return F.linear(x, w, b).float()
+    return F.linear(x, w, b)
 
 
 class _Mlp(nn.Module):
@@ -36,7 +48,7 @@ class _Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
 
     def forward(self, x):
-        return self.fc2(F.gelu(self.fc1(x)))
+        return _linear(self.fc2, F.gelu(_linear(self.fc1, x)))
 
 
 class _Attention(nn.Module):
@@ -49,13 +61,13 @@ class _Attention(nn.Module):
 
     def forward(self, x):
         b, n, c = x.shape
-        y = fused_attention(self.qkv(x), b, n, self.num_heads, c // self.num_heads, self.scale)   # [b,n,c]
-        return self.proj(y)
+        y = fused_attention(_linear(self.qkv, x), b, n, self.num_heads, c // self.num_heads, self.scale)   # [b,n,c]
+        return _linear(self.proj, y)
 
     def keys(self, x):
         """only the K third of the qkv projection: [b, heads, n, d]"""
         b, n, c = x.shape
-        k = F.linear(x, self.qkv.weight[c:2 * c], self.qkv.bias[c:2 * c])
+        k = _linear(self.qkv.weight[c:2 * c], x, self.qkv.bias[c:2 * c])
         return k.reshape(b, n, self.num_heads, c // self.num_heads).permute(0, 2, 1, 3)
 
 

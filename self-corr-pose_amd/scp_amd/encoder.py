@@ -31,9 +31,12 @@ class Encoder(nn.Module):
             # upsampling are ~2x faster on gfx950 than the NCHW paths for these shapes (measured,
             # tools/conv_diag.py); values are layout independent
             x = x.contiguous(memory_format=torch.channels_last)
-        c2, c3, c4, c5 = self.backbone(x)
-        img_code = c5.mean((2, 3))
-        feat = self.featnet(c2, c3, c4, c5).contiguous().reshape(img.shape[0], self.opts.n_corr_feat, -1)
+        # BASELINE configs[4]: convolutions on the bf16 matrix cores, everything after them in fp32
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(getattr(self.opts, "mixed_bf16", False)) and x.is_cuda):
+            c2, c3, c4, c5 = self.backbone(x)
+            feat = self.featnet(c2, c3, c4, c5)
+        img_code = c5.float().mean((2, 3))
+        feat = feat.float().contiguous().reshape(img.shape[0], self.opts.n_corr_feat, -1)
         return img_code, F.normalize(feat, 2, 1)
 
     def forward(self, img, mean_v, pp_crop, foc_crop):

@@ -13,6 +13,9 @@ util/base_rot.py:8.
 import copy
 
 DEFAULTS = dict(
+    # not a reference flag: BASELINE configs[4] "mixed bf16" -- encoder convolutions and ViT linear layers under bf16
+    # autocast; SoftRas, correspondence reductions, attention softmax, losses and the optimizer stay fp32
+    mixed_bf16=False,
     # config.py
     train=False, test=False, seed=0, ngpu=1, local_rank=0, num_workers=8, checkpoint_dir="log",
     name="exp", train_list="", test_list="", model_path="", vis_path="", total_iters=10000,

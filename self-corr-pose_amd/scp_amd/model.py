@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import losses
+from . import dino, losses
 from .correspondence import Correspondence
 from .encoder import Encoder
 from .mesh import CanonicalMesh
@@ -43,6 +43,7 @@ class MeshNet(nn.Module):
 
     def forward(self, data):
         opts, wts = self.opts, self.weights
+        dino.MIXED_BF16 = bool(getattr(opts, "mixed_bf16", False))
         wts.schedule(self.iters)
         img, mask, depth, occ, center, length, foc, foc_crop, pp, pp_crop, indices, gt = data
         bsz = img.shape[0]

@@ -103,3 +103,59 @@ def test_every_wild6d_category_preset_steps(category):
         total, aux, grad = tr.step(data)
         assert torch.isfinite(total).all() and all(torch.isfinite(v).all() for v in aux.values())
     assert not torch.equal(before, tr.model.mesh.mean_v)
+
+
+def test_mixed_bf16_step_tracks_fp32():
+    """BASELINE configs[4] precision (opts.mixed_bf16: bf16 convolutions and ViT linears, fp32 everywhere else): the
+    same model / batch in both precisions.  bf16 carries 8 mantissa bits, so this is a sanity band, not parity: every
+    loss term within 5 % (or 2e-3 absolute) of its fp32 value, finite gradients."""
+    import copy
+    import scp_amd.dino as dino
+    from scp_amd import imgops
+    from scp_amd.flags import Options
+    from scp_amd.trainer import Trainer
+    import scenes
+    import synth
+    dino.ALLOW_RANDOM_INIT = True
+    out = {}
+    state = None
+    for mixed in (False, True):
+        opts = Options("laptop_wild6d", batch_size=2, repeat=2, train=True, total_iters=100, mixed_bf16=mixed)
+        torch.manual_seed(0)
+        tr = Trainer(opts, prior=scenes.bottle_like(3), device="cuda")
+        if state is None:
+            state = copy.deepcopy(tr.model.state_dict())
+        tr.model.load_state_dict(state)
+        tr.model.encoder.random_jitter = torch.nn.Identity()
+        tr.model.rotation_angle = 90.0
+        data = synth.make_batch(2, 2, 256, seed=4, device="cuda")
+        torch.manual_seed(1)
+        total, aux = tr.model(data)
+        total.mean().backward()
+        assert all(torch.isfinite(p.grad).all() for p in tr.model.parameters() if p.grad is not None)
+        out[mixed] = {k: float(v.detach()) for k, v in aux.items()}
+    dino.MIXED_BF16 = False
+    for k, ref in out[False].items():
+        if k == "cycle_loss_pretrain":
+            continue            # discrete top-k / argmax selections on DINO features: re-selected under bf16
+        assert abs(out[True][k] - ref) <= 5e-2 * abs(ref) + 2e-3, (k, out[True][k], ref)
+
+
+def test_high_res_mixed_bf16_step_runs():
+    """BASELINE configs[4]: 512x512, icosphere-4 mesh (2562 v / 5120 f), mixed bf16"""
+    import scp_amd.dino as dino
+    from scp_amd.flags import Options
+    from scp_amd.trainer import Trainer
+    import scenes
+    import synth
+    dino.ALLOW_RANDOM_INIT = True
+    opts = Options("laptop_wild6d", batch_size=1, repeat=2, train=True, total_iters=100, img_size=512, corr_h=128,
+                   corr_w=128, mixed_bf16=True)
+    torch.manual_seed(0)
+    tr = Trainer(opts, prior=scenes.bottle_like(4), device="cuda")
+    data = synth.make_batch(1, 2, 512, seed=3, device="cuda")
+    try:
+        total, aux, grad = tr.step(data)
+    finally:
+        dino.MIXED_BF16 = False
+    assert torch.isfinite(total).all() and all(torch.isfinite(v).all() for v in aux.values())
