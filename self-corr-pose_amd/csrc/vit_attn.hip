@@ -21,6 +21,8 @@
 // 155 TFLOP/s fp32 MFMA peak.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "scp_common.h"
 #include "scp_hip.h"
 
@@ -31,6 +33,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int HD = 64;        // head dim (fixed: ViT-S)
 constexpr int KT = 32;        // keys per tile
 constexpr float RESCALE_THR = 16.f;   // log2 units
+
+// value of the partner lane (lane ^ 32) through v_permlane32_swap (gfx950): a register move between the two halves of
+// the wavefront, instead of ds_bpermute's trip through the LDS crossbar and the lgkmcnt wait behind it
+__device__ __forceinline__ float other_half(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    // r[0] = [x.lo | x.lo], r[1] = [x.hi | x.hi]: the partner's value is whichever differs from "mine"
+    return (threadIdx.x & 32) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
+}
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
@@ -66,22 +76,45 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
     const int q0 = (qg * WAVES + wave) * 32;
     const size_t row_stride = (size_t)3 * H * HD;                 // floats between consecutive tokens
     const float* base = qkv + (size_t)b * N * row_stride + (size_t)h * HD;
-    const float* kbase = base + (size_t)H * HD;
-    const float* vbase = base + (size_t)2 * H * HD;
 
-    auto issue_tile = [&](int kt, int buf, bool do_k, bool do_v) {
-        const int r4 = lane >> 4, slot = lane & 15;
+    // LDS-DMA pieces: a K or V tile is 8 wavefront-instructions of 1 KiB (piece j: rows 4*(j&7) .. +3, 16 lanes x 16 B per
+    // row); the 16 pieces of a (K tile, V tile) pair are dealt round-robin to the wavefronts.  Everything per-lane about a
+    // piece is loop invariant -- row, swizzled chunk, K/V column block -- and is folded into ONE 32-bit element offset here;
+    // per tile the source address is (uniform tile base) + that offset, so the loop carries no per-lane address arithmetic.
+    constexpr int PIECES = (16 + WAVES - 1) / WAVES;
+    const int ntiles = (N + KT - 1) / KT;
+    const int r4 = lane >> 4, slot = lane & 15;
+    unsigned lane_off[PIECES];
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            if (j % WAVES != wave) continue;          // wavefront-uniform
+    for (int i = 0; i < PIECES; i++) {
+        const int j = wave + WAVES * i, jj = j & 7, r = 4 * jj + r4;
+        const bool is_v = j >= 8;
+        const int chunk = is_v ? slot : (slot ^ (r & 15));
+        lane_off[i] = (unsigned)r * (unsigned)row_stride + 4u * chunk + (is_v ? 2u : 1u) * (unsigned)(H * HD);
+    }
+    auto issue_piece = [&](int i, int kt, float* lds_tile) {
+        const int j = wave + WAVES * i;
+        const float* tile = base + (size_t)kt * KT * row_stride;                       // wavefront-uniform
+        unsigned off = lane_off[i];
+        if (kt == ntiles - 1) {   // ragged last tile (wavefront-uniform branch): rows past the sequence re-read the last key
+            const int jj = j & 7, r = min(4 * jj + r4, N - 1 - kt * KT);
             const bool is_v = j >= 8;
-            if (is_v ? !do_v : !do_k) continue;
-            const int jj = j & 7, r = 4 * jj + r4;
-            const int key = min(kt * KT + r, N - 1);
-            const int chunk = is_v ? slot : (slot ^ (r & 15));
-            const float* src = (is_v ? vbase : kbase) + (size_t)key * row_stride + 4 * chunk;
-            float* dst = (is_v ? v_lds[buf] : k_lds[buf]) + jj * 256;
-            __builtin_amdgcn_global_load_lds(SCP_GLOBAL_PTR(src), SCP_LDS_PTR(dst), 16, 0, 0);
+            const int chunk = is_v ? slot : (slot ^ ((4 * jj + r4) & 15));
+            off = (unsigned)r * (unsigned)row_stride + 4u * chunk + (is_v ? 2u : 1u) * (unsigned)(H * HD);
+        }
+        __builtin_amdgcn_global_load_lds(SCP_GLOBAL_PTR(tile + off), SCP_LDS_PTR(lds_tile + (j & 7) * 256), 16, 0, 0);
+    };
+    // K tile kt_k -> k_lds[bufk] and / or V tile kt_v -> v_lds[bufv]
+    auto issue_tiles = [&](bool do_k, int kt_k, int bufk, bool do_v, int kt_v, int bufv) {
+#pragma unroll
+        for (int i = 0; i < PIECES; i++) {
+            const int j = wave + WAVES * i;                                            // wavefront-uniform
+            if (j >= 16) continue;
+            if (j < 8) {
+                if (do_k) issue_piece(i, kt_k, k_lds[bufk]);
+            } else if (do_v) {
+                issue_piece(i, kt_v, v_lds[bufv]);
+            }
         }
     };
 
@@ -108,7 +141,6 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
     // leaves the pipe idle during every softmax phase: measured 0.45 ms MFMA + 0.15 ms VALU, additive).
     // LDS rings: K(t+1) is read in iteration t from k_lds[(t+1)&1], V(t) from v_lds[t&1]; K(t+2) and
     // V(t+1) are in flight (LDS-DMA) meanwhile; one barrier per tile.
-    const int ntiles = (N + KT - 1) / KT;
     const int kslot0 = (8 * half) ^ (l31 & 15);
     auto qk_tile = [&](int kbuf) {
         f32x16 acc;
@@ -125,17 +157,18 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
         }
         return acc;
     };
-    issue_tile(0, 0, true, true);
-    if (ntiles > 1) issue_tile(1, 1, true, false);
+    issue_tiles(true, 0, 0, true, 0, 0);
+    if (ntiles > 1) issue_tiles(true, 1, 1, false, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x16 s = qk_tile(0);
     __syncthreads();   // K(0) has been read by every wavefront before iteration 0 refills k_lds[0] with K(2)
-    for (int kt = 0; kt < ntiles; kt++) {
+    auto tile_step = [&](int kt, auto ragged_tag) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
         const int buf = kt & 1;
         if (!(dbg & 8)) {
-            if (kt + 2 < ntiles) issue_tile(kt + 2, buf, true, false);        // K(t+2) -> k_lds[t&1]
-            if (kt + 1 < ntiles) issue_tile(kt + 1, buf ^ 1, false, true);    // V(t+1) -> v_lds[(t+1)&1]
+            // K(t+2) -> k_lds[t&1], V(t+1) -> v_lds[(t+1)&1]
+            issue_tiles(kt + 2 < ntiles, kt + 2, buf, kt + 1 < ntiles, kt + 1, buf ^ 1);
         }
         // V operands of tile t's P.V MFMAs: issued first so that their LDS latency is covered by the
         // max / rescale work below (the empty asm pins the loads here; the compiler otherwise sinks each
@@ -152,14 +185,14 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
         // ---- running maximum of tile t (lane owns 16 keys of its query; partner lane^32 the other 16)
         const int key_base = kt * KT;
         float m_tile = -INFINITY;
-        if (key_base + KT > N) {   // ragged last tile: wavefront-uniform branch
+        if (RAGGED) {   // only the peeled last tile carries the key-bound test
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 if (key_base + acc_row(r, half) >= N) s[r] = -INFINITY;
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) m_tile = fmaxf(m_tile, s[r]);
-        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        m_tile = fmaxf(m_tile, other_half(m_tile));
         // Deferred rescale: the running maximum is only raised (and O, l rescaled) when some query's tile
         // maximum exceeds it by more than 2^RESCALE_THR; otherwise the probabilities are taken against
         // the old maximum (bounded by 2^RESCALE_THR, harmless in fp32).  Wavefront-uniform decision; O, l
@@ -197,10 +230,16 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
         s = s_next;
         if (!(dbg & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's DMA pieces have landed
         if (!(dbg & 16)) __syncthreads();                                     // ... everybody's; ring slots may be reused
-    }
+    };
+    // the key-bound mask (15 compares + selects per lane) is only needed where a tile crosses the end of the sequence:
+    // peel that tile so that the steady-state loop does not carry it
+    const bool ragged = (N % KT) != 0;
+    const int full = ragged ? ntiles - 1 : ntiles;
+    for (int kt = 0; kt < full; kt++) tile_step(kt, std::false_type());
+    if (ragged) tile_step(ntiles - 1, std::true_type());
 
     // ---- normalise and store: lane holds O[q = l31][d = acc_row(r, half) (+32)]
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = l_run + other_half(l_run);
     const float inv = 1.f / l_tot;
     const int q = q0 + l31;
     if (q < N) {
