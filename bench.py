@@ -93,7 +93,9 @@ def isolated_attention(B, n_tok, heads, hd, flops, iters=30):
     return {"avg_launch_ms": ms, "achieved": tf, "frac": tf / FP32_VALU_PEAK_TF}
 
 
-def build_trainer(device, world, batch_size=8, repeat=4, seed=0, mixed_bf16=False):
+def build_trainer(device, world, batch_size=8, repeat=4, seed=0, mixed_bf16=None):
+    if mixed_bf16 is None:      # tools/*.py reuse this builder; SCP_MIXED_BF16=1 switches them to configs[4] precision
+        mixed_bf16 = os.environ.get("SCP_MIXED_BF16", "0") == "1"
     import scenes
     import scp_amd.dino as dino
     from scp_amd.flags import Options
