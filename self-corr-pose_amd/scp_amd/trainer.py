@@ -40,7 +40,10 @@ def enable_gemm_tuning():
         return
     tun = torch.cuda.tunable
     tun.enable(True)
-    tun.set_filename(os.path.join(tempfile.gettempdir(), "scp_tunableop_%d.csv" % os.getpid()), False)
+    # SCP_GEMM_TUNING_OUT=<file>: where this process writes what it ends up with (shipped + newly tuned shapes), for
+    # regenerating tuning/gemm_gfx950.csv (tools/retune_gemms.sh); default is a scratch file
+    out = os.environ.get("SCP_GEMM_TUNING_OUT") or os.path.join(tempfile.gettempdir(), "scp_tunableop_%d.csv" % os.getpid())
+    tun.set_filename(out, False)
     tun.set_max_tuning_duration(30)
     tun.tuning_enable(True)
     if os.path.exists(TUNED_GEMMS):
