@@ -46,6 +46,8 @@ class Encoder(nn.Module):
         rotation, trans, scale = self.pose_predictor(img_code)
         pred_v = pred_v * scale[:, None]
         # principal-point compensation of the in-plane translation (encoder.py:49)
-        xy = trans[:, :2] - (pp_crop / foc_crop) * trans[:, 2:].detach()
+        # (in place in the reference: evaluated in the promoted dtype -- the loader's intrinsics are float64 -- and rounded
+        # back to the translation's)
+        xy = (trans[:, :2] - (pp_crop / foc_crop) * trans[:, 2:].detach()).to(trans.dtype)
         translation = torch.cat((xy, trans[:, 2:]), 1)
         return img_feat, mesh_feat, pred_v, rotation.reshape(-1, 3, 3), translation.reshape(-1, 1, 3), scale

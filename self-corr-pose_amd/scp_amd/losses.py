@@ -18,14 +18,17 @@ from . import soft_renderer as sr
 
 
 def pinhole_cam(verts, pp, foc):
-    """NDC pinhole projection of camera-space points; z is kept"""
+    """NDC pinhole projection of camera-space points; z is kept.  The reference assigns into `verts` in place
+    (loss_utils.py:38-47), so with the data loader's float64 intrinsics (dataset_wild6d.py:173-176 builds them from
+    numpy doubles) the expression is evaluated in float64 and ROUNDED to the vertices' dtype: same here."""
+    dt = verts.dtype
     if verts.dim() == 3:
-        x = pp[:, 0][:, None] + verts[:, :, 0] * foc[:, 0][:, None] / verts[:, :, 2]
-        y = pp[:, 1][:, None] + verts[:, :, 1] * foc[:, 1][:, None] / verts[:, :, 2]
+        x = (pp[:, 0][:, None] + verts[:, :, 0] * foc[:, 0][:, None] / verts[:, :, 2]).to(dt)
+        y = (pp[:, 1][:, None] + verts[:, :, 1] * foc[:, 1][:, None] / verts[:, :, 2]).to(dt)
         return torch.stack((x, y, verts[:, :, 2]), 2)
     if verts.dim() == 2:
-        x = pp[0] + verts[:, 0] * foc[0] / verts[:, 2]
-        y = pp[1] + verts[:, 1] * foc[1] / verts[:, 2]
+        x = (pp[0] + verts[:, 0] * foc[0] / verts[:, 2]).to(dt)
+        y = (pp[1] + verts[:, 1] * foc[1] / verts[:, 2]).to(dt)
         return torch.stack((x, y, verts[:, 2]), 1)
     raise ValueError("vertices shape must be (bsz, N, 3) or (N, 3).")
 

@@ -152,6 +152,38 @@ class Trainer:
         self.iteration += 1
         return total_loss, aux_output, grad
 
+    def train(self, loader=None, log=print):
+        """the loop of model/trainer.py:104-125: data_loader -> batch_reshape -> step -> periodic log / checkpoint.
+        `loader` defaults to scp_amd.data.data_loader(opts) (same Wild6D layout and sampler, resize on the device);
+        any iterable of reference-style batch dicts works.  Logging is a one-line print (the reference's tensorboard
+        writer and visualisation block are out of scope); checkpoints go to <checkpoint_dir>/<name>/pred_net_<it>.pth
+        every `save_freq` iterations like trainer.py:152-158.  Returns the list of per-iteration total losses."""
+        import time
+        opts = self.opts
+        if loader is None:
+            from .data import data_loader
+            loader, self.dataset = data_loader(opts, self.device)
+        save_dir = os.path.join(opts.checkpoint_dir, opts.name)
+        history, t0 = [], time.time()
+        pending = []                                   # device scalars; read back only at log time (no per-step sync)
+        for i, batch in enumerate(loader):
+            total, aux, grad = self.step(self.batch_reshape(batch))
+            pending.append(total.detach())
+            if (i + 1) % opts.batch_log_interval == 0:
+                vals = torch.stack(pending).cpu().tolist()
+                history.extend(vals)
+                pending = []
+                t1 = time.time()
+                log("batch %d, batch size %d, mean per iter time:%.4f, loss %.5f" % (
+                    i + 1, batch["img"].shape[0], (t1 - t0) / opts.batch_log_interval, vals[-1]))
+                t0 = t1
+            if opts.save_freq and (i + 1) % opts.save_freq == 0:
+                os.makedirs(save_dir, exist_ok=True)
+                self.save(os.path.join(save_dir, "pred_net_%d.pth" % (i + 1)))
+        if pending:
+            history.extend(torch.stack(pending).cpu().tolist())
+        return history
+
     def save(self, path):
         state = self.model.state_dict()
         state["mesh.faces"] = self.model.mesh.faces.cpu()
