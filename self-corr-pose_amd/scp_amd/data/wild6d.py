@@ -55,18 +55,29 @@ def _resized_crop(img, top, left, height, width, size, mode):
 
 
 class Wild6DDataset(Dataset):
+    training = True
+
     def __init__(self, opts):
         self.opts = opts
-        with open(opts.train_list) as f:
+        self._index(opts.train_list, opts.dataset_path)
+        self.samples_per_iter = opts.batch_size * opts.repeat * opts.ngpu
+        self.samples_total = opts.total_iters * self.samples_per_iter
+        self.sample_list = None
+        self.reset()
+
+    def _index(self, list_path, root):
+        """sequence list -> per-sequence frame lists and intrinsics (:44-75; the test set is laid out the same way)"""
+        with open(list_path) as f:
             self.train_list = f.read().strip().split()
-        self.imglist, self.masklist, self.depthlist, self.metalist = [], [], [], []
+        self.imglist, self.masklist, self.depthlist, self.metalist, self.seq_names = [], [], [], [], []
         self.total_frames = 0
-        obj_list = sorted(os.listdir(opts.dataset_path))
+        obj_list = sorted(os.listdir(root))
         for seqname in self.train_list:
             parts = seqname.split("_")
             obj_index, seq_index = int(parts[-2]), int(parts[-1])
-            seq_list = sorted(os.listdir(os.path.join(opts.dataset_path, obj_list[obj_index])))
-            seq_dir = os.path.join(opts.dataset_path, obj_list[obj_index], seq_list[seq_index])
+            seq_list = sorted(os.listdir(os.path.join(root, obj_list[obj_index])))
+            seq_dir = os.path.join(root, obj_list[obj_index], seq_list[seq_index])
+            self.seq_names.append((obj_list[obj_index], seq_list[seq_index]))
             mask_list = glob.glob(os.path.join(seq_dir, "images/*-mask.png"))
             mask_list.sort(key=lambda item: int(item.split("/")[-1].split("-")[0]))
             self.masklist.append(mask_list)
@@ -77,10 +88,6 @@ class Wild6DDataset(Dataset):
             K = np.array(meta["K"]).reshape(3, 3).T if "K" in meta else None     # stored column-major
             self.metalist.append((K, meta.get("w"), meta.get("h"), meta.get("fps")))
             self.total_frames += len(mask_list)
-        self.samples_per_iter = opts.batch_size * opts.repeat * opts.ngpu
-        self.samples_total = opts.total_iters * self.samples_per_iter
-        self.sample_list = None
-        self.reset()
 
     def __len__(self):
         return self.samples_total
@@ -101,11 +108,15 @@ class Wild6DDataset(Dataset):
         self.sample_list = total
 
     # ---- the part shared by both paths: decode, box, intrinsics (:115-158) -------------------------------------------
-    def _load(self, index):
-        o = self.opts
+    def _sample(self, index):
+        """(video, frame, box scale) of item `index`: training draws the 1.2-1.5x scale per item (:121)"""
         batch_id, item_id = divmod(index, self.samples_per_iter)
         video_id, frame_id = self.sample_list[batch_id][item_id]
-        rand_scale = np.random.uniform(1.2, 1.5, size=(2,))
+        return video_id, frame_id, np.random.uniform(1.2, 1.5, size=(2,))
+
+    def _load(self, index):
+        o = self.opts
+        video_id, frame_id, rand_scale = self._sample(index)
         img = _imread_rgb(self.imglist[video_id][frame_id])
         mask = _imread_gray(self.masklist[video_id][frame_id]).astype(bool)
         depth = _imread_unchanged(self.depthlist[video_id][frame_id]) if o.use_depth else None
@@ -113,7 +124,7 @@ class Wild6DDataset(Dataset):
         yid, xid = np.where(mask > 0)
         center = [(xid.max() + xid.min()) // 2, (yid.max() + yid.min()) // 2]
         length = [(xid.max() - xid.min()) // 2, (yid.max() - yid.min()) // 2]
-        if o.no_stretch:
+        if o.no_stretch and self.training:
             m = max(length)
             length = [int(rand_scale[0] * m), int(rand_scale[0] * m)]
         else:
@@ -158,6 +169,58 @@ class Wild6DDataset(Dataset):
             "geom": (y1 - y0, x1 - x0, y0 - top, x0 - left, bh, bw),   # in_h, in_w, pad_top, pad_left, virt_h, virt_w
         }
         return elem
+
+
+class Wild6DTestDataset(Wild6DDataset):
+    """data/dataset_wild6d_test.py:37-200: every `dframe_eval`-th frame of every listed sequence in order, a fixed 1.35x box,
+    and -- with opts.eval -- the ground-truth pose of each frame from
+    <test_set>/../pkl_annotations/<class>/<class>-<obj>-<seq>.pkl (`annotations[i]` = {name, rotation, translation, size})"""
+    training = False
+
+    def __init__(self, opts):
+        import pickle
+        self.opts = opts
+        self._index(opts.test_list, opts.test_dataset_path)
+        self.rot_gt_list, self.trans_gt_list, self.scale_gt_list = [], [], []
+        for obj, seq in self.seq_names:
+            rots, transs, sizes = [], [], []
+            if getattr(opts, "eval", False):
+                root = opts.test_dataset_path
+                prefix = root.rfind("test_set") + 9
+                class_name = root[prefix:-1]
+                gt_path = root[:prefix] + "pkl_annotations/" + root[prefix:] + "{}-{}-{}.pkl".format(class_name, obj, seq)
+                with open(gt_path, "rb") as f:
+                    gt = pickle.load(f)
+                for i, anno in enumerate(gt["annotations"]):
+                    assert int(anno["name"].split("/")[3]) == i
+                    rots.append(np.array(anno["rotation"]))
+                    transs.append(np.array(anno["translation"]))
+                    sizes.append(np.array(anno["size"]))
+            self.rot_gt_list.append(rots)
+            self.trans_gt_list.append(transs)
+            self.scale_gt_list.append(sizes)
+        step = max(1, int(getattr(opts, "dframe_eval", 1)))
+        self.sample_list = [(v, i) for v in range(len(self.masklist)) for i in range(0, len(self.masklist[v]), step)]
+
+    def __len__(self):
+        return len(self.sample_list)
+
+    def reset(self):
+        pass
+
+    def _sample(self, index):
+        video_id, frame_id = self.sample_list[index]
+        return video_id, frame_id, np.array([1.35, 1.35])
+
+    def _load(self, index):
+        out = super()._load(index)
+        if getattr(self.opts, "eval", False):
+            video_id, frame_id = self.sample_list[index]
+            elem = out[4]
+            elem["rotation"] = torch.tensor(self.rot_gt_list[video_id][frame_id])
+            elem["translation"] = torch.tensor(self.trans_gt_list[video_id][frame_id])
+            elem["scale"] = torch.tensor(self.scale_gt_list[video_id][frame_id])
+        return out
 
 
 class _RawView(Dataset):
@@ -239,6 +302,17 @@ class _DeviceLoader:
     def __iter__(self):
         for items in self.loader:
             yield self.collator(items)
+
+
+def test_loader(opts, device="cuda"):
+    """data/dataloader.py:69-84 (batch_size = opts.batch_size, no drop_last) with the resize on the device"""
+    dataset = Wild6DTestDataset(opts)
+    sampler = None
+    if getattr(opts, "local_rank", -1) != -1 and getattr(opts, "ngpu", 1) > 1:
+        sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=opts.ngpu, rank=opts.local_rank, shuffle=False)
+    loader = DataLoader(_RawView(dataset), batch_size=opts.batch_size, num_workers=getattr(opts, "num_workers", 0), sampler=sampler,
+                        shuffle=bool(getattr(opts, "shuffle_test", False)) and sampler is None, collate_fn=list)
+    return _DeviceLoader(loader, GpuCollator(opts.img_size, device, opts.use_depth)), dataset
 
 
 def data_loader(opts, device="cuda"):

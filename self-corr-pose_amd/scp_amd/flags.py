@@ -16,6 +16,8 @@ DEFAULTS = dict(
     # not a reference flag: BASELINE configs[4] "mixed bf16" -- encoder convolutions and ViT linear layers under bf16
     # autocast; SoftRas, correspondence reductions, attention softmax, losses and the optimizer stay fp32
     mixed_bf16=False,
+    # model/tester.py:35-37 (the CUB evaluation and the visualisation flags are not provided)
+    eval=False, eval_nocs=False,
     # config.py
     train=False, test=False, seed=0, ngpu=1, local_rank=0, num_workers=8, checkpoint_dir="log",
     name="exp", train_list="", test_list="", model_path="", vis_path="", total_iters=10000,

@@ -72,6 +72,31 @@ class Tester:
         pred_fit = self.fitter.pose_fitting(depth, mask, match, match_conf, foc_crop, pp_crop, pred_v)
         return pred, pred_fit
 
+    def test(self, loader=None, log=print):
+        """the loop of tester.py:126-203 for the NOCS-style pose metric: test_loader -> eval forward -> pose_fitting ->
+        degree / centimetre hits; returns {"5deg2cm": .., "5deg5cm": .., "10deg2cm": .., "10deg5cm": .., "n": ..} (fractions),
+        or only the predictions' count when opts.eval is off.  (3-D IoU rows of eval_nocs: see the module docstring.)"""
+        opts = self.opts
+        self.define_model()
+        if loader is None:
+            from .data import test_loader
+            loader, self.dataset = test_loader(opts, self.device)
+        self.deg_cm_result, n = [], 0
+        for i, batch in enumerate(loader):
+            self.model.iters = i
+            data = self.batch_reshape(batch)
+            pred, pred_fit = self.predict(data)
+            n += data[0].shape[0]
+            if opts.eval:
+                self.eval_deg_cm(pred_fit, (batch["rotation"], batch["translation"], batch["scale"]))
+        out = {"n": n}
+        if opts.eval and self.deg_cm_result:
+            hits = np.array(self.deg_cm_result) * 1.0
+            for j, (d, c) in enumerate(self.deg_cm_thresh):
+                out["%ddeg%dcm" % (d, c)] = hits[:, j].sum() / hits.shape[0]
+                log("%2ddeg*%dcm: %.4f" % (d, c, out["%ddeg%dcm" % (d, c)]))
+        return out
+
     def eval_deg_cm(self, pred_fit, gt):
         """tester.py:295-321 without the IoU rows: appends one [5deg2cm, 5deg5cm, 10deg2cm, 10deg5cm] hit list per image"""
         bbox, verts, rotation, translation = pred_fit

@@ -124,3 +124,40 @@ def test_trainer_train_loop_on_disk_dataset(tmp_path):
     tr2 = Trainer(Options("laptop_wild6d", batch_size=2, repeat=3, train=True, total_iters=4, model_path=ckpt),
                   prior=scenes.bottle_like(3), device="cuda")
     assert torch.equal(tr2.model.mesh.mean_v, tr.model.mesh.mean_v)
+
+
+def test_test_dataset_order_box_and_ground_truth(tmp_path):
+    """Wild6DTestDataset (dataset_wild6d_test.py): frames in order with stride dframe_eval, fixed 1.35x box, gt from the pkl"""
+    from scp_amd.data import Wild6DTestDataset
+    root, list_path = wild6d_synth.write_test_set(str(tmp_path))
+    o = types.SimpleNamespace(test_list=list_path, test_dataset_path=root, batch_size=2, img_size=64, use_depth=True, eval=True,
+                              dframe_eval=2, no_stretch=False, ngpu=1, local_rank=-1, num_workers=0, shuffle_test=False, test=True)
+    ds = Wild6DTestDataset(o)
+    assert ds.sample_list == [(0, 0), (0, 2), (1, 0), (1, 2)]
+    state = np.random.get_state()[1].copy()
+    e = ds[1]
+    assert np.array_equal(state, np.random.get_state()[1]), "the test item must not consume the numpy generator"
+    assert e["img"].shape == (3, 64, 64) and e["rotation"].shape == (3, 3) and e["scale"].shape == (3,)
+    assert int(e["idx"]) == 0 and int(e["frame_idx"]) == 2
+    raw = ds.raw_item(1)
+    ih, iw, pt, pl, vh, vw = raw["_crop"]["geom"]
+    assert (vh, vw) == (2 * int(e["length"][1]), 2 * int(e["length"][0])) and torch.equal(raw["rotation"], e["rotation"])
+
+
+@pytest.mark.gpu
+def test_tester_test_loop_on_disk_test_set(tmp_path):
+    """end to end: on-disk test set + pkl annotations -> test_loader -> Tester.test() -> pose metric table"""
+    import scenes
+    import scp_amd.dino as dino
+    from scp_amd.flags import Options
+    from scp_amd.tester import Tester
+    dino.ALLOW_RANDOM_INIT = True
+    root, list_path = wild6d_synth.write_test_set(str(tmp_path), n_frames=4, w=320, h=240)
+    opts = Options("laptop_wild6d", batch_size=4, repeat=1, train=False, test=True, eval=True, eval_nocs=True, test_dataset_path=root,
+                   test_list=list_path, num_workers=2, local_rank=-1, dframe_eval=1)
+    t = Tester(opts, prior=scenes.bottle_like(3))
+    torch.manual_seed(0)
+    lines = []
+    out = t.test(log=lines.append)
+    assert out["n"] == 8 and len(t.deg_cm_result) == 8 and len(lines) == 4
+    assert all(0.0 <= out[k] <= 1.0 for k in ("5deg2cm", "5deg5cm", "10deg2cm", "10deg5cm"))

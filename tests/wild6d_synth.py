@@ -40,3 +40,27 @@ def write_dataset(root, n_obj=2, n_seq=2, n_frames=6, w=160, h=120, seed=0):
     with open(list_path, "w") as f:
         f.write("\n".join(names) + "\n")
     return os.path.abspath(list_path)
+
+
+def write_test_set(base, category="laptop", n_obj=1, n_seq=2, n_frames=4, w=160, h=120, seed=3):
+    """the reference's test layout: <base>/test_set/<category>/<obj>/<seq>/... and
+    <base>/test_set/pkl_annotations/<category>/<category>-<obj>-<seq>.pkl with per-frame rotation / translation / size"""
+    import pickle
+    root = os.path.join(base, "test_set", category)
+    list_path = write_dataset(root, n_obj=n_obj, n_seq=n_seq, n_frames=n_frames, w=w, h=h, seed=seed)
+    rng = np.random.RandomState(seed + 1)
+    ann_dir = os.path.join(base, "test_set", "pkl_annotations", category)
+    os.makedirs(ann_dir, exist_ok=True)
+    for obj in sorted(os.listdir(root)):
+        for seq in sorted(os.listdir(os.path.join(root, obj))):
+            annos = []
+            for i in range(n_frames):
+                q, _ = np.linalg.qr(rng.randn(3, 3))
+                if np.linalg.det(q) < 0:
+                    q[:, 0] = -q[:, 0]
+                annos.append({"name": "%s/%s/%s/%d" % (category, obj, seq, i), "rotation": q.tolist(),
+                              "translation": (np.array([0.0, 0.0, 0.6]) + 0.02 * rng.randn(3)).tolist(),
+                              "size": (0.2 + 0.1 * rng.rand(3)).tolist()})
+            with open(os.path.join(ann_dir, "%s-%s-%s.pkl" % (category, obj, seq)), "wb") as f:
+                pickle.dump({"annotations": annos}, f)
+    return root + "/", list_path
