@@ -3,13 +3,13 @@
 Mirrors model/tester.py: `define_model` (:76-94), `batch_reshape` (:96-123, same NDC conversion as the trainer),
 the loop body of `test` (:178-183: `pred = model(data)`, `pred_fit = pose_fitting(data, pred)`), `pose_fitting`
 (:324-427, scp_amd.pose_fit) and the degree / centimetre part of `eval_nocs` (:295-321 with
-model/util/eval_utils.py:182-199 get_best_deg_cm).  The 3-D box IoU of eval_nocs goes through the vendored
-objectron package (third-party/objectron, CPU numpy polytope clipping) and the visualisation through cv2 /
-matplotlib: evaluation-harness code outside the GPU path, not rebuilt here."""
+model/util/eval_utils.py:182-199 get_best_deg_cm) and its 3-D IoU rows (scp_amd.eval_nocs: exact oriented-box IoU and the
+18-fold y-symmetry search of get_best_iou, pinned to the reference's values).  Not rebuilt: the cv2 / matplotlib
+visualisation and the CUB keypoint-transfer evaluation."""
 import numpy as np
 import torch
 
-from . import pose_fit
+from . import eval_nocs, pose_fit
 from .model import MeshNet
 from .trainer import Trainer, enable_gemm_tuning, freeze_batchnorm_affine
 
@@ -38,12 +38,13 @@ def get_best_deg_cm(symmetry_idx, box_vertices, box_rotation, rot_gt, trans_gt, 
 
 class Tester:
     deg_cm_thresh = [[5, 2], [5, 5], [10, 2], [10, 5]]                       # tester.py:154
+    iou_thresh = [0.25, 0.5]                                                  # tester.py:152
 
     def __init__(self, opts, prior=None, device=None):
         self.opts = opts
         self.device = torch.device(device if device is not None else "cuda")
         self.prior = prior
-        self.deg_cm_result = []
+        self.deg_cm_result, self.iou_result = [], []
 
     def define_model(self):
         torch.backends.cudnn.benchmark = True
@@ -81,7 +82,7 @@ class Tester:
         if loader is None:
             from .data import test_loader
             loader, self.dataset = test_loader(opts, self.device)
-        self.deg_cm_result, n = [], 0
+        self.deg_cm_result, self.iou_result, n = [], [], 0
         for i, batch in enumerate(loader):
             self.model.iters = i
             data = self.batch_reshape(batch)
@@ -95,6 +96,10 @@ class Tester:
             for j, (d, c) in enumerate(self.deg_cm_thresh):
                 out["%ddeg%dcm" % (d, c)] = hits[:, j].sum() / hits.shape[0]
                 log("%2ddeg*%dcm: %.4f" % (d, c, out["%ddeg%dcm" % (d, c)]))
+            ious = np.array(self.iou_result) * 1.0
+            for j, th in enumerate(self.iou_thresh):
+                out["iou@%d" % round(100 * th)] = ious[:, j].sum() / ious.shape[0]
+                log("iou@%d: %.4f" % (round(100 * th), out["iou@%d" % round(100 * th)]))
         return out
 
     def eval_deg_cm(self, pred_fit, gt):
@@ -109,5 +114,7 @@ class Tester:
             ang, cm = get_best_deg_cm(self.opts.symmetry_idx, bbox[i], rotation[i].T, rot_gt[i], trans_gt[i], scale_gt[i])
             hits = [bool(ang < d and cm < c) for d, c in self.deg_cm_thresh]
             self.deg_cm_result.append(hits)
+            iou = eval_nocs.get_best_iou(self.opts.symmetry_idx, bbox[i], rot_gt[i], trans_gt[i], scale_gt[i])
+            self.iou_result.append([bool(iou >= th) for th in self.iou_thresh])
             out.append((ang, cm))
         return out

@@ -458,6 +458,19 @@ def gen_posefit():
     # reference's own get_best_deg_cm and the vendored objectron Box (third-party/objectron/dataset/box.py)
     import model.util.eval_utils as ref_eval
     from objectron.dataset import box as ref_box
+    import sys as _sys
+
+    def _angle_axis_to_rotation_matrix(aa):      # kornia is absent: Rodrigues' formula, as published
+        out = []
+        for v in aa.double():
+            th = float(v.norm())
+            k = (v / th).numpy() if th > 1e-12 else np.zeros(3)
+            K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+            out.append(torch.tensor(np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)))
+        return torch.stack(out)
+
+    _sys.modules["kornia.geometry"].angle_axis_to_rotation_matrix = _angle_axis_to_rotation_matrix
+    ref_eval.kornia.geometry.angle_axis_to_rotation_matrix = _angle_axis_to_rotation_matrix
     g = torch.Generator().manual_seed(5)
     metric = {}
     bb = bbox.numpy()
@@ -475,6 +488,18 @@ def gen_posefit():
             ang, cm = ref_eval.get_best_deg_cm(sym, ref_box.Box(bb[i]), rot_gt, trans_gt, scale_gt)
             metric["gt%d_sym%d" % (i, sym)] = np.array([ang, cm])
         print("  deg/cm image %d:" % i, metric["gt%d_sym0" % i], metric["gt%d_sym1" % i])
+        # 3-D IoU (eval_utils.get_best_iou over objectron's exact IoU) against boxes of comparable size: the fitted box
+        # perturbed by a small rotation / shift / rescale, and a barely touching one
+        pred_box = ref_box.Box(bb[i].astype(np.float64))
+        for j, (ang, shift, resc) in enumerate(((0.15, 0.1, 1.1), (0.6, 0.35, 0.8), (0.0, 0.0, 1.0), (1.2, 1.5, 1.0))):
+            a = torch.randn(3, 3, generator=g)
+            rg = torch.linalg.matrix_exp(ang * (a - a.T)).double().numpy() @ pred_box.rotation
+            tg = pred_box.translation + shift * pred_box.scale.mean() * torch.randn(3, generator=g).numpy()
+            sg = pred_box.scale * resc
+            metric["iou%d_%d_rot" % (i, j)], metric["iou%d_%d_trans" % (i, j)], metric["iou%d_%d_scale" % (i, j)] = rg, tg, sg
+            vals = [ref_eval.get_best_iou(sym, pred_box, rg, tg, sg)[0] for sym in (0, 1)]
+            metric["iou%d_%d" % (i, j)] = np.array(vals)
+            print("  iou image %d case %d:" % (i, j), vals)
     save("posefit_metric", n=np.int64(bsz), bbox=bb, rotation=rotation.numpy(), **metric)
 
     # direct estimateSimilarityTransform cases at comparable source/target scale, where the pass threshold

@@ -159,5 +159,5 @@ def test_tester_test_loop_on_disk_test_set(tmp_path):
     torch.manual_seed(0)
     lines = []
     out = t.test(log=lines.append)
-    assert out["n"] == 8 and len(t.deg_cm_result) == 8 and len(lines) == 4
-    assert all(0.0 <= out[k] <= 1.0 for k in ("5deg2cm", "5deg5cm", "10deg2cm", "10deg5cm"))
+    assert out["n"] == 8 and len(t.deg_cm_result) == 8 and len(t.iou_result) == 8 and len(lines) == 6
+    assert all(0.0 <= out[k] <= 1.0 for k in ("5deg2cm", "5deg5cm", "10deg2cm", "10deg5cm", "iou@25", "iou@50"))

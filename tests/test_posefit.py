@@ -208,3 +208,33 @@ def test_deg_cm_metric_matches_reference():
             assert abs(cm - ref[1]) < 1e-6 * (1 + ref[1])
             # near 0 the unclipped arccos turns 1e-7 of rounding in the matrix into ~0.01 degrees (thresholds are 5 / 10)
             assert abs(ang - ref[0]) < 2e-2 + 1e-4 * ref[0], (i, sym, ang, ref[0])
+
+
+def test_box_iou_matches_reference():
+    """scp_amd.eval_nocs.get_best_iou vs eval_utils.get_best_iou over the vendored objectron exact IoU (recorded): partial
+    overlaps, identical boxes, disjoint boxes, with and without the 18-fold y-symmetry search"""
+    from scp_amd import eval_nocs
+    d = np.load(os.path.join(GOLD, "posefit_metric.npz"))
+    for i in range(int(d["n"])):
+        for j in range(4):
+            for k, sym in enumerate((0, 1)):
+                got = eval_nocs.get_best_iou(sym, d["bbox"][i].astype(np.float64), d["iou%d_%d_rot" % (i, j)],
+                                             d["iou%d_%d_trans" % (i, j)], d["iou%d_%d_scale" % (i, j)])
+                ref = float(d["iou%d_%d" % (i, j)][k])
+                assert abs(got - ref) < 2e-6 + 1e-5 * ref, (i, j, sym, got, ref)
+
+
+def test_box_iou_closed_forms():
+    from scp_amd import eval_nocs
+    a = eval_nocs.box_from_transformation(np.eye(3), np.zeros(3), np.array([2.0, 2.0, 2.0]))
+    b = eval_nocs.box_from_transformation(np.eye(3), np.array([1.0, 0.0, 0.0]), np.array([2.0, 2.0, 2.0]))
+    assert abs(eval_nocs.box_iou(a, b) - (4.0 / 12.0)) < 1e-12            # overlap 1x2x2 of two 8-volume cubes
+    c = eval_nocs.box_from_transformation(np.eye(3), np.array([3.0, 0.0, 0.0]), np.array([2.0, 2.0, 2.0]))
+    assert eval_nocs.box_iou(a, c) == 0.0
+    th = np.pi / 4
+    rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    r = eval_nocs.box_from_transformation(rz, np.zeros(3), np.array([2.0, 2.0, 2.0]))
+    inter = 2.0 * (8.0 * (np.sqrt(2.0) - 1.0))                            # regular octagon of the two squares x height 2
+    assert abs(eval_nocs.box_iou(a, r) - inter / (16.0 - inter)) < 1e-9
+    rot, trans, scale = eval_nocs.box_fit(r)
+    assert np.allclose(rot, rz) and np.allclose(scale, 2.0) and np.allclose(trans, 0.0)
