@@ -48,6 +48,9 @@ class _Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
 
     def forward(self, x):
+        if MIXED_BF16 and x.is_cuda:      # keep the hidden activation in bf16 between the two GEMMs (no fp32 round trip)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return self.fc2(F.gelu(self.fc1(x))).float()
         return _linear(self.fc2, F.gelu(_linear(self.fc1, x)))
 
 
