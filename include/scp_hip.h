@@ -222,6 +222,12 @@ size_t scp_mutual_argmax_workspace(int N, int Q);
 int scp_mutual_argmax(const float* scores, const float* rowmask, const float* colmask, int N, int P, int Q,
                       long long* col_index, long long* row_index, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- decoder upsampling backward ---------------------------------------------------------------------------
+ * Backward of `F.interpolate(x, size=(2H,2W), mode="bilinear", align_corners=False)` as used by ResNet_Decoder
+ * (model/module/network/image_encoder.py:141-193), NHWC fp32, exact factor two only:
+ *   grad_out [N,2H,2W,C] -> grad_in [N,H,W,C], C % 4 == 0.  Gather form, no atomics, deterministic. */
+int scp_upsample2x_bilinear_backward(const float* grad_out, float* grad_in, int N, int H, int W, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,27 @@ class _ConvUnit(nn.Module):
         return self.cbr_unit(x)
 
 
+class _Upsample2x(torch.autograd.Function):
+    """exact-2x bilinear upsampling, NHWC fp32: ATen forward, HIP gather backward (csrc/upsample.hip) instead of ATen's
+    atomicAdd scatter -- deterministic and ~5x faster at the decoder's sizes"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return F.interpolate(x, (x.shape[2] * 2, x.shape[3] * 2), mode="bilinear", align_corners=False)
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        from . import capi
+        n, c, h, w = ctx.shape
+        g = g if g.is_contiguous(memory_format=torch.channels_last) else g.contiguous(memory_format=torch.channels_last)
+        gin = torch.empty(ctx.shape, dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
+        capi.check(capi.lib().scp_upsample2x_bilinear_backward(ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(gin.data_ptr()),
+                                                               n, h, w, c, capi.current_stream()), "upsample2x_bilinear_backward")
+        return gin
+
+
 class ResNet_Decoder(nn.Module):
     def __init__(self, is_proj=True, out_channel=64, downsample=4):
         super().__init__()
@@ -99,6 +120,10 @@ class ResNet_Decoder(nn.Module):
 
     @staticmethod
     def _up(x, like):
+        h, w = like.shape[2:]
+        if (x.is_cuda and x.dtype == torch.float32 and x.shape[2] * 2 == h and x.shape[3] * 2 == w and x.shape[1] % 4 == 0
+                and x.is_contiguous(memory_format=torch.channels_last)):
+            return _Upsample2x.apply(x)
         return F.interpolate(x, like.shape[2:], mode="bilinear", align_corners=False)
 
     def forward(self, c2, c3, c4, c5):

@@ -97,3 +97,23 @@ def test_bn_act_full_size_vs_miopen():
     xa.grad = None
     fused_bn.bn_act(xa, bn_a, relu=True).backward(dy)
     assert bn_a.weight.grad is not None and xa.grad is not None   # old .grad kept, new dx produced
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 8, 1, 1), (3, 16, 5, 7), (2, 128, 32, 32), (1, 4, 2, 9)])
+def test_upsample2x_backward_matches_float64_autograd(shape):
+    """decoder upsampling: HIP gather backward vs the float64 CPU autograd of F.interpolate (borders, odd sizes, 1x1)"""
+    from scp_amd.nets import ResNet_Decoder, _Upsample2x
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g)
+    n, c, h, w = shape
+    dy = torch.randn(n, c, 2 * h, 2 * w, generator=g)
+    xr = x.double().requires_grad_(True)
+    torch.nn.functional.interpolate(xr, (2 * h, 2 * w), mode="bilinear", align_corners=False).backward(dy.double())
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    like = torch.empty(n, c, 2 * h, 2 * w, device="cuda")
+    y = ResNet_Decoder._up(xg, like)
+    assert y.grad_fn is not None and "Upsample2x" in type(y.grad_fn).__name__
+    y.backward(dy.cuda())
+    assert (xg.grad.double().cpu() - xr.grad).abs().max().item() < 1e-5
+    assert torch.allclose(y.detach().cpu().double(), torch.nn.functional.interpolate(x.double(), (2 * h, 2 * w), mode="bilinear", align_corners=False), atol=1e-6)
