@@ -57,8 +57,13 @@ class Correspondence:
         return pointcorr, match, imatch, match_conf
 
     def half_grid(self, bsz):
-        grid = self.meshgrid.reshape(2, self.hf, self.wf)[None].expand(bsz, -1, -1, -1)
-        return F.interpolate(grid, (self.hf // 2, self.wf // 2), mode="bilinear")
+        """the constant pixel grid at half resolution (correspondence.py:84-86): interpolated once per device, expanded"""
+        key = (self.meshgrid.device, self.meshgrid.data_ptr())
+        if getattr(self, "_half_grid_key", None) != key:
+            self._half_grid = F.interpolate(self.meshgrid.reshape(2, self.hf, self.wf)[None], (self.hf // 2, self.wf // 2),
+                                            mode="bilinear")
+            self._half_grid_key = key
+        return self._half_grid.expand(bsz, -1, -1, -1)
 
     def compute_rotation_cycle_loss(self, src_img, src_mask, src_img_feat, encoder, angle=None):
         """`angle` pins the random rotation (tests); None draws U(0,360) from the host RNG"""
@@ -70,7 +75,8 @@ class Correspondence:
         src_mask = src_mask[:, None]
         tgt_img = imgops.rotate(src_img, angle, "bilinear")
         tgt_mask = imgops.rotate(src_mask, angle, "nearest")
-        cycle_match_gt = imgops.rotate(grid, angle, "nearest").reshape(bsz, 2, -1)
+        # every image gets the same rotation of the same grid: rotate one copy
+        cycle_match_gt = imgops.rotate(grid[:1], angle, "nearest").expand(bsz, -1, -1, -1).reshape(bsz, 2, -1)
 
         _, tgt_feat = encoder.encode_img(tgt_img)                                   # b,c,hf*wf (unit norm)
         src_mask_down = F.interpolate(src_mask, (hh, wh), mode="nearest").reshape(bsz, -1)

@@ -41,8 +41,14 @@ class PretrainedCorrespondence(nn.Module):
         self.last_nn = None
 
     def half_grid(self, bsz):
-        grid = self.meshgrid.reshape(2, self.hf, self.wf)[None].expand(bsz, -1, -1, -1)
-        return F.interpolate(grid, (self.hf // 2, self.wf // 2), mode="bilinear")
+        """the pixel grid at half the correspondence resolution (pretrained_corr.py:112-114 interpolates the constant
+        meshgrid for every pair of every step): computed once per device and expanded"""
+        key = (self.meshgrid.device, self.meshgrid.data_ptr())
+        if getattr(self, "_half_grid_key", None) != key:
+            grid = self.meshgrid.reshape(2, self.hf, self.wf)[None]
+            self._half_grid = F.interpolate(grid, (self.hf // 2, self.wf // 2), mode="bilinear")
+            self._half_grid_key = key
+        return self._half_grid.expand(bsz, -1, -1, -1)
 
     # -- reference signature: images in, DINO inside --------------------------------------------
     def match(self, src_img, tgt_img, src_mask, tgt_mask, grid):
