@@ -228,6 +228,11 @@ int scp_mutual_argmax(const float* scores, const float* rowmask, const float* co
  *   grad_out [N,2H,2W,C] -> grad_in [N,H,W,C], C % 4 == 0.  Gather form, no atomics, deterministic. */
 int scp_upsample2x_bilinear_backward(const float* grad_out, float* grad_in, int N, int H, int W, int C, void* stream);
 
+/* ---- ViT attention, BASELINE configs[4] precision (mixed bf16) ---------------------------------------------------
+ * Same operator and layouts as scp_vit_attention_forward with bf16 storage: qkv [B,N,3,H,64] bf16 (the output of the bf16
+ * qkv GEMM), out [B,N,H*64] bf16; products on the bf16 matrix cores with fp32 accumulation, softmax statistics in fp32. */
+int scp_vit_attention_bf16_forward(const void* qkv, void* out, int B, int N, int H, int head_dim, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

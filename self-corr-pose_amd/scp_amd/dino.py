@@ -64,6 +64,10 @@ class _Attention(nn.Module):
 
     def forward(self, x):
         b, n, c = x.shape
+        if MIXED_BF16 and x.is_cuda:   # qkv GEMM -> bf16 attention -> proj GEMM without leaving bf16
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = fused_attention_bf16(self.qkv(x), b, n, self.num_heads, c // self.num_heads, self.scale)
+                return self.proj(y).float()
         y = fused_attention(_linear(self.qkv, x), b, n, self.num_heads, c // self.num_heads, self.scale)   # [b,n,c]
         return _linear(self.proj, y)
 
@@ -86,6 +90,22 @@ def fused_attention(qkv, b, n, heads, head_dim, scale):
     code = capi.lib().scp_vit_attention_forward(capi.dev_ptr(qkv, "qkv"), capi.dev_ptr(out, "out"), b, n, heads,
                                                 head_dim, float(scale), capi.current_stream())
     capi.check(code, "scp_vit_attention_forward")
+    return out
+
+
+def fused_attention_bf16(qkv, b, n, heads, head_dim, scale):
+    """configs[4] precision: bf16 qkv [b,n,3*heads*head_dim] (straight from the bf16 qkv GEMM) -> bf16 [b,n,heads*head_dim]
+    on the bf16 matrix cores, fp32 softmax statistics (csrc/vit_attn_bf16.hip).  Forward only, GPU only."""
+    import ctypes
+    from . import capi
+    if torch.is_grad_enabled() and qkv.requires_grad:
+        raise RuntimeError("scp_amd.dino.fused_attention_bf16 is forward-only (frozen ViT)")
+    if not qkv.is_cuda or qkv.dtype != torch.bfloat16:
+        raise RuntimeError("fused_attention_bf16 expects a CUDA bfloat16 tensor")
+    qkv = qkv.contiguous()
+    out = torch.empty(b, n, heads * head_dim, dtype=torch.bfloat16, device=qkv.device)
+    capi.check(capi.lib().scp_vit_attention_bf16_forward(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(out.data_ptr()), b, n, heads,
+                                                         head_dim, float(scale), capi.current_stream()), "scp_vit_attention_bf16_forward")
     return out
 
 

@@ -103,3 +103,21 @@ def test_dino_features_match_reference_fixture():
     np.testing.assert_allclose(feat[:, ::8, ::4, ::4].numpy(), d["dino_feat_sub"], rtol=1e-3, atol=2e-3)
     st = step_case.stats(feat)
     np.testing.assert_allclose(st[1:], d["dino_feat_stats"][1:], rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,H", [(2, 1025, 6), (1, 64, 1), (3, 100, 2), (1, 33, 6), (2, 4097, 6)])
+def test_bf16_attention_vs_fp32_oracle(B, N, H):
+    """configs[4] kernel: bf16 attention vs the fp32 oracle evaluated on the same (bf16-rounded) q/k/v.  bf16 output keeps 8
+    mantissa bits and P is rounded to bf16 before P.V, so this is a band (1e-2 of the output scale), not fp32 parity."""
+    from oracle import vit as oracle_vit
+    from scp_amd import dino
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    qkv = (torch.randn(B, N, 3 * H * 64, generator=g) * 1.5).to(torch.bfloat16)
+    ref = oracle_vit.attention_oracle(qkv.float(), H, 0.125)
+    out = dino.fused_attention_bf16(qkv.cuda(), B, N, H, 64, 0.125).float().cpu()
+    scale = ref.abs().max().item()
+    err = (out - ref).abs()
+    assert err.max().item() < 1.5e-2 * scale, err.max().item() / scale
+    assert err.mean().item() < 2e-3 * scale
+    assert torch.isfinite(out).all()

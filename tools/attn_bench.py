@@ -39,3 +39,15 @@ print("hip attention %.3f ms = %.1f TFLOP/s (%.1f%% of 157.3)   torch sdpa %.3f 
 
 if "--ablate" in sys.argv:
     print("see tools/attn_probe.py (interleaved timing under the kernel's debug switches)")
+
+if "--bf16" in sys.argv:
+    from scp_amd.dino import fused_attention_bf16
+    qb = qkv.to(torch.bfloat16)
+
+    def sdpa_bf16():
+        q, k, v = qb.reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+        return F.scaled_dot_product_attention(q, k, v, scale=0.125).transpose(1, 2).reshape(B, N, H * 64)
+
+    t3, t4 = timeit(lambda: fused_attention_bf16(qb, B, N, H, 64, 0.125)), timeit(sdpa_bf16)
+    print("hip bf16 attention %.3f ms = %.1f TFLOP/s   torch sdpa bf16 %.3f ms = %.1f TFLOP/s   max|diff| %.2e" % (
+        t3, flop / t3 / 1e9, t4, flop / t4 / 1e9, (fused_attention_bf16(qb, B, N, H, 64, 0.125).float() - sdpa_bf16().float()).abs().max().item()))
