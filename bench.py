@@ -187,8 +187,8 @@ def bench_posefit(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mixed-bf16", action="store_true",
                     help="BASELINE configs[4] precision (bf16 convolutions / ViT linears, fp32 elsewhere); NOT the headline")
