@@ -33,6 +33,14 @@
 
 namespace {
 
+// Division inside pure GRADIENT arithmetic (never in a coverage / clipping decision): SCP_FAST_GRAD_DIV selects v_rcp_f32 * x
+// (1-2 ulp) instead of the IEEE sequence (~10 instructions); off by default, the oracle comparison then holds to the last bit
+#ifdef SCP_FAST_GRAD_DIV
+#define GDIV(x, y) ((x) * __builtin_amdgcn_rcpf(y))
+#else
+#define GDIV(x, y) ((x) / (y))
+#endif
+
 constexpr int TILE = 16;        // pixels per tile edge
 constexpr int THREADS = 256;    // 4 wavefronts
 constexpr int NB = 32;          // faces staged per round
@@ -595,8 +603,8 @@ __global__ __launch_bounds__(THREADS) void raster_backward_kernel(const RasterAr
                                 }
                             } else if (front_facing(v) || a.double_side) {
                                 float c_rgb = 0.f;
-                                const float zn = (a.far_ - zp) / (a.far_ - a.near_);
-                                const float zs = cv.frag * expf((zn - sm_max) / a.gamma) / sm_sum;
+                                const float zn = GDIV(a.far_ - zp, a.far_ - a.near_);
+                                const float zs = GDIV(cv.frag * expf(GDIV(zn - sm_max, a.gamma)), sm_sum);
                                 int texel = 0;
                                 if (SAMPLE == SCP_SAMPLE_SURFACE) texel = surface_texel(w, a.R);
 #pragma unroll
@@ -612,14 +620,14 @@ __global__ __launch_bounds__(THREADS) void raster_backward_kernel(const RasterAr
                                     c_rgb += gk * (ck - img[k]);
                                 }
                                 c_rgb *= zs;
-                                c_xy += c_rgb / cv.frag;
-                                const float c_z = c_rgb / a.gamma / (a.near_ - a.far_) * zp * zp;
-                                g[2] = c_z * w[0] / v[2] / v[2];
-                                g[5] = c_z * w[1] / v[5] / v[5];
-                                g[8] = c_z * w[2] / v[8] / v[8];
+                                c_xy += GDIV(c_rgb, cv.frag);
+                                const float c_z = GDIV(GDIV(c_rgb, a.gamma), a.near_ - a.far_) * zp * zp;
+                                g[2] = GDIV(GDIV(c_z * w[0], v[2]), v[2]);
+                                g[5] = GDIV(GDIV(c_z * w[1], v[5]), v[5]);
+                                g[8] = GDIV(GDIV(c_z * w[2], v[8]), v[8]);
                             }
 
-                            c_xy *= cv.frag * (1 - cv.frag) / a.sigma;
+                            c_xy *= GDIV(cv.frag * (1 - cv.frag), a.sigma);
                             if (a.dist_mode == SCP_DIST_EUCLIDEAN) {
 #pragma unroll
                                 for (int k = 0; k < 3; k++) {
