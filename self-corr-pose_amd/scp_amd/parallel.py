@@ -7,9 +7,12 @@ calls the bare module, so its reducer never fires; north_star asks f
 which is what this does.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU), ring all-reduce is per-link bound, so the
-gradients are coalesced into a few large flat buckets (default 32 MiB: 2 buckets for this model)
-instead of many small messages; the buckets are reduced asynchronously and waited for together.
+gradients travel as ONE large message: the trainer flattens them into a persistent buffer (stable device
+address for the collective) and `all_reduce_flat` reduces it with a single call on the current stream.
+`all_reduce()` (bucketed, tolerant of parameters without a gradient on some rank) is the general form.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -36,16 +39,14 @@ class GradientAllReducer:
         for p in self.params:
             dist.broadcast(p.data, src, group=self.group)
 
-    def all_reduce_flat(self, flat, chunk_bytes=32 << 20):
-        """average an already flattened gradient buffer in place: a few large asynchronous all-reduces
-        (xGMI ring all-reduce is per-link bound -> large messages), waited together.  Ranks must pass
-        buffers of equal length (parameters without a gradient on some rank: use all_reduce())."""
-        if self.world == 1:
+    def all_reduce_flat(self, flat):
+        """average an already flattened gradient buffer in place with ONE collective over the whole buffer (~58 MB fp32 for
+        this model: xGMI ring all-reduce is per-link bound, so one large message beats several small ones).  Enqueued on the
+        current stream (RCCL) -- no host synchronisation.  Ranks must pass buffers of equal length (parameters without a
+        gradient on some rank: use all_reduce())."""
+        if self.world == 1 or os.environ.get("SCP_DEBUG_SKIP_ALLREDUCE") == "1":
             return flat
-        n = max(1, chunk_bytes // flat.element_size())
-        work = [dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for c in flat.split(n)]
-        for w in work:
-            w.wait()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat.div_(self.world)
         return flat
 

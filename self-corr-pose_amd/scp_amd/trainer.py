@@ -106,7 +106,14 @@ class Trainer:
             return z, z, z
         grads = [p.grad for p in params]
         sizes = [g.numel() for g in grads]
-        flat = torch.cat([g.reshape(-1) for g in grads])
+        # one PERSISTENT flat buffer: the collective sees the same device address every step (no per-step registration /
+        # staging allocation inside the communication library -- gloo allocated pinned staging per new tensor and took
+        # seconds per step when two ranks shared a device; RCCL likewise prefers stable user buffers)
+        total = sum(sizes)
+        buf = getattr(self, "_flat_grad", None)
+        if buf is None or buf.numel() != total or buf.device != grads[0].device:
+            buf = self._flat_grad = torch.empty(total, dtype=grads[0].dtype, device=grads[0].device)
+        flat = torch.cat([g.reshape(-1) for g in grads], out=buf)
         if self.reducer is not None:
             self.reducer.all_reduce_flat(flat)
         finite = torch.isfinite(flat).all()
