@@ -239,14 +239,23 @@ class GpuCollator:
     staging buffer (grown on demand, reused), one descriptor upload, one launch; everything is queued on the current
     stream.  No CPU fallback: without libscp_hip.so this raises."""
 
+    RING = 3   # staging buffers in flight: the host fills buffer k+1 while the copy engine still reads buffer k
+
     def __init__(self, img_size, device="cuda", use_depth=True):
         self.size, self.device, self.use_depth = img_size, torch.device(device), use_depth
-        self._stage = None
+        self._ring = [[None, None] for _ in range(self.RING)]      # [pinned buffer, event recorded after its H2D copy]
+        self._next = 0
 
     def _staging(self, nbytes):
-        if self._stage is None or self._stage.numel() < nbytes:
-            self._stage = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory()
-        return self._stage
+        """a pinned staging buffer that no asynchronous copy is still reading: the copy is enqueued with non_blocking=True,
+        so the buffer may only be refilled once the event recorded behind that copy has completed"""
+        slot = self._ring[self._next]
+        self._next = (self._next + 1) % self.RING
+        if slot[1] is not None:
+            slot[1].synchronize()
+        if slot[0] is None or slot[0].numel() < nbytes:
+            slot[0] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+        return slot
 
     def __call__(self, items):
         L = capi.lib()
@@ -268,7 +277,8 @@ class GpuCollator:
             off = (off + 15) & ~15
             plan.append((d.img_off, d.mask_off, d.depth_off, c))
         desc_bytes = ctypes.sizeof(capi.CropDesc) * B
-        stage = self._staging(off + desc_bytes)
+        slot = self._staging(off + desc_bytes)
+        stage = slot[0]
         flat = stage.numpy()
         for img_off, mask_off, depth_off, c in plan:
             flat[img_off:img_off + c["img"].size] = c["img"].reshape(-1)
@@ -277,6 +287,8 @@ class GpuCollator:
                 flat[depth_off:depth_off + c["depth"].size * 2] = c["depth"].reshape(-1).view(np.uint8)
         flat[off:off + desc_bytes] = np.frombuffer(bytes(descs), dtype=np.uint8)
         dev_buf = stage[:off + desc_bytes].to(self.device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(self.device))
         img = torch.empty(B, 3, S, S, dtype=torch.float32, device=self.device)
         mask = torch.empty(B, 1, S, S, dtype=torch.float32, device=self.device)
         depth = torch.empty(B, 1, S, S, dtype=torch.float32, device=self.device) if self.use_depth else None

@@ -161,3 +161,27 @@ def test_tester_test_loop_on_disk_test_set(tmp_path):
     out = t.test(log=lines.append)
     assert out["n"] == 8 and len(t.deg_cm_result) == 8 and len(t.iou_result) == 8 and len(lines) == 6
     assert all(0.0 <= out[k] <= 1.0 for k in ("5deg2cm", "5deg5cm", "10deg2cm", "10deg5cm", "iou@25", "iou@50"))
+
+
+@pytest.mark.gpu
+def test_collator_staging_is_not_reused_while_a_copy_is_in_flight(tmp_path):
+    """many batches collated back to back with a busy device: every batch must still equal a fresh collation of the same
+    items (the pinned staging ring may only be refilled behind the event of the copy that read it)"""
+    from scp_amd.data import GpuCollator
+    ds = _dataset(tmp_path)
+    np.random.seed(12)
+    raws = [ds.raw_item(i) for i in range(len(ds))]
+    groups = [raws[i:i + 6] for i in range(0, 24, 6)]
+    ref = [GpuCollator(64, "cuda", True)(g)["img"].clone() for g in groups]
+    torch.cuda.synchronize()
+    col = GpuCollator(64, "cuda", True)
+    busy = torch.randn(4096, 4096, device="cuda")
+    outs = []
+    for rep in range(6):
+        for _ in range(3):
+            busy = busy @ busy * 1e-3          # keep the stream behind the host
+        for g in groups:
+            outs.append(col(g)["img"])
+    torch.cuda.synchronize()
+    for k, o in enumerate(outs):
+        assert torch.equal(o, ref[k % 4]), k
