@@ -227,6 +227,8 @@ int scp_mutual_argmax(const float* scores, const float* rowmask, const float* co
  * (model/module/network/image_encoder.py:141-193), NHWC fp32, exact factor two only:
  *   grad_out [N,2H,2W,C] -> grad_in [N,H,W,C], C % 4 == 0.  Gather form, no atomics, deterministic. */
 int scp_upsample2x_bilinear_backward(const float* grad_out, float* grad_in, int N, int H, int W, int C, void* stream);
+/* same with bf16 storage (configs[4] precision; accumulation in fp32) */
+int scp_upsample2x_bilinear_backward_bf16(const void* grad_out, void* grad_in, int N, int H, int W, int C, void* stream);
 
 /* ---- ViT attention, BASELINE configs[4] precision (mixed bf16) ---------------------------------------------------
  * Same operator and layouts as scp_vit_attention_forward with bf16 storage: qkv [B,N,3,H,64] bf16 (the output of the bf16

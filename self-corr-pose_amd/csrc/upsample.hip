@@ -27,7 +27,21 @@ __device__ __forceinline__ int taps(int i, int n, int idx[4], float w[4]) {
     return c;
 }
 
-__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gin, int N,
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load4(const float* p, size_t quad) { return reinterpret_cast<const float4*>(p)[quad]; }
+__device__ __forceinline__ float4 load4(const __bf16* p, size_t quad) {
+    const bf16x4 v = reinterpret_cast<const bf16x4*>(p)[quad];
+    return float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void store4(float* p, size_t quad, float4 v) { reinterpret_cast<float4*>(p)[quad] = v; }
+__device__ __forceinline__ void store4(__bf16* p, size_t quad, float4 v) {
+    bf16x4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    reinterpret_cast<bf16x4*>(p)[quad] = o;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ gout, T* __restrict__ gin, int N,
                                                              int H, int W, int C4) {
     const long id = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)N * H * W * C4;
@@ -42,27 +56,38 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
     float wy[4], wx[4];
     const int ny = taps(y, H, iy, wy), nx = taps(x, W, ix, wx);
     const int OW = 2 * W;
-    const float4* src = reinterpret_cast<const float4*>(gout) + (size_t)n * (2 * H) * OW * C4 + c4;
+    const size_t src = (size_t)n * (2 * H) * OW * C4 + c4;
     float4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int a = 0; a < ny; a++) {
         float4 row = {0.f, 0.f, 0.f, 0.f};
         for (int b = 0; b < nx; b++) {
-            const float4 v = src[((size_t)iy[a] * OW + ix[b]) * C4];
+            const float4 v = load4(gout, src + ((size_t)iy[a] * OW + ix[b]) * C4);
             row.x += wx[b] * v.x; row.y += wx[b] * v.y; row.z += wx[b] * v.z; row.w += wx[b] * v.w;
         }
         acc.x += wy[a] * row.x; acc.y += wy[a] * row.y; acc.z += wy[a] * row.z; acc.w += wy[a] * row.w;
     }
-    reinterpret_cast<float4*>(gin)[id] = acc;
+    store4(gin, (size_t)id, acc);
 }
 
 }  // namespace
 
-extern "C" int scp_upsample2x_bilinear_backward(const float* grad_out, float* grad_in, int N, int H, int W, int C, void* stream) {
+namespace {
+template <typename T>
+int launch_upsample_bwd(const void* grad_out, void* grad_in, int N, int H, int W, int C, void* stream) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return scp::fail(hipErrorInvalidValue, "upsample2x_backward: empty problem");
     if (C % 4 != 0) return scp::fail(hipErrorInvalidValue, "upsample2x_backward: C must be a multiple of 4");
     if (!grad_out || !grad_in) return scp::fail(hipErrorInvalidValue, "upsample2x_backward: null argument");
     const long total = (long)N * H * W * (C / 4);
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       grad_out, grad_in, N, H, W, C / 4);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const T*>(grad_out), static_cast<T*>(grad_in), N, H, W, C / 4);
     return scp::check_launch("upsample2x_backward");
+}
+}  // namespace
+
+extern "C" int scp_upsample2x_bilinear_backward(const float* grad_out, float* grad_in, int N, int H, int W, int C, void* stream) {
+    return launch_upsample_bwd<float>(grad_out, grad_in, N, H, W, C, stream);
+}
+
+extern "C" int scp_upsample2x_bilinear_backward_bf16(const void* grad_out, void* grad_in, int N, int H, int W, int C, void* stream) {
+    return launch_upsample_bwd<__bf16>(grad_out, grad_in, N, H, W, C, stream);
 }

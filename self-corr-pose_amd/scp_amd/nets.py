@@ -88,7 +88,7 @@ class _ConvUnit(nn.Module):
 
 
 class _Upsample2x(torch.autograd.Function):
-    """exact-2x bilinear upsampling, NHWC fp32: ATen forward, HIP gather backward (csrc/upsample.hip) instead of ATen's
+    """exact-2x bilinear upsampling, NHWC fp32 (or bf16 in configs[4] precision): ATen forward, HIP gather backward (csrc/upsample.hip) instead of ATen's
     atomicAdd scatter -- deterministic and ~5x faster at the decoder's sizes"""
 
     @staticmethod
@@ -102,9 +102,10 @@ class _Upsample2x(torch.autograd.Function):
         from . import capi
         n, c, h, w = ctx.shape
         g = g if g.is_contiguous(memory_format=torch.channels_last) else g.contiguous(memory_format=torch.channels_last)
-        gin = torch.empty(ctx.shape, dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
-        capi.check(capi.lib().scp_upsample2x_bilinear_backward(ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(gin.data_ptr()),
-                                                               n, h, w, c, capi.current_stream()), "upsample2x_bilinear_backward")
+        gin = torch.empty(ctx.shape, dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
+        fn = capi.lib().scp_upsample2x_bilinear_backward if g.dtype == torch.float32 else capi.lib().scp_upsample2x_bilinear_backward_bf16
+        capi.check(fn(ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(gin.data_ptr()), n, h, w, c, capi.current_stream()),
+                   "upsample2x_bilinear_backward")
         return gin
 
 
@@ -121,7 +122,7 @@ class ResNet_Decoder(nn.Module):
     @staticmethod
     def _up(x, like):
         h, w = like.shape[2:]
-        if (x.is_cuda and x.dtype == torch.float32 and x.shape[2] * 2 == h and x.shape[3] * 2 == w and x.shape[1] % 4 == 0
+        if (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[2] * 2 == h and x.shape[3] * 2 == w and x.shape[1] % 4 == 0
                 and x.is_contiguous(memory_format=torch.channels_last)):
             return _Upsample2x.apply(x)
         return F.interpolate(x, like.shape[2:], mode="bilinear", align_corners=False)

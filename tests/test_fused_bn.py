@@ -117,3 +117,19 @@ def test_upsample2x_backward_matches_float64_autograd(shape):
     y.backward(dy.cuda())
     assert (xg.grad.double().cpu() - xr.grad).abs().max().item() < 1e-5
     assert torch.allclose(y.detach().cpu().double(), torch.nn.functional.interpolate(x.double(), (2 * h, 2 * w), mode="bilinear", align_corners=False), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_upsample2x_backward_bf16():
+    from scp_amd.nets import ResNet_Decoder
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 64, 9, 11, generator=g)
+    dy = torch.randn(4, 64, 18, 22, generator=g)
+    xr = x.double().requires_grad_(True)
+    torch.nn.functional.interpolate(xr, (18, 22), mode="bilinear", align_corners=False).backward(dy.to(torch.bfloat16).double())
+    xg = x.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ResNet_Decoder._up(xg, torch.empty(4, 64, 18, 22, device="cuda"))
+    assert "Upsample2x" in type(y.grad_fn).__name__ and y.dtype == torch.bfloat16
+    y.backward(dy.cuda().to(torch.bfloat16))
+    assert xg.grad.dtype == torch.bfloat16
+    assert (xg.grad.double().cpu() - xr.grad).abs().max().item() < 2e-2 * (1 + xr.grad.abs().max().item())

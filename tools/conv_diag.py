@@ -14,7 +14,7 @@ from scp_amd.encoder import Encoder  # noqa: E402
 
 variant = sys.argv[1] if len(sys.argv) > 1 else "default"
 torch.backends.cudnn.benchmark = "bench" in variant
-opts = Options("laptop_wild6d", batch_size=8, repeat=4, train=True)
+opts = Options("laptop_wild6d", batch_size=8, repeat=4, train=True, mixed_bf16="bf16" in variant)
 torch.manual_seed(0)
 enc = Encoder(opts).cuda().train()
 NB = int(os.environ.get("NB", "32"))
@@ -25,8 +25,7 @@ if "cl" in variant:
 
 
 def step():
-    with torch.autocast("cuda", dtype=torch.bfloat16, enabled="bf16" in variant):
-        code, feat = enc.encode_img(x)
+    code, feat = enc.encode_img(x)          # "bf16" variants: opts.mixed_bf16 (the encoder applies its own autocast)
     (feat.float().square().mean() + code.float().mean()).backward()
 
 
