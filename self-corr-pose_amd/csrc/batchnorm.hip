@@ -47,6 +47,17 @@ Geometry geometry(long R, int C) {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// bf16 storage (BASELINE configs[4] precision): 4 values = 8 bytes, arithmetic and statistics stay fp32
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const __bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void st4(__bf16* p, float4 v) {
+    bf16x4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
 __device__ __forceinline__ float bn_apply(float x, float scale, float shift) { return fmaf(x, scale, shift); }
 
 // folds the row lanes of a block in a fixed order and stores the block's partial for 4 channels
@@ -68,7 +79,8 @@ __device__ __forceinline__ void fold_rows(float4 a, float4 b, int tc_n, int ri_n
     }
 }
 
-__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const float* __restrict__ x, long R, int C, int tc_n,
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restrict__ x, long R, int C, int tc_n,
                                                               int rows_per_block, float* __restrict__ psum,
                                                               float* __restrict__ psq) {
     __shared__ float4 lds[2 * BN_THREADS];
@@ -144,12 +156,12 @@ __global__ void bn_finalize_kernel(const float* __restrict__ psum, const float* 
     shift_out[c] = b - mean * scale;
 }
 
-template <bool SKIP, bool RELU>
-__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float* __restrict__ x,
-                                                              const float* __restrict__ skip, long quads, int tc_n,
+template <typename T, bool SKIP, bool RELU>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restrict__ x,
+                                                              const T* __restrict__ skip, long quads, int tc_n,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
-                                                              float* __restrict__ y) {
+                                                              T* __restrict__ y) {
     const long i = (long)blockIdx.x * BN_THREADS + threadIdx.x;
     if (i >= quads) return;
     const int tc = (int)(i % tc_n);
@@ -166,11 +178,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float* __res
 }
 
 // MODE 0: no activation; 1: ReLU, mask recomputed from x; 2: ReLU, mask from the saved output (residual), g written
-template <int MODE>
+template <typename T, int MODE>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
-    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y, long R, int C, int tc_n,
+    const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y, long R, int C, int tc_n,
     int rows_per_block, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ g_out,
+    const float* __restrict__ scale, const float* __restrict__ shift, T* __restrict__ g_out,
     float* __restrict__ pg, float* __restrict__ pgx) {
     __shared__ float4 lds[2 * BN_THREADS];
     const int ri_n = BN_THREADS / tc_n;
@@ -220,15 +232,15 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ pg, const float
     c2[c] = training ? (float)(q / (double)R) : 0.f;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const float* __restrict__ dy,
-                                                               const float* __restrict__ x, long quads, int tc_n,
+template <typename T, int MODE>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T* __restrict__ dy,
+                                                               const T* __restrict__ x, long quads, int tc_n,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ invstd,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ shift,
                                                                const float* __restrict__ c1,
-                                                               const float* __restrict__ c2, float* __restrict__ dx) {
+                                                               const float* __restrict__ c2, T* __restrict__ dx) {
     const long i = (long)blockIdx.x * BN_THREADS + threadIdx.x;
     if (i >= quads) return;
     const int tc = (int)(i % tc_n);
@@ -260,11 +272,13 @@ extern "C" size_t scp_batchnorm_workspace(long R, int C) {
     return ((size_t)2 * geometry(R, C).blocks * C + (size_t)4 * C) * sizeof(float);
 }
 
-extern "C" int scp_batchnorm_act_forward(const float* x, const float* skip, const float* gamma, const float* beta,
-                                         float* running_mean, float* running_var, long long* batches_tracked,
-                                         float momentum, float eps, long R, int C, int relu, int training, float* y,
-                                         float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
-                                         void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+
+template <typename T>
+int bn_forward_impl(const T* x, const T* skip, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    long long* batches_tracked, float momentum, float eps, long R, int C, int relu, int training, T* y,
+                    float* save_mean, float* save_invstd, float* save_scale, float* save_shift, void* workspace,
+                    size_t workspace_bytes, void* stream) {
     if (bad_shape(R, C)) return scp::fail(hipErrorInvalidValue, "batchnorm: C must be a power of two in [16,1024], R > 0");
     if (!x || !y || !save_mean || !save_invstd || !save_scale || !save_shift)
         return scp::fail(hipErrorInvalidValue, "batchnorm: null argument");
@@ -276,18 +290,17 @@ extern "C" int scp_batchnorm_act_forward(const float* x, const float* skip, cons
     float* psum = static_cast<float*>(workspace);
     float* psq = psum + (size_t)g.blocks * C;
     if (training) {
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(g.blocks), dim3(BN_THREADS), 0, st, x, R, C, g.tc, g.rows_per_block,
-                           psum, psq);
+        hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(g.blocks), dim3(BN_THREADS), 0, st, x, R, C, g.tc, g.rows_per_block, psum, psq);
         if (int e = scp::check_launch("batchnorm stats")) return e;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, psum, psq, g.blocks, R, C, gamma, beta,
-                       running_mean, running_var, batches_tracked, momentum, eps, training, save_mean, save_invstd,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, psum, psq, g.blocks, R, C,
+                       gamma, beta, running_mean, running_var, batches_tracked, momentum, eps, training, save_mean, save_invstd,
                        save_scale, save_shift);
     if (int e = scp::check_launch("batchnorm finalize")) return e;
     const long quads = R * C / 4;
     const dim3 grid((unsigned)((quads + BN_THREADS - 1) / BN_THREADS));
 #define SCP_BN_APPLY(S, A) \
-    hipLaunchKernelGGL((bn_apply_kernel<S, A>), grid, dim3(BN_THREADS), 0, st, x, skip, quads, g.tc, save_scale, save_shift, y)
+    hipLaunchKernelGGL((bn_apply_kernel<T, S, A>), grid, dim3(BN_THREADS), 0, st, x, skip, quads, g.tc, save_scale, save_shift, y)
     if (skip && relu) SCP_BN_APPLY(true, true);
     else if (skip) SCP_BN_APPLY(true, false);
     else if (relu) SCP_BN_APPLY(false, true);
@@ -296,11 +309,10 @@ extern "C" int scp_batchnorm_act_forward(const float* x, const float* skip, cons
     return scp::check_launch("batchnorm apply");
 }
 
-extern "C" int scp_batchnorm_act_backward(const float* dy, const float* x, const float* y, const float* save_mean,
-                                          const float* save_invstd, const float* save_scale, const float* save_shift,
-                                          long R, int C, int relu, int has_skip, int training, float* dx, float* dskip,
-                                          float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
-                                          void* stream) {
+template <typename T>
+int bn_backward_impl(const T* dy, const T* x, const T* y, const float* save_mean, const float* save_invstd,
+                     const float* save_scale, const float* save_shift, long R, int C, int relu, int has_skip, int training, T* dx,
+                     T* dskip, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
     if (bad_shape(R, C)) return scp::fail(hipErrorInvalidValue, "batchnorm: C must be a power of two in [16,1024], R > 0");
     if (!dy || !x || !dx || !save_mean || !save_invstd || !save_scale || !save_shift)
         return scp::fail(hipErrorInvalidValue, "batchnorm backward: null argument");
@@ -314,25 +326,66 @@ extern "C" int scp_batchnorm_act_backward(const float* dy, const float* x, const
     float* c1 = pgx + (size_t)g.blocks * C;
     float* c2 = c1 + C;
 #define SCP_BN_REDUCE(M) \
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<M>), dim3(g.blocks), dim3(BN_THREADS), 0, st, dy, x, y, R, C, g.tc, \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M>), dim3(g.blocks), dim3(BN_THREADS), 0, st, dy, x, y, R, C, g.tc, \
                        g.rows_per_block, save_mean, save_invstd, save_scale, save_shift, dskip, pg, pgx)
     if (mode == 0) SCP_BN_REDUCE(0);
     else if (mode == 1) SCP_BN_REDUCE(1);
     else SCP_BN_REDUCE(2);
 #undef SCP_BN_REDUCE
     if (int e = scp::check_launch("batchnorm backward reduce")) return e;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, pg, pgx, g.blocks, R, C, training,
-                       c1, c2, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, pg, pgx, g.blocks, R, C,
+                       training, c1, c2, dgamma, dbeta);
     if (int e = scp::check_launch("batchnorm backward finalize")) return e;
     const long quads = R * C / 4;
     const dim3 grid((unsigned)((quads + BN_THREADS - 1) / BN_THREADS));
     // with a residual the masked gradient was written to dskip by the reduce pass: read that, no mask work
-    const float* gsrc = mode == 2 ? dskip : dy;
+    const T* gsrc = mode == 2 ? dskip : dy;
     if (mode == 1)
-        hipLaunchKernelGGL((bn_bwd_dx_kernel<1>), grid, dim3(BN_THREADS), 0, st, gsrc, x, quads, g.tc, save_mean,
-                           save_invstd, save_scale, save_shift, c1, c2, dx);
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 1>), grid, dim3(BN_THREADS), 0, st, gsrc, x, quads, g.tc, save_mean, save_invstd,
+                           save_scale, save_shift, c1, c2, dx);
     else
-        hipLaunchKernelGGL((bn_bwd_dx_kernel<0>), grid, dim3(BN_THREADS), 0, st, gsrc, x, quads, g.tc, save_mean,
-                           save_invstd, save_scale, save_shift, c1, c2, dx);
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 0>), grid, dim3(BN_THREADS), 0, st, gsrc, x, quads, g.tc, save_mean, save_invstd,
+                           save_scale, save_shift, c1, c2, dx);
     return scp::check_launch("batchnorm backward dx");
+}
+
+}  // namespace
+
+extern "C" int scp_batchnorm_act_forward(const float* x, const float* skip, const float* gamma, const float* beta,
+                                         float* running_mean, float* running_var, long long* batches_tracked,
+                                         float momentum, float eps, long R, int C, int relu, int training, float* y,
+                                         float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    return bn_forward_impl<float>(x, skip, gamma, beta, running_mean, running_var, batches_tracked, momentum, eps, R, C, relu, training, y,
+                                  save_mean, save_invstd, save_scale, save_shift, workspace, workspace_bytes, stream);
+}
+
+extern "C" int scp_batchnorm_act_backward(const float* dy, const float* x, const float* y, const float* save_mean,
+                                          const float* save_invstd, const float* save_scale, const float* save_shift,
+                                          long R, int C, int relu, int has_skip, int training, float* dx, float* dskip,
+                                          float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+    return bn_backward_impl<float>(dy, x, y, save_mean, save_invstd, save_scale, save_shift, R, C, relu, has_skip, training, dx, dskip,
+                                   dgamma, dbeta, workspace, workspace_bytes, stream);
+}
+
+// bf16 activation storage (BASELINE configs[4] precision); parameters, statistics and workspace are fp32 as above
+extern "C" int scp_batchnorm_act_forward_bf16(const void* x, const void* skip, const float* gamma, const float* beta,
+                                              float* running_mean, float* running_var, long long* batches_tracked,
+                                              float momentum, float eps, long R, int C, int relu, int training, void* y,
+                                              float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
+    return bn_forward_impl<__bf16>(static_cast<const __bf16*>(x), static_cast<const __bf16*>(skip), gamma, beta, running_mean, running_var,
+                                   batches_tracked, momentum, eps, R, C, relu, training, static_cast<__bf16*>(y), save_mean,
+                                   save_invstd, save_scale, save_shift, workspace, workspace_bytes, stream);
+}
+
+extern "C" int scp_batchnorm_act_backward_bf16(const void* dy, const void* x, const void* y, const float* save_mean,
+                                               const float* save_invstd, const float* save_scale, const float* save_shift,
+                                               long R, int C, int relu, int has_skip, int training, void* dx, void* dskip,
+                                               float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                               void* stream) {
+    return bn_backward_impl<__bf16>(static_cast<const __bf16*>(dy), static_cast<const __bf16*>(x), static_cast<const __bf16*>(y), save_mean,
+                                    save_invstd, save_scale, save_shift, R, C, relu, has_skip, training, static_cast<__bf16*>(dx),
+                                    static_cast<__bf16*>(dskip), dgamma, dbeta, workspace, workspace_bytes, stream);
 }

@@ -48,7 +48,8 @@ class _BatchNormAct(Function):
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
         training = bn.training or bn.running_mean is None
         momentum = 0.1 if bn.momentum is None else bn.momentum
-        capi.check(L.scp_batchnorm_act_forward(
+        fwd = L.scp_batchnorm_act_forward if x.dtype == torch.float32 else L.scp_batchnorm_act_forward_bf16
+        capi.check(fwd(
             _ptr(x), _ptr(skip), _ptr(weight), _ptr(bias), _ptr(bn.running_mean), _ptr(bn.running_var),
             _ptr(bn.num_batches_tracked if bn.track_running_stats else None), float(momentum), float(bn.eps), rows, c,
             int(relu), int(training), _ptr(y), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]),
@@ -63,7 +64,7 @@ class _BatchNormAct(Function):
         L = capi.lib()
         x, y, stats = ctx.saved_tensors
         rows, c, relu, has_skip, training, has_w, has_b = ctx.cfg
-        dy = _nhwc(dy)
+        dy = _nhwc(dy.to(x.dtype))
         dx = torch.empty_like(x)
         dskip = torch.empty_like(x) if (relu and has_skip) else None
         want_w = has_w and ctx.needs_input_grad[2]
@@ -72,7 +73,8 @@ class _BatchNormAct(Function):
         dbeta = torch.empty(c, dtype=torch.float32, device=x.device) if want_b else None
         ws_bytes = L.scp_batchnorm_workspace(rows, c)
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
-        capi.check(L.scp_batchnorm_act_backward(
+        bwd = L.scp_batchnorm_act_backward if x.dtype == torch.float32 else L.scp_batchnorm_act_backward_bf16
+        capi.check(bwd(
             _ptr(dy), _ptr(x), _ptr(y), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), rows, c,
             int(relu), int(has_skip), int(training), _ptr(dx), _ptr(dskip), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
             ws_bytes, capi.current_stream()), "batchnorm_act_backward")
@@ -82,7 +84,7 @@ class _BatchNormAct(Function):
 
 
 def _fused_ok(x, bn, skip):
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and type(bn) is nn.BatchNorm2d
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 4 and type(bn) is nn.BatchNorm2d
             and x.is_contiguous(memory_format=torch.channels_last)
             and (skip is None or (skip.shape == x.shape and skip.dtype == x.dtype)))
 

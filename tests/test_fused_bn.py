@@ -133,3 +133,34 @@ def test_upsample2x_backward_bf16():
     y.backward(dy.cuda().to(torch.bfloat16))
     assert xg.grad.dtype == torch.bfloat16
     assert (xg.grad.double().cpu() - xr.grad).abs().max().item() < 2e-2 * (1 + xr.grad.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("skip,relu", [(False, True), (True, True), (False, False)])
+def test_bn_act_bf16_storage(skip, relu):
+    """configs[4] precision: bf16 activations in and out, fp32 statistics -- vs the float64 composition on the same
+    (bf16-rounded) inputs; the band is bf16's 8 mantissa bits on outputs and gradients, statistics stay tight"""
+    shape = (4, 64, 12, 10)
+    x, s, bn, dy = _case(*shape, skip, seed=77)
+    x, dy = x.to(torch.bfloat16).float(), dy.to(torch.bfloat16).float()
+    s = None if s is None else s.to(torch.bfloat16).float()
+    y_ref, dx_ref, ds_ref, _, _, bn_ref = _reference(x, s, bn, dy, relu, True)
+    dev = torch.device("cuda")
+    bn_g = copy.deepcopy(bn).to(dev).train(True)
+    xg = x.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    sg = None if s is None else s.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert fused_bn._fused_ok(xg, bn_g, sg)
+    y = fused_bn.bn_act(xg, bn_g, sg, relu=relu)
+    assert y.dtype == torch.bfloat16 and "BatchNormAct" in type(y.grad_fn).__name__
+    y.backward(dy.to(dev).to(torch.bfloat16))
+
+    def close(a, b, tol):
+        a, b = a.detach().double().cpu(), b.detach().double()
+        assert (a - b).abs().max().item() <= tol * (1 + b.abs().max().item())
+
+    close(y, y_ref, 1e-2)
+    close(xg.grad, dx_ref, 2e-2)
+    if skip:
+        close(sg.grad, ds_ref, 1e-2)
+    close(bn_g.running_mean, bn_ref.running_mean, 1e-5)
+    close(bn_g.running_var, bn_ref.running_var, 1e-5)
