@@ -8,7 +8,7 @@ MeshNet.forward (encoder, feature<->vertex correspondence, 4 SoftRas passes, DIN
 rotation cycle loss, all losses) + backward + gradient all-reduce (N>1) + per-group clipping +
 AdamW/OneCycle.  Workload = BASELINE.json's metric configuration: B = batch_size 8 x repeat 4 = 32
 images of 256x256 per GPU, 642-vertex / 1280-face prior mesh ("1280" mesh), the
-laptop_wild6d flag set, synthetic batch (tests/synth.py), random-init weights (no network for the
+laptop_wild6d flag set, synthetic batch (scp_amd/synthetic.py), random-init weights (no network for the
 ImageNet / DINO checkpoints).  Weak scaling: every rank processes its own 32 images; `value` counts
 32-image iterations completed by all ranks per second.
 
@@ -30,7 +30,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "self-corr-pose_amd"), os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "self-corr-pose_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -97,24 +97,24 @@ def isolated_attention(B, n_tok, heads, hd, flops, iters=30):
 def build_trainer(device, world, batch_size=8, repeat=4, seed=0, mixed_bf16=None):
     if mixed_bf16 is None:      # tools/*.py reuse this builder; SCP_MIXED_BF16=1 switches them to configs[4] precision
         mixed_bf16 = os.environ.get("SCP_MIXED_BF16", "0") == "1"
-    import scenes
     import scp_amd.dino as dino
+    from scp_amd import synthetic
     from scp_amd.flags import Options
     from scp_amd.trainer import Trainer
     dino.ALLOW_RANDOM_INIT = True
     opts = Options("laptop_wild6d", batch_size=batch_size, repeat=repeat, train=True, ngpu=world, vis_freq=10 ** 9,
                    mixed_bf16=mixed_bf16)
     torch.manual_seed(seed)
-    return Trainer(opts, prior=scenes.bottle_like(3), device=device), opts
+    return Trainer(opts, prior=synthetic.bottle_like(3), device=device), opts
 
 
 def cpu_baseline(sample_bs=2, sample_repeat=2):
     """the step on the host cores: torch-CPU for the stock networks, the CPU oracle (oracle/: C rasteriser,
     torch restatements of the correspondence / ViT pieces) in place of every HIP kernel
-    (tests/oracle_backend.py).  Checker code, used here only as the thing being timed for the baseline --
+    (oracle/backend.py).  Checker code, used here only as the thing being timed for the baseline --
     the patches are undone before returning and never touch the GPU path."""
-    import oracle_backend
-    import synth
+    from oracle import backend as oracle_backend
+    from scp_amd import synthetic as synth
 
     class _Patch:
         def __init__(self):
@@ -152,7 +152,7 @@ def bench_posefit(args):
     (oracle/posefit.py) on a 4-image sample of the same batch."""
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    from posefit_inputs import posefit_inputs
+    from scp_amd.synthetic import posefit_inputs
     from scp_amd import pose_fit
     B = 32
     data, _ = posefit_inputs(bsz=B, size=256, n_verts=642, seed=3)
@@ -216,7 +216,7 @@ def main():
                                 world_size=world, rank=rank)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
-    import synth
+    from scp_amd import synthetic as synth
     from scp_amd.soft_renderer.cuda import soft_rasterize as native
     tr, opts = build_trainer(device, world, mixed_bf16=args.mixed_bf16)
     if tr.reducer is not None:

@@ -100,7 +100,15 @@ def test_dino_features_match_reference_fixture():
     import step_case
     model, data, d = step_case.build("cuda")
     feat = model.pretrain_corr_net.net(data[0][:2]).cpu()
-    np.testing.assert_allclose(feat[:, ::8, ::4, ::4].numpy(), d["dino_feat_sub"], rtol=1e-3, atol=2e-3)
+    got, ref = feat[:, ::8, ::4, ::4].numpy().astype(np.float64), d["dino_feat_sub"].astype(np.float64)
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    print("DINO block-9 keys vs the reference's CPU run: max abs err %.3e, feature scale (max|ref|) %.3e, rms %.3e -> %.3e of scale"
+          % (err, scale, np.sqrt((ref ** 2).mean()), err / scale))
+    # observed on MI355X: 4.2e-6 abs = 1.4e-6 of the feature scale (nine fp32 blocks of GEMM round-off, MFMA summation
+    # order vs the CPU's).  Bound: 1e-5 of the scale, 10x inside north_star's 1e-4.
+    assert err <= 1e-5 * scale
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5 * scale)
     st = step_case.stats(feat)
     np.testing.assert_allclose(st[1:], d["dino_feat_stats"][1:], rtol=1e-4)
 
