@@ -219,8 +219,6 @@ def main():
     from scp_amd import synthetic as synth
     from scp_amd.soft_renderer.cuda import soft_rasterize as native
     tr, opts = build_trainer(device, world, mixed_bf16=args.mixed_bf16)
-    if tr.reducer is not None:
-        tr.reducer.broadcast_parameters(0)
     data = synth.make_batch(opts.batch_size, opts.repeat, opts.img_size, seed=100 + rank, device=device)
     n_faces, n_verts = tr.model.mesh.num_faces, tr.model.mesh.num_verts
 

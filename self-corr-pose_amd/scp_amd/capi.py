@@ -104,6 +104,9 @@ def check(code, what):
 
 
 def current_stream():
+    """the stream the C ABI launches on: the CURRENT device's current stream.  The raw HIP launches inside libscp_hip.so
+    go to the current device, so tensors must live there: Trainer / Tester call torch.cuda.set_device(their device), and
+    dev_ptr() rejects a tensor from another device instead of faulting on a foreign pointer."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -116,6 +119,9 @@ def dev_ptr(t, name):
         raise RuntimeError("%s must be contiguous" % name)
     if t.dtype != torch.float32:
         raise RuntimeError("%s must be float32 (the gfx950 kernels are fp32-only)" % name)
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError("%s lives on cuda:%d but the current device is cuda:%d (torch.cuda.set_device first)"
+                           % (name, t.device.index, torch.cuda.current_device()))
     return ctypes.c_void_p(t.data_ptr())
 
 

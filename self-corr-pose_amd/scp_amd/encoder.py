@@ -16,7 +16,7 @@ class Encoder(nn.Module):
         self.opts = opts
         self.resnet_transform = imgops.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])
         self.random_jitter = imgops.ColorJitter(0.2, 0.2, 0.2, 0.05)
-        self.backbone = ResNet_Encoder()
+        self.backbone = ResNet_Encoder(getattr(opts, "resnet18_path", None), will_load_checkpoint=bool(getattr(opts, "model_path", "")))
         self.featnet = ResNet_Decoder(is_proj=True, out_channel=opts.n_corr_feat,
                                       downsample=opts.img_size // opts.corr_h)
         self.featnet_mesh = MeshEncoder(opts.n_corr_feat)

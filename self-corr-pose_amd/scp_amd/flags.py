@@ -16,6 +16,9 @@ DEFAULTS = dict(
     # not a reference flag: BASELINE configs[4] "mixed bf16" -- encoder convolutions and ViT linear layers under bf16
     # autocast; SoftRas, correspondence reductions, attention softmax, losses and the optimizer stay fp32
     mixed_bf16=False,
+    # not a reference flag: where torchvision's ImageNet resnet18 state_dict lives on disk (the reference lets torchvision
+    # download it, image_encoder.py:122; there is no network here).  Missing file = error, see nets.ResNet_Encoder.
+    resnet18_path="pretrain/resnet18-f37072fd.pth",
     # model/tester.py:35-37 (the CUB evaluation and the visualisation flags are not provided)
     eval=False, eval_nocs=False,
     # config.py

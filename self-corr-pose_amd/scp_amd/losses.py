@@ -78,16 +78,20 @@ class FlattenLoss(nn.Module):
     def __init__(self, faces, average=False):
         super().__init__()
         f = faces.detach().cpu().numpy()
-        edge_faces = {}
+        edge_faces, listed = {}, set()
         for fi, tri in enumerate(f):
             for a, b in ((0, 1), (1, 2), (2, 0)):
                 key = (min(tri[a], tri[b]), max(tri[a], tri[b]))
                 edge_faces.setdefault(key, []).append(fi)
+                # loss_utils.py:105 builds its edge set from faces[:, 0:2] and faces[:, 1:3] ONLY: an edge that sits in
+                # the (v2, v0) slot of both adjacent faces is not part of the reference's sum -- mirrored, not fixed
+                if (a, b) != (2, 0):
+                    listed.add(key)
         # the reference enumerates the edges through a python set of (v0,v1) tuples; the loss is a
         # sum over edges, so any order is equivalent
         v0s, v1s, v2s, v3s = [], [], [], []
         for (a, b), fl in sorted(edge_faces.items()):
-            if len(fl) < 2:
+            if len(fl) < 2 or (a, b) not in listed:
                 continue
             others = [int([v for v in f[fi] if v != a and v != b][0]) for fi in sorted(fl)[:2]]
             v0s.append(a); v1s.append(b); v2s.append(others[0]); v3s.append(others[1])

@@ -59,12 +59,39 @@ class ResNet18Trunk(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
 
-class ResNet_Encoder(nn.Module):
-    """returns the four pyramid levels (1/4 .. 1/32 resolution: 64, 128, 256, 512 channels)"""
+def load_imagenet_resnet18(trunk, path):
+    """torchvision's resnet18 state_dict (e.g. resnet18-f37072fd.pth; the key names are the trunk's) -> trunk; `fc.*` dropped
+    (image_encoder.py:122-123 builds resnet18(pretrained=True) and sets fc = None)"""
+    sd = torch.load(path, map_location="cpu")
+    sd = sd.get("state_dict", sd)
+    sd = {k: v for k, v in sd.items() if not k.startswith("fc.")}
+    missing, unexpected = trunk.load_state_dict(sd, strict=False)
+    missing = [k for k in missing if not k.endswith("num_batches_tracked")]
+    if missing or unexpected:
+        raise RuntimeError("%s is not a torchvision resnet18 state_dict: missing %s unexpected %s" % (path, missing[:5], unexpected[:5]))
 
-    def __init__(self):
+
+class ResNet_Encoder(nn.Module):
+    """returns the four pyramid levels (1/4 .. 1/32 resolution: 64, 128, 256, 512 channels).
+
+    The reference starts from ImageNet weights (image_encoder.py:122 `resnet18(pretrained=True)`, downloaded by
+    torchvision).  There is no network here, so the weights are read from `weights_path` (a torchvision resnet18
+    state_dict on disk).  Like DINO (scp_amd/dino.py) a missing file is an ERROR -- a silent kaiming re-initialisation
+    would depart from the reference recipe (its BatchNorm affine parameters are frozen, so gamma=1 / beta=0 would stay
+    forever) -- unless a full checkpoint is going to be loaded over it (`will_load_checkpoint`) or synthetic weights were
+    asked for explicitly (scp_amd.dino.ALLOW_RANDOM_INIT: bench, tests)."""
+
+    def __init__(self, weights_path=None, will_load_checkpoint=False):
         super().__init__()
         self.resnet = ResNet18Trunk()
+        import os
+        from . import dino
+        if weights_path and os.path.exists(weights_path):
+            load_imagenet_resnet18(self.resnet, weights_path)
+        elif not (will_load_checkpoint or dino.ALLOW_RANDOM_INIT):
+            raise FileNotFoundError(
+                "ImageNet resnet18 weights not found at %r (flag resnet18_path; torchvision's resnet18-f37072fd.pth).  Pass "
+                "model_path to load a full checkpoint, or set scp_amd.dino.ALLOW_RANDOM_INIT for synthetic weights" % (weights_path,))
 
     def forward(self, x):
         r = self.resnet

@@ -1,72 +1,159 @@
-"""scp_amd/parallel.py -- data-parallel gradient averaging over RCCL (xGMI) / gloo.
+"""scp_amd/parallel.py -- data-parallel gradient averaging over RCCL (xGMI) / gloo, overlapped with backward.
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL on ROCm).  The batch shards by image
-(train.py:29-36, data/dataloader.py:57-64); the model is replicated; per step the trainable
-gradients (~59 MB fp32) are averaged.  The reference builds a DistributedDataParallel wrapper but
-calls the bare module, so its reducer never fires; north_star asks for a real all-reduce,
-which is what this does.
+(train.py:29-36, data/dataloader.py:57-64); the model is replicated; per step the trainable gradients
+(~58 MB fp32) are averaged.  The reference builds a DistributedDataParallel wrapper (model/trainer.py:70-75) but
+calls the bare module, so its reducer never fires; north_star asks for a real all-reduce.
 
-xGMI is point-to-point (7 links x ~153 GB/s per GPU), ring all-reduce is per-link bound, so the
-gradients travel as ONE large message: the trainer flattens them into a persistent buffer (stable device
-address for the collective) and `all_reduce_flat` reduces it with a single call on the current stream.
-`all_reduce()` (bucketed, tolerant of parameters without a gradient on some rank) is the general form.
+FlatGradients (used by the Trainer at every world size):
+  * ONE persistent flat fp32 buffer holds every trainable gradient; each `p.grad` is a VIEW into it, so autograd
+    accumulates straight into the buffer (no per-step cat / copy-back passes) and the collectives always see the
+    same device addresses (no re-registration inside RCCL).
+  * the buffer is laid out in REVERSE parameter-registration order (heads and decoder first, ResNet stem last =
+    roughly the order backward produces them) and cut into ~25 MB buckets, each a contiguous slice.
+  * a post-accumulate-grad hook per parameter counts a bucket down; the moment its last gradient has been
+    accumulated the bucket's all-reduce is enqueued (async_op) on a dedicated communication stream that waits
+    on the producing stream -- so buckets travel over xGMI while the rest of backward is still computing.
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU) and ring all-reduce is per-link bound: few large
+    messages (3 buckets here), not many small ones.
+  * finish(): launches whatever did not fire (parameters without a gradient this step contribute zeros on
+    every rank, so the collective sequence is identical everywhere), makes the compute stream wait for the
+    collectives and returns the flat buffer; the 1/world scale is folded into the caller's clip/NaN pass.
 """
-import os
-
 import torch
 import torch.distributed as dist
 
 
-class GradientAllReducer:
-    def __init__(self, model, process_group=None, bucket_bytes=32 << 20):
+class FlatGradients:
+    def __init__(self, params, process_group=None, bucket_bytes=25 << 20, distributed=None):
         self.group = process_group
-        self.world = dist.get_world_size(process_group)
-        self.params = [p for p in model.parameters() if p.requires_grad]
-        self.buckets, cur, size = [], [], 0
-        for p in self.params:
-            nbytes = p.numel() * p.element_size()
-            if cur and size + nbytes > bucket_bytes:
-                self.buckets.append(cur)
-                cur, size = [], 0
+        self.distributed = dist.is_initialized() if distributed is None else distributed
+        self.world = dist.get_world_size(process_group) if self.distributed else 1
+        self.params = [p for p in params if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        dev, dt = self.params[0].device, self.params[0].dtype
+        assert all(p.device == dev and p.dtype == dt for p in self.params)
+        order = list(reversed(self.params))
+        self.flat = torch.zeros(sum(p.numel() for p in order), dtype=dt, device=dev)
+        self.views, self.span, self.bucket_of = {}, {}, {}
+        self.buckets = []                      # (lo, hi, [params])
+        off, lo, cur = 0, 0, []
+        for p in order:
+            n = p.numel()
+            if cur and (off + n - lo) * p.element_size() > bucket_bytes:
+                self.buckets.append((lo, off, cur))
+                lo, cur = off, []
+            self.views[id(p)] = self.flat[off:off + n].view_as(p)
+            self.span[id(p)] = (off, n)
+            self.bucket_of[id(p)] = len(self.buckets)
             cur.append(p)
-            size += nbytes
-        if cur:
-            self.buckets.append(cur)
-        self._flat = [None] * len(self.buckets)
+            off += n
+        self.buckets.append((lo, off, cur))
+        self._pending = [0] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
+        self._armed = False
+        self._silent, self._fired = set(), set()
+        self.launched_in_backward = 0          # buckets whose collective was enqueued from a hook (test / log)
+        self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" and self.world > 1 else None
+        self._hooks = []
+        if self.world > 1:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
-    def broadcast_parameters(self, src=0):
-        """replicas start identical (DDP's init broadcast, trainer.py:70-75)"""
-        for p in self.params:
-            dist.broadcast(p.data, src, group=self.group)
-
-    def all_reduce_flat(self, flat):
-        """average an already flattened gradient buffer in place with ONE collective over the whole buffer (~58 MB fp32 for
-        this model: xGMI ring all-reduce is per-link bound, so one large message beats several small ones).  Enqueued on the
-        current stream (RCCL) -- no host synchronisation.  Ranks must pass buffers of equal length (parameters without a
-        gradient on some rank: use all_reduce())."""
-        if self.world == 1 or os.environ.get("SCP_DEBUG_SKIP_ALLREDUCE") == "1":
-            return flat
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.div_(self.world)
-        return flat
-
-    def all_reduce(self):
+    # ------------------------------------------------------------------------------------------------
+    def broadcast_parameters(self, module=None, src=0):
+        """replicas start identical (DDP's init broadcast, trainer.py:70-75); with `module`, its buffers
+        (BatchNorm running statistics) too"""
         if self.world == 1:
             return
-        work = []
-        for i, bucket in enumerate(self.buckets):
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
-            flat = torch.cat([g.reshape(-1) for g in grads])
-            self._flat[i] = (flat, grads, bucket)
-            work.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for w, (flat, grads, bucket) in zip(work, self._flat):
-            w.wait()
-            flat.div_(self.world)
-            off = 0
-            for p, g in zip(bucket, grads):
-                n = g.numel()
-                if p.grad is None:
-                    p.grad = flat[off:off + n].view_as(p).clone()
-                else:
-                    p.grad.copy_(flat[off:off + n].view_as(p))
-                off += n
+        tensors = [p.data for p in (module.parameters() if module is not None else self.params)]
+        if module is not None:
+            tensors += [b.data for b in module.buffers() if b.is_floating_point() or b.dtype in (torch.int64, torch.int32)]
+        for t in tensors:
+            dist.broadcast(t, src, group=self.group)
+
+    def average_buffers(self, module):
+        """BatchNorm statistics are per rank (each rank normalises with its own 32 images, like the reference without
+        SyncBatchNorm); before a checkpoint is written they are averaged so the saved ones do not depend on which rank saves"""
+        if self.world == 1:
+            return
+        for b in module.buffers():
+            if b.is_floating_point():
+                dist.all_reduce(b.data, op=dist.ReduceOp.SUM, group=self.group)
+                b.data.div_(self.world)
+
+    # ------------------------------------------------------------------------------------------------
+    def prepare(self):
+        """before forward/backward: zero the buffer and point every p.grad at its view (replaces optimizer.zero_grad)"""
+        self.flat.zero_()
+        for p in self.params:
+            v = self.views[id(p)]
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
+        # parameters that produced no gradient in the previous step (heads that a flag switches off, ...) are not waited
+        # for: their bucket goes out as soon as the others are in (DDP's static-graph assumption; if the set changes the
+        # bucket is simply launched by finish() instead -- the result is the same, only the overlap is lost)
+        self._counted = [[id(p) for p in b[2] if id(p) not in self._silent] for b in self.buckets]
+        self._pending = [len(c) for c in self._counted]
+        self._work = [None] * len(self.buckets)
+        self._fired = set()
+        self.launched_in_backward = 0
+        self._armed = True
+
+    def _launch(self, i):
+        lo, hi, _ = self.buckets[i]
+        seg = self.flat[lo:hi]
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self._work[i] = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._work[i] = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        v = self.views[id(p)]
+        if p.grad is not None and p.grad.data_ptr() != v.data_ptr():     # autograd replaced the view (first-touch steal)
+            v.copy_(p.grad)
+            p.grad = v
+        i = self.bucket_of[id(p)]
+        first = id(p) not in self._fired
+        self._fired.add(id(p))
+        if id(p) in self._silent or not first or self._work[i] is not None:
+            return
+        self._pending[i] -= 1
+        # buckets are launched strictly in index order (here or in finish()), so every rank issues the same
+        # collective sequence whatever the timing of its hooks
+        while True:
+            nxt = next((j for j in range(len(self.buckets)) if self._work[j] is None), None)
+            if nxt is None or self._pending[nxt] != 0:
+                break
+            self._launch(nxt)
+            self.launched_in_backward += 1
+
+    def finish(self):
+        """after backward: adopt gradients that were assigned around the views, launch the buckets that have not fired,
+        wait for the collectives.  Returns the flat buffer holding the SUM over ranks (divide by .world)."""
+        self._armed = False
+        for p in self.params:
+            v = self.views[id(p)]
+            if p.grad is None:
+                p.grad = v                               # no gradient this step: zeros (buffer was cleared)
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+                p.grad = v
+        if self.world > 1:
+            for i in range(len(self.buckets)):
+                if self._work[i] is None:
+                    self._launch(i)
+            self._silent = {id(p) for p in self.params} - self._fired
+            for w in self._work:
+                w.wait()                                  # NCCL: the current stream waits; gloo: blocks
+            if self.comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+        return self.flat
+
+
+# name kept for callers of round 1
+GradientAllReducer = FlatGradients

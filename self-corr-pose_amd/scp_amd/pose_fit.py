@@ -57,20 +57,52 @@ def _select(res, stop_t):
     return best, res.shape[0]
 
 
-def fit_padded(source, target, counts, max_iterations=MAX_ITERATIONS):
+DEFAULT_SCALE, DEFAULT_TRANSLATION = 100.0, (0.0, 0.0, 500.0)     # tester.py:375-378 "using default pose"
+
+
+def fit_padded(source, target, counts, max_iterations=MAX_ITERATIONS, strict=False):
     """B problems: source/target [B,Nmax,3] fp32 CUDA (rows >= counts[b] ignored), counts = python ints.
-    Returns scale [B], rotation [B,3,3], translation [B,3], transform [B,4,4], inlier ratio (list)."""
+    Returns scale [B], rotation [B,3,3], translation [B,3], transform [B,4,4], inlier ratio (list).
+
+    A problem with fewer than 5 correspondences fails PER IMAGE like the reference's try/except around
+    estimateSimilarityTransform (tester.py:369-379): with no correspondence torch.randint(0, 0) raises there and the frame
+    gets the default pose (scale 100, R = I, t = [0,0,500]) while evaluation continues; with 1-4 the 5-point covariance is
+    rank deficient and the reference's result is garbage -- those get the default pose too (and, unlike the reference, draw
+    nothing from the generator).  The failed images are excluded from the batched kernels; `last_report["failed"]` lists
+    them and their inlier ratio is reported as 1.0.  strict=True raises instead."""
     _require_cuda(source, "source")
+    counts = [int(c) for c in counts]
+    failed = [b for b, c in enumerate(counts) if c < 5]
+    if failed:
+        if strict:
+            raise RuntimeError("scp_amd.pose_fit: a problem has fewer than 5 correspondences (%s)" % counts)
+        B, dev = source.shape[0], source.device
+        good = [b for b in range(B) if counts[b] >= 5]
+        scale = torch.full((B,), DEFAULT_SCALE, dtype=torch.float32, device=dev)
+        rotation = torch.eye(3, dtype=torch.float32, device=dev).repeat(B, 1, 1)
+        translation = torch.tensor(DEFAULT_TRANSLATION, dtype=torch.float32, device=dev).repeat(B, 1)
+        transform = torch.eye(4, dtype=torch.float32, device=dev).repeat(B, 1, 1)
+        transform[:, :3, :3] *= DEFAULT_SCALE
+        transform[:, :3, 3] = translation
+        ratios = [1.0] * B
+        sub_report = {}
+        if good:
+            gi = torch.tensor(good, device=dev)
+            nsub = max(counts[b] for b in good)
+            s, r, t, tf, rt = fit_padded(source[gi, :nsub], target[gi, :nsub], [counts[b] for b in good], max_iterations, strict)
+            scale[gi], rotation[gi], translation[gi], transform[gi] = s, r, t, tf
+            for b, x in zip(good, rt):
+                ratios[b] = x
+            sub_report = dict(last_report)
+        print("Umeyama algorithm fails, using default pose (images %s: fewer than 5 correspondences)" % failed)
+        last_report.clear()
+        last_report.update(sub_report, failed=failed, n_points=counts, good=good)
+        return scale, rotation, translation, transform, ratios
     L = capi.lib()
     B, nmax, _ = source.shape
     K = max_iterations
     dev = source.device
     source, target = source.contiguous().float(), target.contiguous().float()
-    counts = [int(c) for c in counts]
-    if min(counts) < 5:
-        # torch.randint would still draw, the 5-point covariance is then rank deficient: the reference produces
-        # NaN/garbage here; refuse loudly instead
-        raise RuntimeError("scp_amd.pose_fit: a problem has fewer than 5 correspondences (%s)" % counts)
     counts_dev = torch.tensor(counts, dtype=torch.int32, device=dev)
     pass_t, stop_t = _thresholds(source, target, counts_dev)
     stop_host = None
@@ -121,7 +153,8 @@ def fit_padded(source, target, counts, max_iterations=MAX_ITERATIONS):
                                          ws_bytes, capi.current_stream()), "umeyama_fit_inliers")
     n_in_host = n_in.cpu().tolist()
     ratios = [n / c for n, c in zip(n_in_host, counts)]
-    last_report.update(rounds=rounds_run, n_inliers=n_in_host, n_points=counts, chosen=chosen_round)
+    last_report.clear()
+    last_report.update(rounds=rounds_run, n_inliers=n_in_host, n_points=counts, chosen=chosen_round, failed=[])
     return scale, rotation, translation, transform, ratios
 
 

@@ -15,7 +15,7 @@ import torch
 
 from .model import MeshNet
 from .optimizers import Optimizers
-from .parallel import GradientAllReducer
+from .parallel import FlatGradients
 
 
 def freeze_batchnorm_affine(model):
@@ -58,6 +58,9 @@ class Trainer:
         # it MIOpen's immediate mode falls back to naive fp32 convolutions for several layers
         torch.backends.cudnn.benchmark = True
         if self.device.type == "cuda":
+            # the C-ABI launches go to the CURRENT device's current stream (scp_amd/capi.py): make the trainer's
+            # device the current one so that Trainer(device="cuda:1") in a process sitting on cuda:0 cannot mix devices
+            torch.cuda.set_device(self.device)
             enable_gemm_tuning()
         # the rotation-cycle branch runs on a side stream (model.py); its parameters' AccumulateGrad nodes
         # then see gradients from two streams, which autograd synchronises correctly but warns about
@@ -75,13 +78,22 @@ class Trainer:
             self.model.encoder.featnet.to(memory_format=torch.channels_last)
         self.model.train()
         self.optim = Optimizers(opts, self.model)
-        self.reducer = GradientAllReducer(self.model, process_group) if torch.distributed.is_initialized() else None
         self.iteration = 0
         named = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad]
         self._mean_v = [p for n, p in named if "mean_v" in n]
         self._shapenerf = [p for n, p in named if "mean_v" not in n and "shapenerf" in n]
         self._pose = [p for n, p in named if "mean_v" not in n and "shapenerf" not in n and "pose_predictor" in n]
         self._trainable = [p for _, p in named]
+        # every gradient lives in one flat buffer (p.grad = view); with torch.distributed initialised its buckets are
+        # all-reduced from autograd hooks while backward is still running (scp_amd/parallel.py)
+        self.grads = FlatGradients(self._trainable, process_group)
+        self.reducer = self.grads if self.grads.world > 1 else None
+        self.rank = torch.distributed.get_rank(process_group) if torch.distributed.is_initialized() else 0
+        if self.reducer is not None:
+            # DDP's init broadcast (trainer.py:70-75): replicas start identical whatever the per-rank seeding, BatchNorm
+            # buffers included
+            self.reducer.broadcast_parameters(self.model, 0)
+        self._group_spans = None
 
     def batch_reshape(self, batch):
         o, dev = self.opts, self.device
@@ -98,48 +110,36 @@ class Trainer:
     def collect_grad(self):
         """All-reduce (data parallel), per-group clipping (trainer.py:132-150: mean_v 1.0, shapenerf 1.0,
         pose_predictor 0.1) and NaN guard (a non-finite gradient anywhere zeroes every gradient, like
-        the reference's zero_grad()) on ONE flat copy of the gradients: ~10 launches and no host round
-        trip, instead of one isnan().sum() > 0 sync per parameter."""
-        params = [p for p in self._trainable if p.grad is not None]
-        if not params:
-            z = torch.zeros((), device=self.device)
-            return z, z, z
-        grads = [p.grad for p in params]
-        sizes = [g.numel() for g in grads]
-        # one PERSISTENT flat buffer: the collective sees the same device address every step (no per-step registration /
-        # staging allocation inside the communication library -- gloo allocated pinned staging per new tensor and took
-        # seconds per step when two ranks shared a device; RCCL likewise prefers stable user buffers)
-        total = sum(sizes)
-        buf = getattr(self, "_flat_grad", None)
-        if buf is None or buf.numel() != total or buf.device != grads[0].device:
-            buf = self._flat_grad = torch.empty(total, dtype=grads[0].dtype, device=grads[0].device)
-        flat = torch.cat([g.reshape(-1) for g in grads], out=buf)
-        if self.reducer is not None:
-            self.reducer.all_reduce_flat(flat)
+        the reference's zero_grad()) directly on the flat gradient buffer the parameters' .grad are views of:
+        ~10 launches, no host round trip, no gather / scatter copies (the reference does one isnan().sum() > 0
+        host sync per parameter).  With N > 1 most of the all-reduce has already run underneath backward."""
+        flat = self.grads.finish()                      # SUM over ranks; waits for the in-flight buckets
+        if self.grads.world > 1:
+            flat.div_(self.grads.world)
         finite = torch.isfinite(flat).all()
-        flat = torch.where(finite, flat, torch.zeros((), dtype=flat.dtype, device=flat.device))
-        views = list(flat.split(sizes))
-        offsets, off = {}, 0
-        for p, n in zip(params, sizes):
-            offsets[id(p)] = (off, n)
-            off += n
+        flat.nan_to_num_(0., 0., 0.).mul_(finite.to(flat.dtype))
+        if self._group_spans is None:
+            self._group_spans = []
+            for group, max_norm in ((self._mean_v, 1.), (self._shapenerf, 1.), (self._pose, 0.1)):
+                spans = sorted(self.grads.span[id(p)] for p in group)
+                merged = []
+                for o, n in spans:                       # merge adjacent parameters into contiguous ranges
+                    if merged and merged[-1][0] + merged[-1][1] == o:
+                        merged[-1] = (merged[-1][0], merged[-1][1] + n)
+                    else:
+                        merged.append((o, n))
+                self._group_spans.append((merged, max_norm))
         out = []
-        for group, max_norm in ((self._mean_v, 1.), (self._shapenerf, 1.), (self._pose, 0.1)):
-            spans = sorted(offsets[id(p)] for p in group if id(p) in offsets)
+        for spans, max_norm in self._group_spans:
             if not spans:
                 out.append(torch.zeros((), device=self.device))
                 continue
-            lo, hi = spans[0][0], spans[-1][0] + spans[-1][1]
-            if hi - lo == sum(n for _, n in spans):          # the group is one contiguous range
-                seg = [flat[lo:hi]]
-            else:
-                seg = [flat[o:o + n] for o, n in spans]
+            seg = [flat[o:o + n] for o, n in spans]
             total = seg[0].norm(2) if len(seg) == 1 else torch.stack([t.norm(2) for t in seg]).norm(2)
             coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)           # clip_grad_norm_'s coefficient
             for t in seg:
                 t.mul_(coef)
             out.append(total)
-        torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(views, grads)])
         return tuple(out)
 
     def step(self, data, next_data=None):
@@ -149,7 +149,7 @@ class Trainer:
         side stream before this step's backward and overlaps with it (software pipelining across
         iterations; the next step finds them ready).  Per-step work is unchanged."""
         self.model.iters = self.iteration
-        self.optim.zero_grad()
+        self.grads.prepare()                            # zero_grad: clears the flat buffer, p.grad = its views
         total_loss, aux_output = self.model(data)
         if next_data is not None:
             self.model.pretrain_corr_net.prefetch_features(next_data[0])
@@ -185,13 +185,19 @@ class Trainer:
                     i + 1, batch["img"].shape[0], (t1 - t0) / opts.batch_log_interval, vals[-1]))
                 t0 = t1
             if opts.save_freq and (i + 1) % opts.save_freq == 0:
-                os.makedirs(save_dir, exist_ok=True)
                 self.save(os.path.join(save_dir, "pred_net_%d.pth" % (i + 1)))
         if pending:
             history.extend(torch.stack(pending).cpu().tolist())
         return history
 
     def save(self, path):
+        """rank 0 writes (trainer.py:152-158 guards with local_rank <= 0); every rank must call it: the per-rank BatchNorm
+        statistics are averaged first so the checkpoint does not depend on which rank saves"""
+        if self.reducer is not None:
+            self.reducer.average_buffers(self.model)
+        if self.rank != 0:
+            return
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         state = self.model.state_dict()
         state["mesh.faces"] = self.model.mesh.faces.cpu()
         torch.save(state, path)

@@ -57,6 +57,24 @@ def stats(t):
     return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
 
 
+def conditioning_band(case="step_conditioning_bottle_b2x2", slack=1.5):
+    """per-loss relative band from the conditioning fixture (tests/golden/make_golden.py gen_step_conditioning): the
+    REFERENCE's own forward re-run with its encoder outputs (pred_v, rotation, translation) perturbed by iid
+    N(0, sigma^2), sigma in {1e-6, 3e-6, 1e-5}, 12 draws each.  band[k] = max(1e-4, slack * max |loss_k - base_k| / |base_k|)
+    over all draws: a term the reference itself holds to 1e-4 under such perturbations must meet north_star's 1e-4;
+    a term the reference itself spreads further (the sigma = gamma = 1e-4 silhouette terms) gets the
+    reference's measured spread times `slack` (12 draws under-sample the maximum)."""
+    c = golden_io.load(case)
+    band, spread = {}, {}
+    for key in c:
+        if key.startswith("cond_"):
+            k = key[5:]
+            base = float(c["base_" + k])
+            spread[k] = float(np.abs(c[key] - base).max() / max(abs(base), 1e-12)) if base != 0 else 0.0
+            band[k] = max(1e-4, slack * spread[k])
+    return band, spread, c["sigmas"]
+
+
 def run_and_compare(model, data, d, rtol_loss=1e-4, grad_rel_l2=1e-3, grad_cos=0.9999):
     """north_star: every loss scalar and the predicted pose within 1e-4 relative of the reference;
     gradients: relative L2 (summation orders differ between CPU BLAS / MIOpen / wavefront trees)"""
@@ -70,7 +88,9 @@ def run_and_compare(model, data, d, rtol_loss=1e-4, grad_rel_l2=1e-3, grad_cos=0
         ref = float(d["aux_" + k])
         got = float(v)
         report[k] = (got, ref)
-        assert abs(got - ref) <= rtol_loss * max(abs(ref), 1e-6), "%s: %.9g vs reference %.9g" % (k, got, ref)
+        tol = rtol_loss[k] if isinstance(rtol_loss, dict) else rtol_loss
+        assert abs(got - ref) <= tol * max(abs(ref), 1e-6), "%s: %.9g vs reference %.9g (rel %.2e > %.2e)" % (
+            k, got, ref, abs(got - ref) / max(abs(ref), 1e-6), tol)
     rot, trans = model.last_pose
     np.testing.assert_allclose(rot.cpu().numpy(), d["rotation"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(trans.cpu().numpy(), d["translation"], rtol=1e-4, atol=1e-5)

@@ -61,3 +61,19 @@ def test_eval_mode_confidence_matches_reference(monkeypatch):
     # the nearest-vertex argmin can flip at exact near-ties of the L2 expansion; allow a handful of pixels
     bad = np.abs(conf.numpy() - d["match_conf"]) > 1e-4
     assert bad.mean() < 2e-3, bad.mean()
+
+
+def test_flatten_loss_matches_reference():
+    """loss_utils.py:98-171 incl. its edge enumeration (slots (0,1),(1,2) only, :105) -- off in the shipped configs
+    (flatten_loss=False) but part of MeshNet's loss surface (model.py:116-119)"""
+    from scp_amd import losses as L
+    d = golden_io.load("flatten_loss_small")
+    for tag in ("ico1", "bottle2"):
+        fl = L.FlattenLoss(torch.tensor(d[tag + "_faces"]), average=True)
+        assert fl.v0s.numel() == int(d[tag + "_n_edges"])
+        x = _t(d[tag + "_verts"], True)
+        y = fl(x)
+        y.backward()
+        assert abs(float(y) - float(d[tag + "_loss"])) <= 2e-6 * abs(float(d[tag + "_loss"]))
+        # the edge ORDER differs (python set iteration in the reference), so index_add accumulates in another order
+        np.testing.assert_allclose(x.grad.numpy(), d[tag + "_grad"], rtol=1e-4, atol=1e-6 * np.abs(d[tag + "_grad"]).max())

@@ -1,7 +1,8 @@
 """Data-parallel path on CPU: 2 processes, gloo backend (the GPU box uses the same code over RCCL).
 
-(1) GradientAllReducer: bucketing + averaging equals the mean of the per-rank gradients, parameters
-    without a gradient on one rank are handled, replicas start identical after broadcast.
+(1) FlatGradients: p.grad are views of one flat buffer; bucketed all-reduce launched from autograd hooks equals the
+    mean of the per-rank gradients, parameters without a gradient are handled, replicas (and buffers) start identical
+    after the broadcast; buckets go out BEFORE backward ends (overlap).
 (2) Trainer.step with world_size 2: both ranks end the step with bit-identical parameters although
     they saw different batches (gradients were averaged before clipping / AdamW)."""
 import os
@@ -35,29 +36,73 @@ def _init(rank, world, port):
 
 def _reducer_worker(rank, world, port, out):
     _init(rank, world, port)
-    from scp_amd.parallel import GradientAllReducer
+    from scp_amd.parallel import FlatGradients
     torch.manual_seed(rank)           # replicas start DIFFERENT on purpose
     model = torch.nn.Sequential(torch.nn.Linear(7, 33), torch.nn.ReLU(), torch.nn.Linear(33, 5), torch.nn.Linear(5, 3))
-    red = GradientAllReducer(model, bucket_bytes=600)     # forces several buckets
+    model.register_buffer("running", torch.full((3,), float(rank)))
+    red = FlatGradients(model.parameters(), bucket_bytes=600)     # forces several buckets
     assert len(red.buckets) > 1
-    red.broadcast_parameters(0)
-    w0 = [p.detach().clone() for p in model.parameters()]
+    # the flat buffer is laid out in reverse registration order, buckets are contiguous slices that tile it
+    assert red.buckets[0][0] == 0 and red.buckets[-1][1] == red.flat.numel()
+    assert all(a[1] == b[0] for a, b in zip(red.buckets, red.buckets[1:]))
+    assert red.span[id(list(model.parameters())[-1])][0] == 0
+    red.broadcast_parameters(model, 0)
+    w0 = [p.detach().clone() for p in model.parameters()] + [model.running.clone()]
     x = torch.randn(4, 7, generator=torch.Generator().manual_seed(100 + rank))
+    # local gradients first (no hooks armed), for the expected value
     h = model[1](model[0](x))
-    loss = model[2](h).square().sum()                      # model[3] gets no gradient at all
-    loss.backward()
+    model[2](h).square().sum().backward()                  # model[3] gets no gradient at all
     local = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
-    red.all_reduce()
+    for p in model.parameters():
+        p.grad = None
+    # step 1 learns that model[3] never produces a gradient (nothing can overlap yet: its bucket comes first);
+    # step 2 no longer waits for it
+    for step in range(2):
+        red.prepare()
+        assert all(p.grad.data_ptr() == red.views[id(p)].data_ptr() for p in model.parameters())
+        h = model[1](model[0](x))
+        loss = model[2](h).square().sum()
+        loss.backward()
+        launched_during = red.launched_in_backward
+        flat = red.finish()
+    assert flat.data_ptr() == red.flat.data_ptr()
+    flat.div_(world)
     gathered = [None] * world
     dist.all_gather_object(gathered, [None if g is None else g.numpy() for g in local])
     for i, p in enumerate(model.parameters()):
+        assert p.grad.data_ptr() == red.views[id(p)].data_ptr()          # still views of the flat buffer
         parts = [torch.zeros_like(p) if g[i] is None else torch.tensor(g[i]) for g in gathered]
         torch.testing.assert_close(p.grad, sum(parts) / world, rtol=1e-6, atol=1e-7)
     sync = [None] * world
     dist.all_gather_object(sync, [w.numpy() for w in w0])
     for a, b in zip(sync[0], sync[1]):
         assert (a == b).all()
-    out.put((rank, "ok"))
+    red.average_buffers(model)
+    out.put((rank, launched_during))
+    dist.destroy_process_group()
+
+
+def _overlap_worker(rank, world, port, out):
+    """the bucket holding the LAST layers' gradients must be on the wire before backward has reached the first layer:
+    a backward hook on the first layer records how many buckets had been launched when autograd got there"""
+    _init(rank, world, port)
+    from scp_amd.parallel import FlatGradients
+    torch.manual_seed(0)
+    layers = [torch.nn.Linear(64, 64) for _ in range(8)]
+    model = torch.nn.Sequential(*layers)
+    red = FlatGradients(model.parameters(), bucket_bytes=2 * (64 * 64 + 64) * 4)     # 2 layers per bucket -> 4 buckets
+    assert len(red.buckets) == 4
+    seen = {}
+
+    def at_first_layer(g):
+        seen.setdefault("at_first_layer", red.launched_in_backward)
+    layers[0].weight.register_hook(at_first_layer)
+    red.prepare()
+    x = torch.randn(16, 64, generator=torch.Generator().manual_seed(rank))
+    model(x).square().mean().backward()
+    seen["at_backward_end"] = red.launched_in_backward
+    red.finish()
+    out.put((rank, (seen["at_first_layer"], seen["at_backward_end"])))
     dist.destroy_process_group()
 
 
@@ -77,10 +122,9 @@ def _trainer_worker(rank, world, port, out):
     dino.ALLOW_RANDOM_INIT = True
     opts = Options("laptop_wild6d", batch_size=1, repeat=2, train=True, total_iters=50, img_size=128, corr_h=32,
                    corr_w=32, pretrain_k=40, ngpu=world)
-    torch.manual_seed(0)
+    torch.manual_seed(rank)            # different seeds per rank ON PURPOSE: the init broadcast must make replicas identical
     tr = Trainer(opts, prior=scenes.bottle_like(2), device="cpu")
-    assert tr.reducer is not None
-    tr.reducer.broadcast_parameters(0)
+    assert tr.reducer is not None and tr.reducer.world == world       # Trainer.__init__ broadcast rank 0's replica
     data = synth.make_batch(1, 2, 128, seed=10 + rank, device="cpu")   # different data per rank
     total, aux, _ = tr.step(data)
     flat = torch.cat([p.detach().reshape(-1) for p in tr.model.parameters() if p.requires_grad])
@@ -102,11 +146,21 @@ def _run(worker, world=2):
     for p in procs:
         p.join(300)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    assert sorted(q.get(timeout=5)[0] for _ in range(world)) == list(range(world))
+    got = dict(q.get(timeout=5) for _ in range(world))
+    assert sorted(got) == list(range(world))
+    return got
 
 
-def test_gradient_all_reducer_gloo_world2():
-    _run(_reducer_worker)
+def test_flat_gradients_gloo_world2():
+    got = _run(_reducer_worker)
+    assert all(v >= 1 for v in got.values())           # at least one bucket went out from a hook, i.e. inside backward
+
+
+def test_bucket_all_reduce_overlaps_backward_gloo_world2():
+    got = _run(_overlap_worker)
+    for first, end in got.values():
+        assert first >= 2, "no bucket was launched before backward reached the first layer"
+        assert end >= 3
 
 
 def test_trainer_step_data_parallel_gloo_world2():

@@ -104,6 +104,43 @@ def test_hip_pose_fitting_matches_reference():
 
 
 @pytest.mark.gpu
+def test_failed_frame_gets_default_pose_and_the_rest_is_unchanged():
+    """tester.py:369-379: a frame whose fit fails (no valid correspondence: torch.randint(0, 0) raises in the reference)
+    gets scale 100 / R = I / t = [0,0,500] and evaluation continues; the other frames and the generator state are exactly
+    what they are without the empty frame in between (it consumes no random numbers)"""
+    from scp_amd import pose_fit
+    d = np.load(os.path.join(GOLD, "posefit_b3_64.npz"))
+    keys = ("depth", "mask", "match", "match_conf", "foc_crop", "pp_crop", "pred_v")
+    t = {k: torch.from_numpy(d[k]).cuda() for k in keys + ("base_rot",)}
+    fit = pose_fit.PoseFitter(img_size=d["depth"].shape[-1], base_rot=t["base_rot"])
+    torch.manual_seed(int(d["seed"]))
+    clean = fit.pose_fitting(*(t[k] for k in keys))
+    state_clean = torch.get_rng_state()
+    # insert an image with an empty mask (and one with 3 valid pixels) between images 0 and 1
+    def widen(x, fill):
+        return torch.cat((x[:1], fill(x[:1]), fill(x[:1]), x[1:]), 0)
+    w = {k: widen(t[k], lambda a: a.clone()) for k in keys}
+    w["mask"][1] = 0
+    w["mask"][2] = 0
+    valid = ((w["depth"][2] > 0) & (w["match_conf"][2, 0] > 0)).nonzero()[:3]
+    w["mask"][2][valid[:, 0], valid[:, 1]] = 1
+    torch.manual_seed(int(d["seed"]))
+    bbox, verts, rot, tr = fit.pose_fitting(*(w[k] for k in keys))
+    assert pose_fit.last_report["failed"] == [1, 2]
+    assert torch.equal(torch.get_rng_state(), state_clean)
+    keep = [0, 3, 4]
+    for got, ref in zip((bbox, verts, rot, tr), clean):
+        assert torch.equal(got[keep], ref)
+    base = t["base_rot"].reshape(3, 3)
+    for b in (1, 2):
+        assert torch.allclose(rot[b], base)                               # base_rot @ I
+        assert torch.allclose(tr[b].reshape(-1), torch.tensor([0., 0., 0.5], device="cuda"))   # 500 mm -> m
+    with pytest.raises(RuntimeError):
+        src, tgt, counts = fit.correspondences(*(w[k].float() for k in keys[:-1]))
+        pose_fit.fit_padded(src, tgt, counts, strict=True)
+
+
+@pytest.mark.gpu
 def test_hip_pose_fitting_full_size_against_oracle():
     """bench geometry (B=8 here, 256x256): HIP vs the numpy oracle fed the same index stream"""
     from posefit_inputs import posefit_inputs

@@ -32,14 +32,34 @@ def test_full_step_matches_reference_on_gpu(case):
 
 
 def test_full_step_free_running_on_gpu():
-    """nothing pinned but the discrete selections: the stock-PyTorch encoder's library rounding
-    (MIOpen's solver choice varies from process to process) perturbs pred_v / pose at the 5e-6 level,
-    and the silhouette-sensitive render losses amplify that to 1e-5 ... 8e-4 relative (observed
-    spread over runs; SURVEY F12 measured the same amplification between two builds of the reference
-    itself).  Sanity bound only: 2e-3 on every loss, 1e-4 on the pose -- the parity claim is the
-    pinned test above."""
+    """nothing pinned but the discrete selections.  The stock MIOpen/rocBLAS encoder rounds pred_v / pose
+    differently from the CPU reference (measured and asserted below: <= 1e-5), and the silhouette-sensitive render
+    terms amplify that.  The allowed deviation per loss is NOT hand-picked: it is the spread the REFERENCE ITSELF shows
+    when its own encoder outputs are perturbed at that level (tests/golden/step_conditioning_bottle_b2x2.npz, recorded by
+    make_golden.py step_conditioning; see step_case.conditioning_band).  Terms the reference holds to 1e-4 under such
+    perturbations must meet north_star's 1e-4 here."""
+    import numpy as np
     model, data, d = step_case.build("cuda")
-    step_case.run_and_compare(model, data, d, rtol_loss=2e-3, grad_rel_l2=0.1, grad_cos=0.995)
+    band, spread, sigmas = step_case.conditioning_band()
+    cap = {}
+    fwd = model.encoder.forward
+
+    def spy(*a, **k):
+        out = fwd(*a, **k)
+        cap["enc"] = out
+        return out
+    model.encoder.forward = spy
+    report = step_case.run_and_compare(model, data, d, rtol_loss=band, grad_rel_l2=0.1, grad_cos=0.995)
+    # the premise of the band: the encoder's geometric outputs deviate from the reference's by no more than the
+    # perturbation levels the fixture covers
+    for j, key in ((2, "pred_v"), (3, "rotation"), (4, "translation")):
+        dev = np.abs(cap["enc"][j].detach().cpu().numpy().astype(np.float64) - d[key])
+        print("encoder %-12s deviation from the reference: rms %.2e max %.2e" % (key, np.sqrt((dev ** 2).mean()), dev.max()))
+        assert np.sqrt((dev ** 2).mean()) <= float(sigmas.max())
+    for k, (got, ref) in report.items():
+        if k in band:
+            print("%-22s rel dev %.2e | allowed %.2e (reference's own spread under perturbation %.2e)"
+                  % (k, abs(got - ref) / max(abs(ref), 1e-12), band[k], spread[k]))
 
 
 def test_trainer_step_runs_and_updates():

@@ -103,3 +103,30 @@ def test_category_presets_equal_the_shipped_flag_sets():
         assert o.category == cat and o.batch_size == 8 and o.repeat == 4 and o.pretrain_k == 200 and o.divide_fn == "both"
         for k, v in fields.items():
             assert getattr(o, k) == v, (cat, k)
+
+
+def test_resnet18_imagenet_weights_are_required_or_loaded(tmp_path):
+    """the backbone must start from ImageNet weights like the reference (image_encoder.py:122); a missing
+    file raises instead of silently falling back to a random initialisation"""
+    import scp_amd.dino as dino
+    from scp_amd import nets
+    saved = dino.ALLOW_RANDOM_INIT
+    try:
+        dino.ALLOW_RANDOM_INIT = False
+        with pytest.raises(FileNotFoundError):
+            nets.ResNet_Encoder(str(tmp_path / "nope.pth"))
+        nets.ResNet_Encoder(str(tmp_path / "nope.pth"), will_load_checkpoint=True)      # a checkpoint will overwrite it
+        # a torchvision-style state_dict (same key names + fc.*) is loaded, fc dropped
+        torch.manual_seed(1)
+        donor = nets.ResNet18Trunk()
+        sd = {k: torch.randn_like(v) if v.is_floating_point() else v for k, v in donor.state_dict().items()}
+        sd["fc.weight"], sd["fc.bias"] = torch.zeros(1000, 512), torch.zeros(1000)
+        torch.save(sd, tmp_path / "resnet18.pth")
+        enc = nets.ResNet_Encoder(str(tmp_path / "resnet18.pth"))
+        for k, v in enc.resnet.state_dict().items():
+            assert torch.equal(v, sd[k]), k
+        torch.save({"conv1.weight": sd["conv1.weight"]}, tmp_path / "bad.pth")
+        with pytest.raises(RuntimeError):
+            nets.ResNet_Encoder(str(tmp_path / "bad.pth"))
+    finally:
+        dino.ALLOW_RANDOM_INIT = saved
