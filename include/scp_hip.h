@@ -64,6 +64,20 @@ int scp_soft_rasterize_forward(const float* faces, const float* textures, float*
                                float* aggrs_info, float* soft_colors, const scp_raster_params* p,
                                void* stream);
 
+/* Two of the reference's render passes in ONE launch (no reference counterpart as a single call; replaces two
+ * forward_soft_rasterize calls, model/module/renderer.py:13-24,52-61): `renderer_depth` (softmax rgb, vertex textures
+ * = projected coordinates) and `renderer_hardtex` (hard rgb, vertex textures = canonical coordinates) rasterise the same
+ * projected faces with the same sigma / distance / alpha aggregation, so every coverage decision, soft fragment and the
+ * alpha plane are shared.  `p` describes the primary pass (func_id_rgb must be SCP_RGB_SOFTMAX,
+ * texture_sample_type SCP_SAMPLE_VERTEX; gamma_val is the primary's -- hard rgb does not use gamma).  The *_hard buffers
+ * follow the same caller-initialised protocol as the primary ones: soft_colors_hard [B,4,S,S] pre-filled with ITS
+ * background, aggrs_info_hard [B,2,S,S] (z_min, face index as float).  Outputs are bit-identical to two separate
+ * scp_soft_rasterize_forward calls. */
+int scp_soft_rasterize_forward_dual(const float* faces, const float* textures, float* faces_info,
+                                    float* aggrs_info, float* soft_colors, const float* textures_hard,
+                                    float* aggrs_info_hard, float* soft_colors_hard,
+                                    const scp_raster_params* p, void* stream);
+
 /* Replaces backward_soft_rasterize (cpp:94-132).
  *   grad_faces [B,F,9], grad_textures [B,F,T,3]: caller-zeroed, accumulated into.
  *   grad_soft_colors [B,4,S,S] contiguous. */
@@ -77,6 +91,12 @@ int scp_soft_rasterize_backward(const float* faces, const float* textures, const
  * uint64, caller-zeroed. */
 int scp_soft_rasterize_count_pairs(const float* faces, unsigned long long* count,
                                    const scp_raster_params* p, void* stream);
+
+/* Device self-test of the rasteriser's exact division by a hoisted divisor (csrc/softras.hip xdiv: q = a * RN(1/b) plus
+ * two fused residual corrections must equal the IEEE quotient a / b bit for bit): evaluates `n` generated operand pairs
+ * (uniform and adversarial mantissas, exponents within the range the kernels admit) and adds the number of mismatching
+ * results to *mismatches (one device uint64, caller-zeroed).  Expected: 0. */
+int scp_selftest_exact_division(unsigned long long n, unsigned seed, unsigned long long* mismatches, void* stream);
 
 /* ---- dense correspondence: masked softmax / soft-argmax over an all-pairs score tensor ------------
  * scores S[N,P,Q], Q contiguous.  A score is "masked" (treated as the constant -1e5, like

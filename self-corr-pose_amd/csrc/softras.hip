@@ -5,56 +5,68 @@
 //     :245-305 per-face precompute, :308-483 per-pixel forward, :486-668 per-pixel backward
 // (semantics checklist: SURVEY.md Appendix A).  How it computes it is CDNA4-first:
 //
-//   * one 256-thread workgroup (4 wavefronts of 64) owns a 16x16 pixel tile; each wavefront owns
-//     an 8x8 quadrant so that a face whose dilated bounding box misses the quadrant costs the
-//     wavefront a single LDS broadcast read + compare (s_cbranch_execz skips the rest);
-//   * the tile first bins the faces: 256 faces per round are tested against the tile rectangle
-//     and compacted IN FACE-INDEX ORDER (ballot + popcount prefix) into an LDS list -- order
-//     matters, the alpha product / online softmax / z-buffer tie-break are order dependent and
-//     must equal the reference's brute-force loop bit for bit;
-//   * listed faces are staged 32 at a time into LDS as 44-float records (dilated bbox, corners,
-//     inverse, Gram matrix, obtuse flags, vertex colours); all 64 lanes read the same record ->
-//     LDS broadcast, no bank conflicts, nothing is re-read from L2 per pixel (the reference
-//     re-reads every face from global memory in every thread);
-//   * backward: per (wavefront, face) the 18 partial derivatives are combined with a butterfly
-//     reduce-scatter over the wavefront (17+12 cross-lane ops instead of 18x6), added to an LDS
-//     accumulator with ds_add_f32, and flushed with ONE global atomic per (tile, face, component)
-//     -- the reference issues 9-18 global atomics per (pixel, face);
-//   * blockIdx is remapped so that the tiles of one image run on one XCD (its faces stay in that
-//     XCD's L2).
+//   * one 256-thread workgroup (4 wavefronts of 64) owns a pixel tile; the tile first bins the faces: 256 faces per
+//     round are tested against the tile rectangle and compacted IN FACE-INDEX ORDER (ballot + popcount prefix) into an
+//     LDS list -- order matters, the alpha product / online softmax / z-buffer tie-break are order dependent and must
+//     equal the reference's brute-force loop bit for bit;
+//   * listed faces are staged 32 at a time into LDS as 72-float records (corners, inverse, Gram matrix, obtuse flags,
+//     vertex colours, and the face-only terms hoisted out of the pair loop: edge vectors of the Gram matrix, edge
+//     denominators and the correctly rounded reciprocals of every face-constant divisor); nothing is re-read from L2
+//     per pixel (the reference re-reads every face from global memory in every thread);
+//   * forward: each wavefront owns an 8x8 quadrant; a face whose dilated bounding box misses the quadrant costs a single
+//     LDS broadcast read + compare;
+//   * backward works per (pixel, face) PAIR, not per face x 64 lanes: every wavefront scans the staged faces against
+//     its pixels, appends the bbox-surviving pairs to a small LDS ring (each face's run padded to a multiple of 16
+//     lanes) and runs the pair arithmetic on full groups of 64 queued pairs; per-pixel inputs come from an LDS pixel
+//     table, per-face records are read with a per-row address.  The 18 partial derivatives are combined with a DPP
+//     butterfly reduce-scatter inside every 16-lane row (one face per row by construction), added to an LDS accumulator
+//     with ds_add_f32, and flushed with ONE global atomic per (tile, face, component) -- the reference issues 9-18
+//     global atomics per (pixel, face);
+//   * divisions by face / pass constants are exact without the IEEE division sequence: with y = RN(1/b) hoisted,
+//     q = a*y followed by two fused residual corrections is the correctly rounded a/b (Markstein), 5 instructions
+//     instead of ~11 and bit-identical to a/b (scp_selftest_exact_division checks it on the device);
+//   * blockIdx is remapped so that the tiles of one image run on one XCD (its faces stay in that XCD's L2).
 //
-// Numerics: this file is compiled with -ffp-contract=off and without fast-math; every expression
-// keeps the reference's evaluation order and its fp64 promotions, so the only
-// source of difference from the CPU oracle is the last-ulp behaviour of expf.
+// Numerics: this file is compiled with -ffp-contract=off and without fast-math; every expression keeps the
+// reference's evaluation order and its fp64 promotions where they change a value, so the only source
+// of difference from the CPU oracle is the last-ulp behaviour of expf.  Explicit __builtin_fmaf calls are the exact-
+// division residuals, never a contraction of the reference's arithmetic.
 #include <hip/hip_runtime.h>
 
 #include "scp_hip.h"
 #include "scp_common.h"
+#include <cstdlib>
 
 namespace {
-
-// Division inside pure GRADIENT arithmetic (never in a coverage / clipping decision): SCP_FAST_GRAD_DIV selects v_rcp_f32 * x
-// (1-2 ulp) instead of the IEEE sequence (~10 instructions); off by default, the oracle comparison then holds to the last bit
-#ifdef SCP_FAST_GRAD_DIV
-#define GDIV(x, y) ((x) * __builtin_amdgcn_rcpf(y))
-#else
-#define GDIV(x, y) ((x) / (y))
-#endif
 
 constexpr int TILE = 16;        // pixels per tile edge
 constexpr int THREADS = 256;    // 4 wavefronts
 constexpr int NB = 32;          // faces staged per round
-constexpr int REC = 44;         // floats per staged face record
+constexpr int REC = 72;         // floats per staged face record (multiple of 4, and 72 mod 64 = 8: the four rows of a wavefront
+                                // read four different records without sharing a bank)
 constexpr int LIST_CAP = 1024;  // binned face ids held before a flush
+constexpr int PIXREC = 20;      // floats per pixel-table entry (backward); 20*p mod 64 hits 16 distinct 4-bank groups
+constexpr int QCAP = 256;       // pair-queue ring entries per wavefront (max outstanding 63 + 64 + 15)
 
 // record layout (floats)
-constexpr int R_BBOX = 0;   // lo_x, hi_x, lo_y, hi_y  (already dilated by sqrt(threshold))
-constexpr int R_V = 4;      // 9 corner coordinates
-constexpr int R_INV = 13;   // 9
-constexpr int R_SYM = 22;   // 9
-constexpr int R_OBT = 31;   // 3
-constexpr int R_TEX = 34;   // 9 (vertex colours) -- only valid when texture_size == 3
-constexpr int R_IDX = 43;   // face index (int bits)
+constexpr int R_V = 0;      // 9 corner coordinates
+constexpr int R_INV = 9;    // 9
+constexpr int R_SYM = 18;   // 9 (copied with R_INV / R_OBT in one run; read through R_EA)
+[[maybe_unused]] constexpr int R_SYM_USED = R_SYM;
+constexpr int R_OBT = 27;   // 3
+constexpr int R_TEX = 30;   // 9 (vertex colours) -- only valid when texture_size == 3
+constexpr int R_IDX = 39;   // face index (int bits)
+constexpr int R_EA = 40;    // 9: edge e = (v0 = e, v1 = e+1 mod 3): a_j = sym[v0][j] - sym[v1][j]   (kernel.cu:41-44)
+constexpr int R_EDEN = 49;  // 3: a[v0] - a[v1]  (the divisor of kernel.cu:45)
+constexpr int R_ERCP = 52;  // 3: RN(1 / R_EDEN)
+constexpr int R_ZRCP = 55;  // 3: RN(1 / z_corner)
+constexpr int R_SLOW = 58;  // int bits: 1 = some face-constant divisor is zero / non-finite / extreme -> IEEE division
+constexpr int R_PRE = 59;   // 3: conservative early-out thresholds m_k: a pixel with w_k < -m_k lies further than the dilation
+                            //    margin behind edge line k and cannot pass the reference's `dis < threshold` test; +inf = off
+constexpr int R_TEX2 = 62;  // 9: vertex colours of the fused hard-colour output (dual forward only)
+
+// pixel-table layout (floats; backward)
+constexpr int P_IMG = 0, P_GIMG = 4, P_SUM = 8, P_MAX = 9, P_XP = 10, P_YP = 11, P_RSUM = 12, P_SLOW = 13;
 
 struct RasterArgs {
     const float* faces;
@@ -62,6 +74,9 @@ struct RasterArgs {
     const float* faces_info;
     float* aggrs_info;
     float* soft_colors;
+    const float* textures2;      // dual forward: vertex colours, z-buffer info and image of the fused hard-colour pass
+    float* aggrs_info2;
+    float* soft_colors2;
     const float* soft_colors_in;
     const float* aggrs_info_in;
     const float* grad_soft_colors;
@@ -72,15 +87,45 @@ struct RasterArgs {
     int tiles_per_row, tiles_per_image, total_tiles, tiles_per_xcd;
     float near_, far_, eps, sigma, dist_eps, gamma;
     float threshold, margin;
+    float range, nrange;                                  // far - near, near - far (fp32, as the reference forms them)
+    float rcp_sigma, rcp_gamma, rcp_range, rcp_nrange;    // RN(1 / x) of the pass constants
+    int const_slow;                                       // a pass constant is outside the exact-division range
     int dist_mode, alpha_mode, double_side;
-    int dbg;   // profiling ablations (tools/softras_ablate.py): 1 = skip reduction+flush, 2 = skip pair math
+    int dbg_nopre; /*DBG*/
 };
-
-int g_debug_flags = 0;
 
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float pick3(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
+
+// ------------------------------------------------------------------------------------------------
+// exact division by a hoisted divisor.  y = RN(1/b) (one IEEE division per face / pixel / pass).  q0 = RN(a*y) is within
+// 2 ulp of a/b; q1 = RN(q0 + r0*y) with the exact residual r0 = a - b*q0 is faithful; one more residual step gives the
+// correctly rounded quotient (Markstein 1990, the same iteration the hardware's v_div_* sequence runs, minus its scaling
+// and fix-up instructions).  Valid while no intermediate leaves the normal range: divisors are range-checked when they
+// are hoisted; a pair whose face / pixel / pass constants fail the check runs the FAST = false instantiation of the pair
+// arithmetic (plain a / b everywhere).  Verified against a / b on the device by scp_selftest_exact_division
+// (tests/test_softras_gpu.py).
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ bool fast_div_range(float b) {
+    const float ab = fabsf(b);
+    return ab > 1e-15f && ab < 1e15f;   // false for NaN
+}
+
+template <bool FAST>
+__device__ __forceinline__ float xdiv(float a, float b, float y) {
+    if (!FAST) return a / b;
+    float q = a * y;
+    float r = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r, y, q);
+}
+
+// RN_f32(RN_f64(1 / s)) for a float s, as the reference's `1. / (w0/z0 + w1/z1 + w2/z2)` evaluates it (kernel.cu:68): the
+// double rounding is harmless here -- a float midpoint m has 25 significant bits, so s*m is a 49-bit product and cannot
+// lie within 2^-53 of 1 without being 1 -- hence the value is simply the correctly rounded fp32 reciprocal.
+__device__ __forceinline__ float rcp_as_double(float s) { return 1.0f / s; }
 
 // blockIdx -> (image, tile): consecutive logical ids live on the same XCD (observed placement:
 // block b runs on XCD b % 8), so one image's faces are fetched into one L2.
@@ -195,10 +240,10 @@ __device__ __forceinline__ int bin_chunk(const RasterArgs& a, int bn, int c, con
     return n + total;
 }
 
-// stages faces list[s .. s+cnt) into LDS records; 8 threads per face
-template <bool WITH_TEX>
+// stages faces list[s .. s+cnt) into LDS records (8 threads per face) and hoists the face-only terms of the pair loop
+template <bool WITH_TEX, bool WITH_TEX2 = false>
 __device__ __forceinline__ void stage_faces(const RasterArgs& a, int bn, const unsigned* list, int s,
-                                            int cnt, float* stage) {
+                                            int cnt, float* stage, float4* bbox) {
     const int slot = threadIdx.x >> 3, part = threadIdx.x & 7;
     if (slot < cnt) {
         const unsigned f = list[s + slot];
@@ -213,18 +258,76 @@ __device__ __forceinline__ void stage_faces(const RasterArgs& a, int bn, const u
             else if (j < 30) rec[R_INV + (j - 9)] = fi[j - 9];
             else if (j < 39) { if (WITH_TEX) rec[R_TEX + (j - 30)] = a.textures[g * 9 + (j - 30)]; }
         }
-        if (part == 7) {
-            rec[R_BBOX + 0] = min3f(fv[0], fv[3], fv[6]) - a.margin;
-            rec[R_BBOX + 1] = max3f(fv[0], fv[3], fv[6]) + a.margin;
-            rec[R_BBOX + 2] = min3f(fv[1], fv[4], fv[7]) - a.margin;
-            rec[R_BBOX + 3] = max3f(fv[1], fv[4], fv[7]) + a.margin;
+        if (WITH_TEX2) {
+            rec[R_TEX2 + part] = a.textures2[g * 9 + part];
+            if (part == 0) rec[R_TEX2 + 8] = a.textures2[g * 9 + 8];
+        }
+        if (part < 3) {
+            // edge `part` runs from corner v0 = part to v1 = part + 1 (kernel.cu:41-45, func `closest point on an edge`)
+            const int v0 = part, v1 = part == 2 ? 0 : part + 1;
+            const float a0 = fi[9 + 3 * v0 + 0] - fi[9 + 3 * v1 + 0];
+            const float a1 = fi[9 + 3 * v0 + 1] - fi[9 + 3 * v1 + 1];
+            const float a2 = fi[9 + 3 * v0 + 2] - fi[9 + 3 * v1 + 2];
+            rec[R_EA + 3 * part + 0] = a0;
+            rec[R_EA + 3 * part + 1] = a1;
+            rec[R_EA + 3 * part + 2] = a2;
+            const float den = pick3(v0, a0, a1, a2) - pick3(v1, a0, a1, a2);
+            rec[R_EDEN + part] = den;
+            rec[R_ERCP + part] = 1.0f / den;
+        } else if (part < 6) {
+            const int k = part - 3;
+            rec[R_ZRCP + k] = 1.0f / fv[3 * k + 2];
+            // early-out threshold for barycentric weight k.  |grad w_k| = 1 / height_k, so w_k < -d * |grad w_k| puts the
+            // pixel further than d behind the line through the opposite edge, i.e. at a true distance > d from the
+            // triangle.  The reference skips a pair when ITS computed distance satisfies dis >= threshold (kernel.cu:384);
+            // that distance is |sum_k (t_k - w_k) v_k| with t a convex combination on an edge, so it can fall short of the
+            // true one only through the rounding of the w_k it is built from.  Bound E on that (u = 2^-24):
+            //   w_k = inv_k . (x, y, 1):     3u * (|inv_k0| + |inv_k1| + |inv_k2|)          (products and sums)
+            //   inv = adj / det:             |w_k| * 4u * D / |det|, D = sum |x_i| |y_j - y_k|   (det cancels for slivers)
+            //                                2u * vmax^2 / |det|                                (adj_k2 = x_i y_j - x_j y_i)
+            //   |w_k| <= 1 + |grad w_k| * (diameter + 2 * margin) for every pixel of the dilated bounding box
+            // d = 1.02 * margin + 5 * E * max|v|.  For well-shaped faces that is 1-3 % above the margin; for slivers E
+            // exceeds the margin and the early-out is effectively off; degenerate faces switch it off (+inf).
+            const float x0 = fv[0], y0 = fv[1], x1 = fv[3], y1 = fv[4], x2 = fv[6], y2 = fv[7];
+            const float e01 = (x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0);
+            const float e12 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
+            const float e20 = (x0 - x2) * (x0 - x2) + (y0 - y2) * (y0 - y2);
+            const float det = x2 * (y0 - y1) + x0 * (y1 - y2) + x1 * (y2 - y0);
+            const float dsum = fabsf(x2) * fabsf(y0 - y1) + fabsf(x0) * fabsf(y1 - y2) + fabsf(x1) * fabsf(y2 - y0);
+            const float vmax = fmaxf(1.f, fmaxf(fmaxf(fmaxf(fabsf(x0), fabsf(y0)), fmaxf(fabsf(x1), fabsf(y1))), fmaxf(fabsf(x2), fabsf(y2))));
+            const float reach = sqrtf(fmaxf(fmaxf(e01, e12), e20)) + 2.f * a.margin;
+            const float rel_det = 2.4e-7f * dsum / fabsf(det);
+            float err = 3.f * 1.2e-7f * vmax * vmax / fabsf(det);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const float gj = sqrtf(fi[3 * j] * fi[3 * j] + fi[3 * j + 1] * fi[3 * j + 1]);
+                err += 1.8e-7f * (fabsf(fi[3 * j]) + fabsf(fi[3 * j + 1]) + fabsf(fi[3 * j + 2])) + (1.f + gj * reach) * rel_det;
+            }
+            const bool usable = a.dist_mode == SCP_DIST_EUCLIDEAN && fabsf(det) > 1e-9f && fminf(fminf(e01, e12), e20) > 0.f && !a.dbg_nopre;
+            const float gn = sqrtf(fi[3 * k] * fi[3 * k] + fi[3 * k + 1] * fi[3 * k + 1]);
+            const float thr = (1.02f * a.margin + 5.f * err * vmax) * gn + 1e-6f;
+            rec[R_PRE + k] = (usable && thr == thr) ? thr : INFINITY;
+        } else if (part == 6) {
+            bbox[slot] = make_float4(min3f(fv[0], fv[3], fv[6]) - a.margin, max3f(fv[0], fv[3], fv[6]) + a.margin,
+                                     min3f(fv[1], fv[4], fv[7]) - a.margin, max3f(fv[1], fv[4], fv[7]) + a.margin);
+        } else {
+            bool ok = fast_div_range(fv[2]) && fast_div_range(fv[5]) && fast_div_range(fv[8]);
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                const int v1 = e == 2 ? 0 : e + 1;
+                const float av0 = fi[9 + 3 * e + e] - fi[9 + 3 * v1 + e];
+                const float av1 = fi[9 + 3 * e + v1] - fi[9 + 3 * v1 + v1];
+                ok = ok && fast_div_range(av0 - av1);
+            }
             reinterpret_cast<unsigned*>(rec)[R_IDX] = f;
+            reinterpret_cast<unsigned*>(rec)[R_SLOW] = ok ? 0u : 1u;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // per (pixel, face) geometry shared by forward and backward (kernel.cu:24-151, :375-404)
+// `rec` may be a per-lane pointer (backward: one face per 16-lane row)
 // ------------------------------------------------------------------------------------------------
 struct Cover {
     float w[3], t[3];
@@ -239,27 +342,28 @@ __device__ __forceinline__ bool front_facing(const float* v) {
     return (v[7] - v[1]) * (v[3] - v[0]) < (v[4] - v[1]) * (v[6] - v[0]);
 }
 
+// kernel.cu:55-60.  The reference clamps in double (`max(min(w, 1.), 0.)`, `max(sum, 1e-5)`): on float operands a
+// double min/max only selects one of them, and RN_f32(1e-5) is the largest float below the double 1e-5, so the float
+// clamps below select exactly the same values.
 __device__ __forceinline__ void clip_weights(float* w) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) w[k] = (float)fmax(fmin((double)w[k], 1.), 0.);
-    const float s = (float)fmax((double)(w[0] + w[1] + w[2]), 1e-5);
+    for (int k = 0; k < 3; k++) w[k] = fmaxf(fminf(w[k], 1.f), 0.f);
+    const float s = fmaxf(w[0] + w[1] + w[2], 1e-5f);
 #pragma unroll
     for (int k = 0; k < 3; k++) w[k] /= s;
 }
 
-// parameter of the projection of the pixel onto edge (v0 -> v1); `sym` points into the LDS record
-// and may be indexed with a per-lane v0 (distinct rows sit in distinct banks)
-__device__ __forceinline__ float edge_param(const float* sym, const float* w, int v0, int v1) {
-    const float a0 = sym[3 * v0 + 0] - sym[3 * v1 + 0];
-    const float a1 = sym[3 * v0 + 1] - sym[3 * v1 + 1];
-    const float a2 = sym[3 * v0 + 2] - sym[3 * v1 + 2];
-    const float av1 = pick3(v1, a0, a1, a2), av0 = pick3(v0, a0, a1, a2);
-    return (w[0] * a0 + w[1] * a1 + w[2] * a2 - av1) / (av0 - av1);
+// parameter of the projection of the pixel onto edge e = (v0 = e, v1 = e + 1): (w . a - a[v1]) / (a[v0] - a[v1])
+template <bool FAST>
+__device__ __forceinline__ float edge_param(const float* rec, const float* w, int e) {
+    const float* ea = rec + R_EA + 3 * e;
+    const float a0 = ea[0], a1 = ea[1], a2 = ea[2];
+    const float av1 = pick3(e == 2 ? 0 : e + 1, a0, a1, a2);
+    return xdiv<FAST>(w[0] * a0 + w[1] * a1 + w[2] * a2 - av1, rec[R_EDEN + e], rec[R_ERCP + e]);
 }
 
-__device__ __forceinline__ void euclid_distance(Cover& c, const float* v, const float* rec, float xp,
-                                                float yp) {
-    const float* sym = rec + R_SYM;
+template <bool FAST>
+__device__ __forceinline__ void euclid_distance(Cover& c, const float* v, const float* rec, float xp, float yp) {
     const float* w = c.w;
     if (w[0] > 0 && w[1] > 0 && w[2] > 0 && w[0] < 1 && w[1] < 1 && w[2] < 1) {
         float best = 100000000, bx = 0, by = 0;
@@ -267,7 +371,7 @@ __device__ __forceinline__ void euclid_distance(Cover& c, const float* v, const 
         for (int k = 0; k < 3; k++) {
             const int v0 = k, v1 = (k + 1) % 3, v2 = (k + 2) % 3;
             float t0[3];
-            t0[v0] = edge_param(sym, w, v0, v1);
+            t0[v0] = edge_param<FAST>(rec, w, k);
             t0[v1] = 1 - t0[v0];
             t0[v2] = 0;
             t0[0] -= w[0]; t0[1] -= w[1]; t0[2] -= w[2];
@@ -294,7 +398,7 @@ __device__ __forceinline__ void euclid_distance(Cover& c, const float* v, const 
         else if (w[1] <= 0) v0 = 2;
         else if (w[2] <= 0) v0 = 0;
         const int v1 = v0 == 2 ? 0 : v0 + 1;
-        const float tp = edge_param(sym, w, v0, v1);
+        const float tp = edge_param<FAST>(rec, w, v0);
         const float tq = 1 - tp;
         float t[3];
         t[0] = v0 == 0 ? tp : (v1 == 0 ? tq : 0.f);
@@ -302,7 +406,7 @@ __device__ __forceinline__ void euclid_distance(Cover& c, const float* v, const 
         t[2] = v0 == 2 ? tp : (v1 == 2 ? tq : 0.f);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            t[k] = (float)fmin(fmax((double)t[k], 0.), 1.);
+            t[k] = fminf(fmaxf(t[k], 0.f), 1.f);      // kernel.cu:141 clamps in double: a selection, see clip_weights
             t[k] -= w[k];
             c.t[k] = t[k];
         }
@@ -313,6 +417,7 @@ __device__ __forceinline__ void euclid_distance(Cover& c, const float* v, const 
 }
 
 // returns false when the pair is skipped (bbox is tested by the caller)
+template <bool FAST>
 __device__ __forceinline__ bool pair_coverage(const RasterArgs& a, Cover& c, const float* v,
                                               const float* rec, float xp, float yp) {
     const float* inv = rec + R_INV;
@@ -321,22 +426,30 @@ __device__ __forceinline__ bool pair_coverage(const RasterArgs& a, Cover& c, con
     c.sign = 0; c.dx = 0; c.dy = 0; c.dis = 0;
     c.t[0] = c.t[1] = c.t[2] = 0;
     if (a.dist_mode == SCP_DIST_EUCLIDEAN) {
-        euclid_distance(c, v, rec, xp, yp);
+        euclid_distance<FAST>(c, v, rec, xp, yp);
         c.dis = c.dx * c.dx + c.dy * c.dy;
         if (c.sign < 0 && c.dis >= a.threshold) return false;
-        c.frag = (float)(1. / (1. + (double)expf(-c.sign * c.dis / a.sigma)));
+        c.frag = (float)(1. / (1. + (double)expf(xdiv<FAST>(-c.sign * c.dis, a.sigma, a.rcp_sigma))));
     } else if (a.dist_mode == SCP_DIST_BARYCENTRIC) {
         const float* w = c.w;
         float d = w[0] > w[1] ? (w[1] > w[2] ? w[2] : w[1]) : (w[0] > w[2] ? w[2] : w[0]);
         c.dis = d > 0 ? d * d : -(d * d);
         c.t[0] = w[0]; c.t[1] = w[1]; c.t[2] = w[2];
         if (-c.dis >= a.threshold) return false;
-        c.frag = (float)(1. / (1. + (double)expf(-c.dis / a.sigma)));
+        c.frag = (float)(1. / (1. + (double)expf(xdiv<FAST>(-c.dis, a.sigma, a.rcp_sigma))));
     } else {
         c.frag = weights_inside(c.w) ? 1.f : 0.f;
         if (c.frag == 0.f) return false;
     }
     return true;
+}
+
+// perspective-correct depth of the pixel on the face (kernel.cu:66-69): 1 / (w0/z0 + w1/z1 + w2/z2), outer division in double
+template <bool FAST>
+__device__ __forceinline__ float pair_depth(const float* w, const float* v, const float* rec) {
+    const float s = xdiv<FAST>(w[0], v[2], rec[R_ZRCP + 0]) + xdiv<FAST>(w[1], v[5], rec[R_ZRCP + 1]) +
+                    xdiv<FAST>(w[2], v[8], rec[R_ZRCP + 2]);
+    return rcp_as_double(s);
 }
 
 // surface-texture sampling reads global memory (kernel.cu:178-188); `limit` keeps the reference's
@@ -364,9 +477,84 @@ __device__ __forceinline__ float sample_colour(const RasterArgs& a, const float*
 // ------------------------------------------------------------------------------------------------
 // forward (kernel.cu:308-483)
 // ------------------------------------------------------------------------------------------------
-template <int RGB, int SAMPLE>
+struct PixelState {            // the order-dependent per-pixel aggregates of kernel.cu:354-367
+    float col[4];
+    float sm_sum, sm_max, zmin;
+    int fmin;
+};
+
+// bbox-surviving pixel outside the dilated triangle? (see R_PRE)  Same w as pair_coverage computes.
+__device__ __forceinline__ bool behind_an_edge(const float* rec, float xp, float yp) {
+    const float* inv = rec + R_INV;
+    bool out = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) out = out || (inv[3 * k] * xp + inv[3 * k + 1] * yp + inv[3 * k + 2] < -rec[R_PRE + k]);
+    return out;
+}
+
+struct HardState {             // z-buffer of the fused hard-colour output (dual forward)
+    float col[3];
+    float zmin;
+    int fmin;
+};
+
+template <int RGB, int SAMPLE, bool FAST, bool DUAL>
+__device__ __forceinline__ void forward_pair(const RasterArgs& a, PixelState& st, HardState& hs, const float* rec, float xp,
+                                             float yp, int bn) {
+    float v[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = rec[R_V + k];
+    Cover cv;
+    if (!pair_coverage<FAST>(a, cv, v, rec, xp, yp)) return;
+
+    if (a.alpha_mode == SCP_ALPHA_PROD) st.col[3] = (float)((double)st.col[3] * (1. - (double)cv.frag));
+    else if (a.alpha_mode == SCP_ALPHA_SUM) st.col[3] += cv.frag;
+    else if (cv.frag > 0.5) st.col[3] = 1.f;
+
+    float wc[3] = {cv.w[0], cv.w[1], cv.w[2]};
+    clip_weights(wc);
+    const float zp = pair_depth<FAST>(wc, v, rec);
+    if (zp < a.near_ || zp > a.far_) return;
+
+    const unsigned f = reinterpret_cast<const unsigned*>(rec)[R_IDX];
+    const size_t face_g = (size_t)bn * a.F + f;
+    if (DUAL) {      // the hard-colour pass of the same coverage (kernel.cu:428-439 with func_id_rgb = 0, vertex textures)
+        if (zp < hs.zmin && weights_inside(cv.w) && (a.double_side || front_facing(v))) {
+            hs.zmin = zp;
+            hs.fmin = (int)f;
+            const float* tex = rec + R_TEX2;
+#pragma unroll
+            for (int k = 0; k < 3; k++) hs.col[k] = wc[0] * tex[k] + wc[1] * tex[3 + k] + wc[2] * tex[6 + k];
+        }
+    }
+    if (RGB == SCP_RGB_HARD) {
+        if (zp < st.zmin && weights_inside(cv.w) && (a.double_side || front_facing(v))) {
+            st.zmin = zp;
+            st.fmin = (int)f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) st.col[k] = sample_colour<SAMPLE>(a, rec, face_g, wc, k);
+        }
+    } else if (front_facing(v) || a.double_side) {
+        const float zn = xdiv<FAST>(a.far_ - zp, a.range, a.rcp_range);
+        float rescale = 1.f;
+        if (zn > st.sm_max) {
+            rescale = expf(xdiv<FAST>(st.sm_max - zn, a.gamma, a.rcp_gamma));
+            st.sm_max = zn;
+        }
+        const float ez = expf(xdiv<FAST>(zn - st.sm_max, a.gamma, a.rcp_gamma));
+        st.sm_sum = rescale * st.sm_sum + ez * cv.frag;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float ck = sample_colour<SAMPLE>(a, rec, face_g, wc, k);
+            st.col[k] = rescale * st.col[k] + ez * cv.frag * ck;
+        }
+    }
+}
+
+template <int RGB, int SAMPLE, bool DUAL = false>
 __global__ __launch_bounds__(THREADS) void raster_forward_kernel(const RasterArgs a) {
     __shared__ __attribute__((aligned(16))) float stage[NB * REC];
+    __shared__ float4 bbox[NB];
     __shared__ unsigned list[LIST_CAP];
     __shared__ int wave_cnt[4];
 
@@ -378,19 +566,24 @@ __global__ __launch_bounds__(THREADS) void raster_forward_kernel(const RasterArg
     const size_t npix = (size_t)a.S * a.S;
     float* out = a.soft_colors + (size_t)px.bn * 4 * npix + px.pn;
 
-    float col[4] = {1.f, 1.f, 1.f, 0.f};
-    if (a.alpha_mode == SCP_ALPHA_PROD) col[3] = 1.f;
-    float sm_sum = expf(a.eps / a.gamma);
-    float sm_max = a.eps;
+    PixelState st;
+    st.col[0] = st.col[1] = st.col[2] = 1.f;
+    st.col[3] = a.alpha_mode == SCP_ALPHA_PROD ? 1.f : 0.f;
+    st.sm_sum = expf(a.eps / a.gamma);
+    st.sm_max = a.eps;
     if (px.valid) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const float bg = out[k * npix];
-            col[k] = RGB == SCP_RGB_HARD ? bg : bg * sm_sum;
+            st.col[k] = RGB == SCP_RGB_HARD ? bg : bg * st.sm_sum;
         }
     }
-    float zmin = 10000000;
-    int fmin = -1;
+    st.zmin = 10000000;
+    st.fmin = -1;
+    HardState hs;
+    hs.col[0] = hs.col[1] = hs.col[2] = 0.f;
+    hs.zmin = 10000000;
+    hs.fmin = -1;
 
     int n = 0;
     for (int c = 0; c < a.F; c += THREADS) {
@@ -398,54 +591,18 @@ __global__ __launch_bounds__(THREADS) void raster_forward_kernel(const RasterArg
         if (n <= LIST_CAP - THREADS && c + THREADS < a.F) continue;
         for (int s = 0; s < n; s += NB) {
             const int cnt = min(NB, n - s);
-            stage_faces<SAMPLE == SCP_SAMPLE_VERTEX>(a, px.bn, list, s, cnt, stage);
+            stage_faces<SAMPLE == SCP_SAMPLE_VERTEX, DUAL>(a, px.bn, list, s, cnt, stage, bbox);
             __syncthreads();
             if (px.valid) {
                 for (int q = 0; q < cnt; q++) {
-                    const float* rec = stage + q * REC;
-                    const float4 bb = *reinterpret_cast<const float4*>(rec + R_BBOX);
+                    const float4 bb = bbox[q];
                     if (px.xp > bb.y || px.xp < bb.x || px.yp > bb.w || px.yp < bb.z) continue;
-                    float v[9];
-#pragma unroll
-                    for (int k = 0; k < 9; k++) v[k] = rec[R_V + k];
-                    Cover cv;
-                    if (!pair_coverage(a, cv, v, rec, px.xp, px.yp)) continue;
-
-                    if (a.alpha_mode == SCP_ALPHA_PROD) col[3] = (float)((double)col[3] * (1. - (double)cv.frag));
-                    else if (a.alpha_mode == SCP_ALPHA_SUM) col[3] += cv.frag;
-                    else if (cv.frag > 0.5) col[3] = 1.f;
-
-                    float wc[3] = {cv.w[0], cv.w[1], cv.w[2]};
-                    clip_weights(wc);
-                    const float zp = (float)(1. / (double)(wc[0] / v[2] + wc[1] / v[5] + wc[2] / v[8]));
-                    if (zp < a.near_ || zp > a.far_) continue;
-
-                    const unsigned f = reinterpret_cast<const unsigned*>(rec)[R_IDX];
-                    const size_t face_g = (size_t)px.bn * a.F + f;
-                    if (RGB == SCP_RGB_HARD) {
-                        if (zp < zmin && weights_inside(cv.w) && (a.double_side || front_facing(v))) {
-                            zmin = zp;
-                            fmin = (int)f;
-#pragma unroll
-                            for (int k = 0; k < 3; k++) col[k] = sample_colour<SAMPLE>(a, rec, face_g, wc, k);
-                        }
-                    } else {
-                        if (front_facing(v) || a.double_side) {
-                            const float zn = (a.far_ - zp) / (a.far_ - a.near_);
-                            float rescale = 1.f;
-                            if (zn > sm_max) {
-                                rescale = expf((sm_max - zn) / a.gamma);
-                                sm_max = zn;
-                            }
-                            const float ez = expf((zn - sm_max) / a.gamma);
-                            sm_sum = rescale * sm_sum + ez * cv.frag;
-#pragma unroll
-                            for (int k = 0; k < 3; k++) {
-                                const float ck = sample_colour<SAMPLE>(a, rec, face_g, wc, k);
-                                col[k] = rescale * col[k] + ez * cv.frag * ck;
-                            }
-                        }
-                    }
+                    const float* rec = stage + q * REC;
+                    if (behind_an_edge(rec, px.xp, px.yp)) continue;
+                    if (reinterpret_cast<const unsigned*>(rec)[R_SLOW] != 0u || a.const_slow)
+                        forward_pair<RGB, SAMPLE, false, DUAL>(a, st, hs, rec, px.xp, px.yp, px.bn);
+                    else
+                        forward_pair<RGB, SAMPLE, true, DUAL>(a, st, hs, rec, px.xp, px.yp, px.bn);
                 }
             }
             __syncthreads();
@@ -454,23 +611,36 @@ __global__ __launch_bounds__(THREADS) void raster_forward_kernel(const RasterArg
     }
 
     if (!px.valid) return;
-    if (a.alpha_mode == SCP_ALPHA_PROD) out[3 * npix] = (float)(1. - (double)col[3]);
-    else if (a.alpha_mode == SCP_ALPHA_SUM) out[3 * npix] = col[3] / a.F;
-    else out[3 * npix] = col[3];
+    float alpha;
+    if (a.alpha_mode == SCP_ALPHA_PROD) alpha = (float)(1. - (double)st.col[3]);
+    else if (a.alpha_mode == SCP_ALPHA_SUM) alpha = st.col[3] / a.F;
+    else alpha = st.col[3];
+    out[3 * npix] = alpha;
+    if (DUAL) {      // same coverage -> same alpha plane; colours only where a face won the z-test (kernel.cu:466-472)
+        float* out2 = a.soft_colors2 + (size_t)px.bn * 4 * npix + px.pn;
+        out2[3 * npix] = alpha;
+        if (hs.fmin != -1) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) out2[k * npix] = hs.col[k];
+        }
+        float* ag2 = a.aggrs_info2 + (size_t)px.bn * 2 * npix + px.pn;
+        ag2[0] = hs.zmin;
+        ag2[npix] = (float)hs.fmin;
+    }
 
     float* ag = a.aggrs_info + (size_t)px.bn * 2 * npix + px.pn;
     if (RGB == SCP_RGB_HARD) {
-        if (fmin != -1) {
+        if (st.fmin != -1) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) out[k * npix] = col[k];
+            for (int k = 0; k < 3; k++) out[k * npix] = st.col[k];
         }
-        ag[0] = zmin;
-        ag[npix] = (float)fmin;
+        ag[0] = st.zmin;
+        ag[npix] = (float)st.fmin;
     } else {
 #pragma unroll
-        for (int k = 0; k < 3; k++) out[k * npix] = col[k] / sm_sum;
-        ag[0] = sm_sum;
-        ag[npix] = sm_max;
+        for (int k = 0; k < 3; k++) out[k * npix] = st.col[k] / st.sm_sum;
+        ag[0] = st.sm_sum;
+        ag[npix] = st.sm_max;
     }
 }
 
@@ -519,15 +689,161 @@ __device__ __forceinline__ float row_sum16(float x) {
     return x;
 }
 
+// the 18 partial derivatives of one (pixel, face) pair (kernel.cu:560-660); g[] arrives zeroed
+template <int RGB, int SAMPLE, bool FAST>
+__device__ __forceinline__ void backward_pair(const RasterArgs& a, float* g, const float* rec, const float* pr, int bn) {
+    const float xp = pr[P_XP], yp = pr[P_YP];
+    float v[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = rec[R_V + k];
+    Cover cv;
+    if (!pair_coverage<FAST>(a, cv, v, rec, xp, yp)) return;
+    const float img3 = pr[P_IMG + 3];
+    float c_xy = 0;
+    float c_alpha = pr[P_GIMG + 3];
+    if (a.alpha_mode == SCP_ALPHA_SUM) c_alpha /= a.F;
+    else if (a.alpha_mode == SCP_ALPHA_PROD)
+        c_alpha = (float)((double)c_alpha * ((double)(1 - img3) / fmax((double)(1 - cv.frag), 1e-6)));
+    c_xy += c_alpha;
+
+    float w[3] = {cv.w[0], cv.w[1], cv.w[2]};
+    clip_weights(w);
+    const float zp = pair_depth<FAST>(w, v, rec);
+    if (zp < a.near_ || zp > a.far_) return;
+    const unsigned f = reinterpret_cast<const unsigned*>(rec)[R_IDX];
+    const size_t face_g = (size_t)bn * a.F + f;
+    const float sm_max = pr[P_MAX];
+    if (RGB == SCP_RGB_HARD) {
+        if ((float)(int)f == sm_max) {
+            if (SAMPLE == SCP_SAMPLE_VERTEX) {
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) g[9 + 3 * j + k] = w[j] * pr[P_GIMG + k];
+            } else {
+                const int texel = surface_texel(w, a.R);
+                if (texel >= 0 && texel < a.T) {
+                    float* gt = a.grad_textures + face_g * a.T * 3 + texel * 3;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) atomicAdd(gt + k, pr[P_GIMG + k]);
+                }
+            }
+        }
+    } else if (front_facing(v) || a.double_side) {
+        float c_rgb = 0.f;
+        const float zn = xdiv<FAST>(a.far_ - zp, a.range, a.rcp_range);
+        const float ez = expf(xdiv<FAST>(zn - sm_max, a.gamma, a.rcp_gamma));
+        const float zs = xdiv<FAST>(cv.frag * ez, pr[P_SUM], pr[P_RSUM]);
+        int texel = 0;
+        if (SAMPLE == SCP_SAMPLE_SURFACE) texel = surface_texel(w, a.R);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float gk = pr[P_GIMG + k];
+            if (SAMPLE == SCP_SAMPLE_VERTEX) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) g[9 + 3 * j + k] = zs * (w[j] * gk);
+            } else if (texel >= 0 && texel < a.T) {
+                atomicAdd(a.grad_textures + face_g * a.T * 3 + texel * 3 + k, zs * gk);
+            }
+            const float ck = sample_colour<SAMPLE>(a, rec, face_g, w, k);
+            c_rgb += gk * (ck - pr[P_IMG + k]);
+        }
+        c_rgb *= zs;
+        c_xy += c_rgb / cv.frag;
+        const float c_z = xdiv<FAST>(xdiv<FAST>(c_rgb, a.gamma, a.rcp_gamma), a.nrange, a.rcp_nrange) * zp * zp;
+        g[2] = xdiv<FAST>(xdiv<FAST>(c_z * w[0], v[2], rec[R_ZRCP + 0]), v[2], rec[R_ZRCP + 0]);
+        g[5] = xdiv<FAST>(xdiv<FAST>(c_z * w[1], v[5], rec[R_ZRCP + 1]), v[5], rec[R_ZRCP + 1]);
+        g[8] = xdiv<FAST>(xdiv<FAST>(c_z * w[2], v[8], rec[R_ZRCP + 2]), v[8], rec[R_ZRCP + 2]);
+    }
+
+    c_xy *= xdiv<FAST>(cv.frag * (1 - cv.frag), a.sigma, a.rcp_sigma);
+    if (a.dist_mode == SCP_DIST_EUCLIDEAN) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            g[3 * k + 0] = 2 * cv.sign * c_xy * (cv.t[k] + cv.w[k]) * cv.dx;
+            g[3 * k + 1] = 2 * cv.sign * c_xy * (cv.t[k] + cv.w[k]) * cv.dy;
+        }
+    } else if (a.dist_mode == SCP_DIST_BARYCENTRIC) {
+        // kernel.cu:161-175
+        const float* t = cv.t;
+        const float* inv = rec + R_INV;
+        const int pm = t[0] > t[1] ? (t[1] > t[2] ? 2 : 1) : (t[0] > t[2] ? 2 : 0);
+        const float scale2 = cv.dis > 0 ? sqrtf(cv.dis) : sqrtf(-cv.dis);
+#pragma unroll
+        for (int l = 0; l < 2; l++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float gk = 0;
+#pragma unroll
+                for (int qq = 0; qq < 3; qq++)
+                    gk += -inv[3 * pm + l] * inv[3 * k + qq] * (qq == 0 ? xp : (qq == 1 ? yp : 1.f));
+                float r = gk * c_xy;
+                r = (float)((double)r * (2. * (double)scale2));
+                g[3 * k + l] = r;
+            }
+    }
+}
+
+// One group of 64 queued (pixel, face) pairs: lane = pair.  Queue entry: bits 0-7 pixel of the wavefront's quadrant,
+// bits 8-12 staged-face slot, bit 15 = padding lane (carries the slot of its row).  Every 16-lane row holds one face.
 // NG = 18: [grad_face 0..8 | grad_texture 0..8] (softmax rgb or vertex textures);
 // NG = 6 : grad_face x/y only (hard rgb with surface textures, e.g. the mask pass)
 template <int RGB, int SAMPLE>
-__global__ __launch_bounds__(THREADS) void raster_backward_kernel(const RasterArgs a) {
+__device__ __forceinline__ void backward_group(const RasterArgs& a, const float* stage, const float* pix_wave,
+                                               float* acc, const unsigned short* queue, int head, int n_valid,
+                                               int bn) {
     constexpr bool FULL = !(RGB == SCP_RGB_HARD && SAMPLE == SCP_SAMPLE_SURFACE);
     constexpr int NACC = 18;
+    const int lane = threadIdx.x & 63;
+    const unsigned e = queue[(head + lane) & (QCAP - 1)];
+    const bool in_range = lane < n_valid;
+    const bool live = in_range && !(e & 0x8000u);
+    const unsigned long long row_first = __ballot(in_range);          // rows are whole: bit of the row's first lane
+    const int q = in_range ? (int)((e >> 8) & 31u) : 0;
+    const float* rec = stage + q * REC;
+    const float* pr = pix_wave + (live ? (int)(e & 0xFFu) : 0) * PIXREC;
+
+    float g[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) g[k] = 0.f;
+    if (live) {
+        const bool slow = reinterpret_cast<const unsigned*>(rec)[R_SLOW] != 0u ||
+                          reinterpret_cast<const unsigned*>(pr)[P_SLOW] != 0u || a.const_slow;
+        if (slow) backward_pair<RGB, SAMPLE, false>(a, g, rec, pr, bn);
+        else backward_pair<RGB, SAMPLE, true>(a, g, rec, pr, bn);
+    }
+#ifdef SCP_ABLATE_NO_REDUCE   // tools/softras_ablate.py builds: price the reduction + flush
+    if (g[0] + g[5] + g[11] == 12345.f) acc[0] = 1.f;
+    return;
+#endif
+    // rows are merged by the LDS atomics themselves (several rows of a group may hold the same face)
+    const bool row_live = (row_first >> (lane & 48)) & 1ull;
+    float* slot_acc = acc + q * NACC;
+    if (FULL) {
+        const float g16 = row_sum16(g[16]), g17 = row_sum16(g[17]);
+        const float r = group_reduce_scatter<16>(g);
+        const int l16 = lane & 15;
+        if (row_live) {
+            atomicAdd(slot_acc + l16, r);
+            if (l16 < 2) atomicAdd(slot_acc + 16 + l16, l16 == 0 ? g16 : g17);
+        }
+    } else {
+        float h[8] = {g[0], g[1], g[3], g[4], g[6], g[7], 0.f, 0.f};
+        const float r = group_reduce_scatter<8>(h);
+        const int l8 = lane & 7;
+        if (row_live && l8 < 6) atomicAdd(slot_acc + (l8 + (l8 >> 1)), r);  // 0,1,3,4,6,7
+    }
+}
+
+template <int RGB, int SAMPLE>
+__global__ __launch_bounds__(THREADS) void raster_backward_kernel(const RasterArgs a) {
+    constexpr int NACC = 18;
     __shared__ __attribute__((aligned(16))) float stage[NB * REC];
+    __shared__ __attribute__((aligned(16))) float pix[THREADS * PIXREC];
+    __shared__ float4 bbox[NB];
     __shared__ float acc[NB * NACC];
     __shared__ unsigned list[LIST_CAP];
+    __shared__ unsigned short queue[4 * QCAP];
     __shared__ int wave_cnt[4];
 
     const int tile_id = logical_tile(a);
@@ -536,18 +852,28 @@ __global__ __launch_bounds__(THREADS) void raster_backward_kernel(const RasterAr
     const Pixel px = pixel_of_thread(a, tile_id, tx0, ty0);
     const TileRect rect = tile_rect(a, tx0, ty0);
     const size_t npix = (size_t)a.S * a.S;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    float img[4] = {0, 0, 0, 0}, gimg[4] = {0, 0, 0, 0}, sm_sum = 1.f, sm_max = 0.f;
-    if (px.valid) {
-        const float* ip = a.soft_colors_in + (size_t)px.bn * 4 * npix + px.pn;
-        const float* gp = a.grad_soft_colors + (size_t)px.bn * 4 * npix + px.pn;
+    {   // this thread's pixel -> LDS pixel table (entry threadIdx.x = wave * 64 + lane)
+        float* pr = pix + threadIdx.x * PIXREC;
+        float sm_sum = 1.f;
+        if (px.valid) {
+            const float* ip = a.soft_colors_in + (size_t)px.bn * 4 * npix + px.pn;
+            const float* gp = a.grad_soft_colors + (size_t)px.bn * 4 * npix + px.pn;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { img[k] = ip[k * npix]; gimg[k] = gp[k * npix]; }
-        sm_sum = a.aggrs_info_in[((size_t)px.bn * 2 + 0) * npix + px.pn];
-        sm_max = a.aggrs_info_in[((size_t)px.bn * 2 + 1) * npix + px.pn];
+            for (int k = 0; k < 4; k++) { pr[P_IMG + k] = ip[k * npix]; pr[P_GIMG + k] = gp[k * npix]; }
+            sm_sum = a.aggrs_info_in[((size_t)px.bn * 2 + 0) * npix + px.pn];
+            pr[P_MAX] = a.aggrs_info_in[((size_t)px.bn * 2 + 1) * npix + px.pn];
+        }
+        pr[P_SUM] = sm_sum;
+        pr[P_RSUM] = 1.0f / sm_sum;
+        pr[P_XP] = px.xp;
+        pr[P_YP] = px.yp;
+        reinterpret_cast<unsigned*>(pr)[P_SLOW] = fast_div_range(sm_sum) ? 0u : 1u;
     }
     for (int i = threadIdx.x; i < NB * NACC; i += THREADS) acc[i] = 0.f;
+    unsigned short* qw = queue + wave * QCAP;
+    const float* pix_wave = pix + wave * 64 * PIXREC;
 
     int n = 0;
     for (int c = 0; c < a.F; c += THREADS) {
@@ -555,132 +881,41 @@ __global__ __launch_bounds__(THREADS) void raster_backward_kernel(const RasterAr
         if (n <= LIST_CAP - THREADS && c + THREADS < a.F) continue;
         for (int s = 0; s < n; s += NB) {
             const int cnt = min(NB, n - s);
-            stage_faces<SAMPLE == SCP_SAMPLE_VERTEX>(a, px.bn, list, s, cnt, stage);
+            stage_faces<SAMPLE == SCP_SAMPLE_VERTEX>(a, px.bn, list, s, cnt, stage, bbox);
             __syncthreads();
-            for (int q = 0; q < cnt; q++) {
-                const float* rec = stage + q * REC;
-                const float4 bb = *reinterpret_cast<const float4*>(rec + R_BBOX);
-                float g[18];
-#pragma unroll
-                for (int k = 0; k < 18; k++) g[k] = 0.f;
-                bool active = false;
-                if (px.valid && !(a.dbg & 2) && !(px.xp > bb.y || px.xp < bb.x || px.yp > bb.w || px.yp < bb.z)) {
-                    float v[9];
-#pragma unroll
-                    for (int k = 0; k < 9; k++) v[k] = rec[R_V + k];
-                    Cover cv;
-                    if (pair_coverage(a, cv, v, rec, px.xp, px.yp)) {
-                        float c_xy = 0;
-                        float c_alpha = gimg[3];
-                        if (a.alpha_mode == SCP_ALPHA_SUM) c_alpha /= a.F;
-                        else if (a.alpha_mode == SCP_ALPHA_PROD)
-                            c_alpha = (float)((double)c_alpha *
-                                              ((double)(1 - img[3]) / fmax((double)(1 - cv.frag), 1e-6)));
-                        c_xy += c_alpha;
-
-                        float w[3] = {cv.w[0], cv.w[1], cv.w[2]};
-                        clip_weights(w);
-                        const float zp = (float)(1. / (double)(w[0] / v[2] + w[1] / v[5] + w[2] / v[8]));
-                        if (!(zp < a.near_ || zp > a.far_)) {
-                            active = true;
-                            const unsigned f = reinterpret_cast<const unsigned*>(rec)[R_IDX];
-                            const size_t face_g = (size_t)px.bn * a.F + f;
-                            if (RGB == SCP_RGB_HARD) {
-                                if ((float)(int)f == sm_max) {
-                                    if (SAMPLE == SCP_SAMPLE_VERTEX) {
-#pragma unroll
-                                        for (int k = 0; k < 3; k++)
-#pragma unroll
-                                            for (int j = 0; j < 3; j++) g[9 + 3 * j + k] = w[j] * gimg[k];
-                                    } else {
-                                        const int texel = surface_texel(w, a.R);
-                                        if (texel >= 0 && texel < a.T) {
-                                            float* gt = a.grad_textures + face_g * a.T * 3 + texel * 3;
-#pragma unroll
-                                            for (int k = 0; k < 3; k++) atomicAdd(gt + k, gimg[k]);
-                                        }
-                                    }
-                                }
-                            } else if (front_facing(v) || a.double_side) {
-                                float c_rgb = 0.f;
-                                const float zn = GDIV(a.far_ - zp, a.far_ - a.near_);
-                                const float zs = GDIV(cv.frag * expf(GDIV(zn - sm_max, a.gamma)), sm_sum);
-                                int texel = 0;
-                                if (SAMPLE == SCP_SAMPLE_SURFACE) texel = surface_texel(w, a.R);
-#pragma unroll
-                                for (int k = 0; k < 3; k++) {
-                                    const float gk = gimg[k];
-                                    if (SAMPLE == SCP_SAMPLE_VERTEX) {
-#pragma unroll
-                                        for (int j = 0; j < 3; j++) g[9 + 3 * j + k] = zs * (w[j] * gk);
-                                    } else if (texel >= 0 && texel < a.T) {
-                                        atomicAdd(a.grad_textures + face_g * a.T * 3 + texel * 3 + k, zs * gk);
-                                    }
-                                    const float ck = sample_colour<SAMPLE>(a, rec, face_g, w, k);
-                                    c_rgb += gk * (ck - img[k]);
-                                }
-                                c_rgb *= zs;
-                                c_xy += GDIV(c_rgb, cv.frag);
-                                const float c_z = GDIV(GDIV(c_rgb, a.gamma), a.near_ - a.far_) * zp * zp;
-                                g[2] = GDIV(GDIV(c_z * w[0], v[2]), v[2]);
-                                g[5] = GDIV(GDIV(c_z * w[1], v[5]), v[5]);
-                                g[8] = GDIV(GDIV(c_z * w[2], v[8]), v[8]);
-                            }
-
-                            c_xy *= GDIV(cv.frag * (1 - cv.frag), a.sigma);
-                            if (a.dist_mode == SCP_DIST_EUCLIDEAN) {
-#pragma unroll
-                                for (int k = 0; k < 3; k++) {
-                                    g[3 * k + 0] = 2 * cv.sign * c_xy * (cv.t[k] + cv.w[k]) * cv.dx;
-                                    g[3 * k + 1] = 2 * cv.sign * c_xy * (cv.t[k] + cv.w[k]) * cv.dy;
-                                }
-                            } else if (a.dist_mode == SCP_DIST_BARYCENTRIC) {
-                                // kernel.cu:161-175
-                                const float* t = cv.t;
-                                const float* inv = rec + R_INV;
-                                const int pm = t[0] > t[1] ? (t[1] > t[2] ? 2 : 1) : (t[0] > t[2] ? 2 : 0);
-                                const float scale2 = cv.dis > 0 ? sqrtf(cv.dis) : sqrtf(-cv.dis);
-#pragma unroll
-                                for (int l = 0; l < 2; l++)
-#pragma unroll
-                                    for (int k = 0; k < 3; k++) {
-                                        float gk = 0;
-#pragma unroll
-                                        for (int qq = 0; qq < 3; qq++)
-                                            gk += -inv[3 * pm + l] * inv[3 * k + qq] * (qq == 0 ? px.xp : (qq == 1 ? px.yp : 1.f));
-                                        float r = gk * c_xy;
-                                        r = (float)((double)r * (2. * (double)scale2));
-                                        g[3 * k + l] = r;
-                                    }
-                            }
+            // scan: the surviving pairs of this wavefront's 64 pixels go to the ring face by face, each face's run padded
+            // to whole 16-lane rows; a group of 64 is processed as soon as it exists (and the remainder at the end)
+            int head = 0, tail = 0, q = 0;
+            while (true) {
+                while (tail - head < 64 && q < cnt) {
+                    const float4 bb = bbox[q];
+                    bool hit = px.valid && !(px.xp > bb.y || px.xp < bb.x || px.yp > bb.w || px.yp < bb.z);
+                    if (__ballot(hit) != 0ull) {
+                        hit = hit && !behind_an_edge(stage + q * REC, px.xp, px.yp);
+                        const unsigned long long m = __ballot(hit);
+                        if (m != 0ull) {
+                            const int c_hit = __popcll(m);
+                            if (hit) qw[(tail + __popcll(m & ((1ull << lane) - 1ull))) & (QCAP - 1)] = (unsigned short)(lane | (q << 8));
+                            const int pad = (-(tail + c_hit)) & 15;
+                            if (lane < pad) qw[(tail + c_hit + lane) & (QCAP - 1)] = (unsigned short)(0x8000 | (q << 8));
+                            tail += c_hit + pad;
                         }
                     }
+                    q++;
                 }
-                // wavefront-uniform: nothing to add if no lane produced a term
-                if (__ballot(active) == 0ull) continue;
-                if (a.dbg & 1) { if (g[0] + g[5] + g[11] == 12345.f) acc[0] = 1.f; continue; }
-                float* slot_acc = acc + q * NACC;
-                // the 4 rows (8 groups) of the wavefront are merged by the LDS atomics themselves
-                if (FULL) {
-                    const float g16 = row_sum16(g[16]), g17 = row_sum16(g[17]);
-                    const float r = group_reduce_scatter<16>(g);
-                    const int l16 = lane & 15;
-                    atomicAdd(slot_acc + l16, r);
-                    if (l16 < 2) atomicAdd(slot_acc + 16 + l16, l16 == 0 ? g16 : g17);
-                } else {
-                    float h[8] = {g[0], g[1], g[3], g[4], g[6], g[7], 0.f, 0.f};
-                    const float r = group_reduce_scatter<8>(h);
-                    const int l8 = lane & 7;
-                    if (l8 < 6) atomicAdd(slot_acc + (l8 + (l8 >> 1)), r);  // 0,1,3,4,6,7
-                }
+                if (tail == head) break;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                const int n_valid = min(64, tail - head);
+                backward_group<RGB, SAMPLE>(a, stage, pix_wave, acc, qw, head, n_valid, px.bn);
+                head += n_valid;
             }
             __syncthreads();
             // flush the per-batch accumulators: one global atomic per (tile, face, component)
             for (int i = threadIdx.x; i < cnt * NACC; i += THREADS) {
-                const int q = i / NACC, j = i - q * NACC;
+                const int qq = i / NACC, j = i - qq * NACC;
                 const float val = acc[i];
                 if (val != 0.f) {
-                    const unsigned f = reinterpret_cast<const unsigned*>(stage + q * REC)[R_IDX];
+                    const unsigned f = reinterpret_cast<const unsigned*>(stage + qq * REC)[R_IDX];
                     const size_t face_g = (size_t)px.bn * a.F + f;
                     if (j < 9) atomicAdd(a.grad_faces + face_g * 9 + j, val);
                     else atomicAdd(a.grad_textures + face_g * 9 + (j - 9), val);
@@ -697,7 +932,7 @@ __global__ __launch_bounds__(THREADS) void raster_backward_kernel(const RasterAr
 // instrumentation: bbox-surviving (pixel, face) pairs
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(THREADS) void count_pairs_kernel(const RasterArgs a) {
-    __shared__ __attribute__((aligned(16))) float stage[NB * REC];
+    __shared__ float4 bbox[NB];
     __shared__ unsigned list[LIST_CAP];
     __shared__ int wave_cnt[4];
     const int tile_id = logical_tile(a);
@@ -712,20 +947,15 @@ __global__ __launch_bounds__(THREADS) void count_pairs_kernel(const RasterArgs a
         if (n <= LIST_CAP - THREADS && c + THREADS < a.F) continue;
         for (int s = 0; s < n; s += NB) {
             const int cnt = min(NB, n - s);
-            // only the bbox part of the record is needed, but faces_info may be absent here
-            const int slot = threadIdx.x >> 3, part = threadIdx.x & 7;
-            if (slot < cnt && part == 0) {
-                const float* fv = a.faces + ((size_t)px.bn * a.F + list[s + slot]) * 9;
-                float* rec = stage + slot * REC;
-                rec[0] = min3f(fv[0], fv[3], fv[6]) - a.margin;
-                rec[1] = max3f(fv[0], fv[3], fv[6]) + a.margin;
-                rec[2] = min3f(fv[1], fv[4], fv[7]) - a.margin;
-                rec[3] = max3f(fv[1], fv[4], fv[7]) + a.margin;
+            if ((int)threadIdx.x < cnt) {
+                const float* fv = a.faces + ((size_t)px.bn * a.F + list[s + threadIdx.x]) * 9;
+                bbox[threadIdx.x] = make_float4(min3f(fv[0], fv[3], fv[6]) - a.margin, max3f(fv[0], fv[3], fv[6]) + a.margin,
+                                                min3f(fv[1], fv[4], fv[7]) - a.margin, max3f(fv[1], fv[4], fv[7]) + a.margin);
             }
             __syncthreads();
             if (px.valid)
                 for (int q = 0; q < cnt; q++) {
-                    const float4 bb = *reinterpret_cast<const float4*>(stage + q * REC);
+                    const float4 bb = bbox[q];
                     mine += !(px.xp > bb.y || px.xp < bb.x || px.yp > bb.w || px.yp < bb.z);
                 }
             __syncthreads();
@@ -737,6 +967,30 @@ __global__ __launch_bounds__(THREADS) void count_pairs_kernel(const RasterArgs a
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) lo += __shfl_xor(lo, m);
     if ((threadIdx.x & 63) == 0) atomicAdd(a.counter, (unsigned long long)lo);
+}
+
+// self-test of xdiv: n (a, b) pairs from a counter-based generator, mantissas uniform, exponents of b in +-2^40 and of a
+// in +-2^60 around it, a share of adversarial mantissas (all ones / one / powers of two); counts xdiv(a,b,RN(1/b)) != a/b
+__global__ void exact_division_selftest_kernel(unsigned long long n, unsigned seed, unsigned long long* mismatches) {
+    unsigned long long bad = 0;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        unsigned long long x = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+        x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+        unsigned ma = (unsigned)x & 0x7FFFFFu, mb = (unsigned)(x >> 23) & 0x7FFFFFu;
+        const unsigned kind = (unsigned)(x >> 46) & 15u;
+        if (kind == 0) mb = 0x7FFFFFu; else if (kind == 1) mb = 0u; else if (kind == 2) mb = 1u; else if (kind == 3) ma = 0x7FFFFFu;
+        else if (kind == 4) { ma = 0u; } else if (kind == 5) { mb = 0x7FFFFEu; ma = 1u; }
+        const int eb = 127 + (int)((x >> 50) % 81u) - 40;
+        const int ea = eb + (int)((x >> 57) % 121u) - 60;
+        const float b = __uint_as_float(((unsigned)(x >> 63) << 31) | ((unsigned)eb << 23) | mb);
+        const float av = __uint_as_float((((unsigned)(x >> 62) & 1u) << 31) | ((unsigned)max(1, min(ea, 254)) << 23) | ma);
+        const float y = 1.0f / b;
+        const float q = fast_div_range(b) ? xdiv<true>(av, b, y) : xdiv<false>(av, b, y);
+        const float r = av / b;
+        bad += __float_as_uint(q) != __float_as_uint(r);
+    }
+    if (bad) atomicAdd(mismatches, bad);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -761,8 +1015,14 @@ int fill_args(RasterArgs& a, const scp_raster_params* p) {
     a.dist_eps = p->dist_eps; a.gamma = p->gamma_val;
     a.threshold = p->dist_eps * p->sigma_val;  // kernel.cu:352 (fp32 product)
     a.margin = sqrtf(a.threshold);             // kernel.cu:375 (fp32 sqrt)
+    a.range = a.far_ - a.near_;                // kernel.cu:423 forms (far - near) in fp32
+    a.nrange = a.near_ - a.far_;               // kernel.cu:637
+    a.rcp_sigma = 1.0f / a.sigma; a.rcp_gamma = 1.0f / a.gamma;
+    a.rcp_range = 1.0f / a.range; a.rcp_nrange = 1.0f / a.nrange;
+    a.const_slow = !(fast_div_range(a.sigma) && fast_div_range(a.gamma) && fast_div_range(a.range));
     a.dist_mode = p->func_id_dist; a.alpha_mode = p->func_id_alpha; a.double_side = p->double_side != 0;
-    a.dbg = g_debug_flags;
+    if (getenv("SCP_DBG_SLOW")) a.const_slow = 1;   /*DBG*/
+    if (getenv("SCP_DBG_NOPRE")) a.dbg_nopre = 1;   /*DBG*/
     return 0;
 }
 
@@ -789,8 +1049,6 @@ template <int RGB, int SAMPLE> struct BwdLaunch {
 
 }  // namespace
 
-extern "C" void scpdbg_set_flags(int flags) { g_debug_flags = flags; }
-
 extern "C" int scp_soft_rasterize_forward(const float* faces, const float* textures, float* faces_info,
                                           float* aggrs_info, float* soft_colors,
                                           const scp_raster_params* p, void* stream) {
@@ -806,6 +1064,29 @@ extern "C" int scp_soft_rasterize_forward(const float* faces, const float* textu
         if (int e = scp::check_launch("face_setup")) return e;
     }
     return dispatch<FwdLaunch>(a, p->func_id_rgb, p->texture_sample_type, st);
+}
+
+extern "C" int scp_soft_rasterize_forward_dual(const float* faces, const float* textures, float* faces_info,
+                                               float* aggrs_info, float* soft_colors, const float* textures_hard,
+                                               float* aggrs_info_hard, float* soft_colors_hard,
+                                               const scp_raster_params* p, void* stream) {
+    RasterArgs a{};
+    if (int e = fill_args(a, p)) return e;
+    if (p->func_id_rgb != SCP_RGB_SOFTMAX || p->texture_sample_type != SCP_SAMPLE_VERTEX)
+        return scp::fail(hipErrorInvalidValue, "forward_dual: the primary pass must be softmax rgb with vertex textures");
+    if (a.B == 0 || a.total_tiles == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    a.faces = faces; a.textures = textures; a.faces_info = faces_info;
+    a.aggrs_info = aggrs_info; a.soft_colors = soft_colors;
+    a.textures2 = textures_hard; a.aggrs_info2 = aggrs_info_hard; a.soft_colors2 = soft_colors_hard;
+    const int nf = a.B * a.F;
+    if (nf > 0) {
+        hipLaunchKernelGGL(face_setup_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, faces, faces_info, nf);
+        if (int e = scp::check_launch("face_setup")) return e;
+    }
+    hipLaunchKernelGGL((raster_forward_kernel<SCP_RGB_SOFTMAX, SCP_SAMPLE_VERTEX, true>), dim3(a.tiles_per_xcd * 8),
+                       dim3(THREADS), 0, st, a);
+    return scp::check_launch("soft_rasterize_forward_dual");
 }
 
 extern "C" int scp_soft_rasterize_backward(const float* faces, const float* textures,
@@ -831,4 +1112,11 @@ extern "C" int scp_soft_rasterize_count_pairs(const float* faces, unsigned long 
     hipLaunchKernelGGL(count_pairs_kernel, dim3(a.tiles_per_xcd * 8), dim3(THREADS), 0,
                        static_cast<hipStream_t>(stream), a);
     return scp::check_launch("count_pairs");
+}
+
+extern "C" int scp_selftest_exact_division(unsigned long long n, unsigned seed, unsigned long long* mismatches,
+                                           void* stream) {
+    hipLaunchKernelGGL(exact_division_selftest_kernel, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), n, seed,
+                       mismatches);
+    return scp::check_launch("exact_division_selftest");
 }

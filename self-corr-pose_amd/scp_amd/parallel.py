@@ -43,7 +43,7 @@ class FlatGradients:
             if cur and (off + n - lo) * p.element_size() > bucket_bytes:
                 self.buckets.append((lo, off, cur))
                 lo, cur = off, []
-            self.views[id(p)] = self.flat[off:off + n].view_as(p)
+            self.views[id(p)] = self._view_like(p, off)
             self.span[id(p)] = (off, n)
             self.bucket_of[id(p)] = len(self.buckets)
             cur.append(p)
@@ -59,6 +59,17 @@ class FlatGradients:
         if self.world > 1:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _view_like(self, p, off):
+        """a view of flat[off : off + p.numel()] with p's sizes AND strides: the fused optimizer requires gradients in the
+        parameter's own layout (the encoder's convolution weights are channels_last)"""
+        dims = sorted(range(p.dim()), key=lambda d: p.stride(d), reverse=True)
+        expect, dense = 1, True
+        for d in reversed(dims):
+            dense &= p.size(d) == 1 or p.stride(d) == expect
+            expect *= p.size(d)
+        assert dense, "parameter is neither contiguous nor a dense permutation"
+        return torch.as_strided(self.flat, p.size(), p.stride(), off)
 
     # ------------------------------------------------------------------------------------------------
     def broadcast_parameters(self, module=None, src=0):

@@ -2,15 +2,16 @@
 
 API and semantics of model/module/renderer.py (Renderer.__init__ :11-27, render_mean_mesh :29-36,
 render_all :38-73).  The pass configurations (sigma, gamma, aggregation, background) are the
-reference's.  Exact savings taken here: the canonical-xyz ("hardtex") pass runs without autograd
-because its backward is identically zero (detached vertices/colours, hard colours carry no
-geometry gradient and its alpha is only thresholded) -- SURVEY F8.
+reference's.  Exact savings taken here: the mask is the depth pass' alpha plane, the
+canonical-xyz ("hardtex") pass is a second colour output of the depth pass' launch and carries no
+backward (detached vertices/colours, hard colours have no geometry gradient, its alpha is only
+thresholded) -- four reference passes = two forward launches + two backward launches.
 """
 import torch
 import torch.nn.functional as F
 
 from . import soft_renderer as sr
-from .losses import pinhole_cam, render
+from .losses import pinhole_cam, project_for_render, render
 
 
 class Renderer:
@@ -50,16 +51,26 @@ class Renderer:
         else:
             tex_mask = tex_render = None
 
-        depth_out = render(self.renderer_depth, pred_v, faces, None, *cam, render_depth=True, texture_type="vertex")
+        # The canonical-xyz ("hardtex") pass rasterises the same projected faces with the same sigma / distance /
+        # alpha functions as the depth pass (renderer.py:17-24: only gamma and the rgb aggregation differ), and its
+        # inputs are detached values of the same tensors: every coverage decision is shared, so it rides on the depth
+        # pass' launch as a second colour output (scp_soft_rasterize_forward_dual; bit-identical images, asserted in
+        # tests/test_softras_gpu.py).  It has no backward in the reference either.
+        canon = pred_v.detach()
+        fuse_hard = pred_v.is_cuda and getattr(self, "share_hardtex_with_depth", True)
+        if fuse_hard:
+            verts = project_for_render(pred_v, *cam)
+            depth_out, match_out = self.renderer_depth.render_mesh_with_hard(
+                sr.Mesh(verts, faces, verts, texture_type="vertex"), self.renderer_hardtex, canon)
+        else:
+            depth_out = render(self.renderer_depth, pred_v, faces, None, *cam, render_depth=True, texture_type="vertex")
+            with torch.no_grad():  # zero backward in the reference as well (F8)
+                match_out = render(self.renderer_hardtex, canon, faces, canon, *cam, texture_type="vertex")
         if fuse_mask:
             mask_render = depth_out[:, 3]
         if not self.opts.use_depth:
             depth_out = depth_out.detach()
         depth_mask, depth_render = depth_out[:, 3], depth_out[:, 2].clone()
-
-        with torch.no_grad():  # zero backward in the reference as well (F8)
-            canon = pred_v.detach()
-            match_out = render(self.renderer_hardtex, canon, faces, canon, *cam, texture_type="vertex")
         match_mask, match_gt = match_out[:, -1], match_out[:, :3]
 
         # projected vertex positions: differentiable w.r.t. rotation / translation (renderer.py:63-67)

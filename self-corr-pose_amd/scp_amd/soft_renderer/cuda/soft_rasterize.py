@@ -32,6 +32,24 @@ def forward_soft_rasterize(faces, textures, faces_info, aggrs_info, soft_colors,
     return [faces_info, aggrs_info, soft_colors]
 
 
+def forward_soft_rasterize_dual(faces, textures, faces_info, aggrs_info, soft_colors, textures_hard, aggrs_info_hard,
+                                soft_colors_hard, image_size, near, far, eps, sigma_val, func_id_dist, dist_eps,
+                                gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side):
+    """two forward_soft_rasterize calls that share their coverage (softmax-rgb primary + hard-rgb secondary on the same
+    projected faces, same sigma / dist / alpha functions) as ONE launch: include/scp_hip.h scp_soft_rasterize_forward_dual.
+    The scalars are the primary pass' (the reference's argument order); buffers follow the reference's protocol."""
+    p = _params(faces, textures, image_size, near, far, eps, sigma_val, func_id_dist, dist_eps,
+                gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side)
+    code = capi.lib().scp_soft_rasterize_forward_dual(
+        capi.dev_ptr(faces, "faces"), capi.dev_ptr(textures, "textures"),
+        capi.dev_ptr(faces_info, "faces_info"), capi.dev_ptr(aggrs_info, "aggrs_info"),
+        capi.dev_ptr(soft_colors, "soft_colors"), capi.dev_ptr(textures_hard, "textures_hard"),
+        capi.dev_ptr(aggrs_info_hard, "aggrs_info_hard"), capi.dev_ptr(soft_colors_hard, "soft_colors_hard"),
+        p, capi.current_stream())
+    capi.check(code, "scp_soft_rasterize_forward_dual")
+    return [faces_info, aggrs_info, soft_colors, aggrs_info_hard, soft_colors_hard]
+
+
 def backward_soft_rasterize(faces, textures, soft_colors, faces_info, aggrs_info, grad_faces,
                             grad_textures, grad_soft_colors, image_size, near, far, eps, sigma_val,
                             func_id_dist, dist_eps, gamma_val, func_id_rgb, func_id_alpha,

@@ -76,6 +76,57 @@ def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0,
                                        aggr_func_rgb, aggr_func_alpha, texture_type)
 
 
+class SoftRasterizeDualFunction(Function):
+    """SoftRasterizeFunction for the depth-style pass (softmax rgb, vertex textures) that ALSO emits the hard-rgb image of
+    a second vertex-texture set over the same coverage (model/module/renderer.py:52-61: `renderer_depth` and
+    `renderer_hardtex` share sigma, distance and alpha functions and the projected geometry) -- one launch
+    instead of two.  The second image carries no gradient (its inputs are detached in the reference and hard colours have
+    none w.r.t. geometry); backward is the primary pass' backward, unchanged."""
+
+    @staticmethod
+    def forward(ctx, face_vertices, textures, textures_hard, image_size, background_color, background_color_hard,
+                near, far, fill_back, eps, sigma_val, dist_func, dist_eps, gamma_val, aggr_func_alpha):
+        ctx.scalars = (int(image_size), float(near), float(far), float(eps), float(sigma_val),
+                       DIST_IDS[dist_func], float(np.log(1. / dist_eps - 1.)), float(gamma_val),
+                       RGB_IDS["softmax"], ALPHA_IDS[aggr_func_alpha], SAMPLE_IDS["vertex"], bool(fill_back))
+        nb, nf = face_vertices.shape[:2]
+        fv = face_vertices.detach().reshape(nb, nf, 9).contiguous()
+        tex = textures.detach().reshape(nb, nf, 3, 3).contiguous()
+        tex_h = textures_hard.detach().reshape(nb, nf, 3, 3).contiguous()
+        dev = fv.device
+        faces_info = torch.zeros(nb, nf, 27, dtype=torch.float32, device=dev)
+        aggrs = torch.zeros(2, nb, 2, image_size, image_size, dtype=torch.float32, device=dev)
+        cols = torch.ones(2, nb, 4, image_size, image_size, dtype=torch.float32, device=dev)
+        for i, bg in enumerate((background_color, background_color_hard)):
+            for k in range(3):
+                if bg[k] != 1:
+                    cols[i, :, k].fill_(float(bg[k]))
+        soft, hard = cols[0], cols[1]
+        _native.forward_soft_rasterize_dual(fv, tex, faces_info, aggrs[0], soft, tex_h, aggrs[1], hard, *ctx.scalars)
+        ctx.save_for_backward(fv, tex, soft, faces_info, aggrs[0])
+        ctx.in_shapes = (face_vertices.shape, textures.shape)
+        ctx.mark_non_differentiable(hard)
+        return soft, hard
+
+    @staticmethod
+    def backward(ctx, grad_soft_colors, _grad_hard):
+        fv, tex, soft_colors, faces_info, aggrs_info = ctx.saved_tensors
+        grad_faces = torch.zeros_like(fv)
+        grad_textures = torch.zeros_like(tex)
+        _native.backward_soft_rasterize(fv, tex, soft_colors, faces_info, aggrs_info, grad_faces,
+                                        grad_textures, grad_soft_colors.contiguous(), *ctx.scalars)
+        return (grad_faces.reshape(ctx.in_shapes[0]), grad_textures.reshape(ctx.in_shapes[1])) + (None,) * 13
+
+
+def soft_rasterize_dual(face_vertices, textures, textures_hard, image_size=256, background_color=[0, 0, 0],
+                        background_color_hard=[0, 0, 0], near=1, far=100, fill_back=True, eps=1e-3, sigma_val=1e-5,
+                        dist_func="euclidean", dist_eps=1e-4, gamma_val=1e-4, aggr_func_alpha="prod"):
+    """-> (softmax-rgb image of `textures`, hard-rgb image of `textures_hard`), both [B,4,S,S]"""
+    return SoftRasterizeDualFunction.apply(face_vertices, textures, textures_hard, image_size, background_color,
+                                           background_color_hard, near, far, fill_back, eps, sigma_val, dist_func,
+                                           dist_eps, gamma_val, aggr_func_alpha)
+
+
 class _SharedTopologyGather(Function):
     """vertices[:, faces] for ONE face list shared by the batch.  Backward = incidence^T-matmul
     (a [V, 3F] 0/1 matrix times the face gradients): deterministic and ~30x faster on the GPU than the

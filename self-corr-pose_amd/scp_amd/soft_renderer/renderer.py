@@ -148,5 +148,25 @@ class SoftRenderer(nn.Module):
         mesh = self.transform(mesh)
         return self.rasterizer(mesh, mode)
 
+    def render_mesh_with_hard(self, mesh, hard_renderer, hard_textures):
+        """render_mesh(mesh) with this (softmax-rgb, vertex-texture) renderer AND hard_renderer.render_mesh(Mesh(same
+        vertices, same faces, hard_textures, 'vertex')) in one rasteriser launch.  Legal only when both renderers
+        produce the same coverage: same image size, sigma, distance / alpha functions, clipping and camera -- checked."""
+        ra, rb = self.rasterizer, hard_renderer.rasterizer
+        same = ("image_size", "near", "far", "anti_aliasing", "fill_back", "eps", "sigma_val", "dist_func", "dist_eps",
+                "aggr_func_alpha")
+        if (any(getattr(ra, k) != getattr(rb, k) for k in same) or ra.aggr_func_rgb != "softmax" or rb.aggr_func_rgb != "hard"
+                or mesh.texture_type != "vertex" or ra.anti_aliasing
+                or self.transform.transformer._eye != hard_renderer.transform.transformer._eye):
+            raise ValueError("render_mesh_with_hard: the two renderers do not share their coverage")
+        self.set_texture_mode("vertex")
+        hard_renderer.set_texture_mode("vertex")
+        hard = hard_renderer.lighting(Mesh(mesh.vertices, mesh.faces, hard_textures, texture_type="vertex"))
+        mesh = self.transform(self.lighting(mesh))
+        return srf.soft_rasterize_dual(mesh.face_vertices, mesh.face_textures, srf.face_vertices(hard.textures, hard.faces),
+                                       ra.image_size, ra.background_color, rb.background_color, ra.near, ra.far,
+                                       ra.fill_back, ra.eps, ra.sigma_val, ra.dist_func, ra.dist_eps, ra.gamma_val,
+                                       ra.aggr_func_alpha)
+
     def forward(self, vertices, faces, textures=None, mode=None, texture_type="surface"):
         return self.render_mesh(Mesh(vertices, faces, textures=textures, texture_type=texture_type), mode)

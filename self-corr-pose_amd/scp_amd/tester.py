@@ -49,7 +49,8 @@ class Tester:
     def define_model(self):
         torch.backends.cudnn.benchmark = True
         if self.device.type == "cuda":
-            torch.cuda.set_device(self.device)      # the C-ABI launches use the current device's current stream
+            if self.device.index is not None:
+                torch.cuda.set_device(self.device)      # the C-ABI launches use the current device's current stream
             enable_gemm_tuning()
         self.model = MeshNet(self.opts, self.prior)
         if self.opts.model_path:

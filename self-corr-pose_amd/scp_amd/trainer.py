@@ -60,7 +60,8 @@ class Trainer:
         if self.device.type == "cuda":
             # the C-ABI launches go to the CURRENT device's current stream (scp_amd/capi.py): make the trainer's
             # device the current one so that Trainer(device="cuda:1") in a process sitting on cuda:0 cannot mix devices
-            torch.cuda.set_device(self.device)
+            if self.device.index is not None:
+                torch.cuda.set_device(self.device)
             enable_gemm_tuning()
         # the rotation-cycle branch runs on a side stream (model.py); its parameters' AccumulateGrad nodes
         # then see gradients from two streams, which autograd synchronises correctly but warns about

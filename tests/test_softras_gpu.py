@@ -218,3 +218,73 @@ def test_full_size_properties(full_scene):
     n_gpu = native.count_pairs(fv_t[:3].reshape(3, 1280, 9).contiguous(), 256, 1e-4, float(np.log(1. / 1e-4 - 1.)))
     n_cpu = oracle.count_pairs(np.ascontiguousarray(fv[:3].reshape(3, 1280, 9)), 256, 1e-4, float(np.log(1. / 1e-4 - 1.)))
     assert n_gpu == n_cpu
+
+
+def test_exact_division_by_hoisted_divisor_is_bit_identical_to_ieee_division():
+    """csrc/softras.hip replaces a / b by q = a * RN(1/b) + two fused residual corrections wherever b is a face / pixel /
+    pass constant; the coverage decisions and the knife-edge gamma = 1e-4 softmax need the IEEE quotient exactly: 2^31
+    generated operand pairs (uniform + adversarial mantissas), zero mismatches allowed"""
+    import ctypes
+    from scp_amd import capi
+    bad = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for seed in (1, 2):
+        capi.check(capi.lib().scp_selftest_exact_division(ctypes.c_ulonglong(1 << 30), seed, ctypes.c_void_p(bad.data_ptr()),
+                                                          capi.current_stream()), "selftest")
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0, "%d of 2^31 quotients differ from IEEE division" % int(bad.item())
+
+
+def test_dual_forward_equals_two_separate_passes_bit_for_bit():
+    """scp_soft_rasterize_forward_dual (depth pass + canonical-colour hard pass in one launch) against two
+    scp_soft_rasterize_forward calls: both images, both aggregate buffers and the backward of the primary pass"""
+    from scp_amd.soft_renderer import functional as srf
+    v, f = scenes.bottle_like(3)
+    fv, ftex = scenes.raster_inputs(v, f, 5, seed=31, tex="depth")
+    _, fcanon = scenes.raster_inputs(v, f, 5, seed=31, tex="canon")
+    for size in (256, 100):
+        common = dict(image_size=size, dist_func="euclidean", aggr_func_alpha="prod")
+        fv_a = torch.tensor(fv, device=DEV, requires_grad=True)
+        tex_a = torch.tensor(ftex, device=DEV, requires_grad=True)
+        canon = torch.tensor(fcanon, device=DEV)
+        depth = srf.soft_rasterize(fv_a, tex_a, **common, **PASSES["depth"])
+        hard = srf.soft_rasterize(fv_a.detach(), canon, **common, **PASSES["hardtex"])
+        fv_b = torch.tensor(fv, device=DEV, requires_grad=True)
+        tex_b = torch.tensor(ftex, device=DEV, requires_grad=True)
+        depth2, hard2 = srf.soft_rasterize_dual(fv_b, tex_b, canon, size, PASSES["depth"]["background_color"],
+                                                PASSES["hardtex"]["background_color"], sigma_val=1e-4, gamma_val=1e-4)
+        assert torch.equal(depth, depth2) and torch.equal(hard, hard2)
+        assert not hard2.requires_grad
+        g = torch.randn(depth.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(size))
+        depth.backward(g)
+        depth2.backward(g)
+        # same kernel, same inputs; only the unordered atomics differ
+        assert torch.linalg.norm(fv_a.grad - fv_b.grad) <= 2e-5 * torch.linalg.norm(fv_a.grad)
+        assert torch.linalg.norm(tex_a.grad - tex_b.grad) <= 2e-5 * torch.linalg.norm(tex_a.grad)
+
+
+def test_render_all_fused_equals_unfused():
+    """Renderer.render_all with the hardtex pass riding on the depth launch == the four-pass form, output by output"""
+    import scp_amd.dino as dino
+    from scp_amd.flags import Options
+    from scp_amd.model import MeshNet
+    dino.ALLOW_RANDOM_INIT = True
+    opts = Options("laptop_wild6d", batch_size=1, repeat=3, train=True)
+    torch.manual_seed(0)
+    model = MeshNet(opts, prior=scenes.bottle_like(3)).to(DEV)
+    B, V = 3, model.mesh.num_verts
+    g = torch.Generator().manual_seed(5)
+    pred_v = (model.mesh.mean_v.detach().cpu()[None] + 0.01 * torch.randn(B, V, 3, generator=g)).to(DEV)
+    tex = torch.rand(B, V, 3, generator=g).to(DEV)
+    rot = torch.tensor(scenes.random_rotations(B, np.random.default_rng(1)), dtype=torch.float32, device=DEV)
+    trans = torch.tensor([[[0.02, -0.03, 5.1]]], device=DEV).repeat(B, 1, 1)
+    foc = torch.full((B, 2), 5.9, device=DEV)
+    pp = torch.zeros(B, 2, device=DEV)
+    faces = model.mesh.faces[None].expand(B, -1, -1)
+    r = model.renderer
+    r.share_hardtex_with_depth = True
+    fused = r.render_all(pred_v, faces, tex, foc, pp, rot, trans, None)
+    r.share_hardtex_with_depth = False
+    plain = r.render_all(pred_v, faces, tex, foc, pp, rot, trans, None)
+    r.share_hardtex_with_depth = True
+    for a, b in zip(fused, plain):
+        assert torch.equal(a, b)

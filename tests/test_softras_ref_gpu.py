@@ -182,3 +182,42 @@ def test_reference_fp64_instantiation_bounds_the_fp32_error():
               "reference %.2e rel" % (ch, m64, abs(m_ref - m64) / abs(m64), abs(m_prod - m64) / abs(m64), abs(m_prod - m_ref) / abs(m64)))
         assert abs(m_prod - m_ref) <= 1e-5 * abs(m64)            # product == fp32 reference (un-contracted) to 1e-5
         assert abs(m_prod - m64) <= 1.05 * abs(m_ref - m64) + 1e-6 * abs(m64)   # and no further from the fp64 truth than it
+
+
+@pytest.mark.parametrize("pname", ["depth", "softtex"])
+def test_sliver_and_degenerate_faces_against_reference_kernels(pname):
+    """adversarial geometry for the hoisted-divisor and early-out machinery of csrc/softras.hip: thin slivers (heights
+    1e-4 .. 1e-2 NDC, |barycentric weights| in the hundreds), tiny and huge faces, exactly degenerate faces (zero area,
+    repeated corners), faces partly off screen -- every pixel against the reference's own kernels"""
+    rng = np.random.default_rng(7)
+    n_f, size = 1500, 160
+    a = rng.uniform(-1.1, 1.1, (2, n_f, 2))
+    ang = rng.uniform(0, 2 * np.pi, (2, n_f))
+    length = 10 ** rng.uniform(-2.2, -0.3, (2, n_f))
+    height = length * 10 ** rng.uniform(-3.5, 0, (2, n_f))
+    d = np.stack((np.cos(ang), np.sin(ang)), -1)
+    nrm = np.stack((-np.sin(ang), np.cos(ang)), -1)
+    b = a + d * length[..., None]
+    c = a + d * (length * rng.uniform(-0.2, 1.2, (2, n_f)))[..., None] + nrm * height[..., None] * rng.choice([-1, 1], (2, n_f))[..., None]
+    tri = np.stack((a, b, c), 2)                                  # [2, F, 3, 2]
+    z = rng.uniform(3.0, 9.0, (2, n_f, 3, 1))
+    fv = np.concatenate((tri, z), -1).astype(np.float32)
+    fv[0, 10] = fv[0, 10, :1]                                     # all three corners identical
+    fv[0, 11, 2] = fv[0, 11, 1]                                   # two corners identical
+    fv[1, 12, 2, :2] = 0.5 * (fv[1, 12, 0, :2] + fv[1, 12, 1, :2])  # collinear
+    ftex = rng.uniform(0, 1, (2, n_f, 3, 3)).astype(np.float32)
+    grad = rng.standard_normal((2, 4, size, size)).astype(np.float32)
+    kw = dict(image_size=size, dist_func="euclidean", aggr_func_alpha="prod", **PASSES[pname])
+    got = hip_render(fv, ftex, grad, **kw)
+    ref = ref_as_golden(ref_gpu.render(fv, ftex, grad_soft_colors=grad, variant="nocontract", **kw), got)
+    finite = np.isfinite(ref["soft_colors"]).all(1, keepdims=True) & np.isfinite(ref["aggrs_info"]).all(1, keepdims=True)
+    print("%s: %.4f of the reference's pixels finite" % (pname, finite.mean()))
+    np.testing.assert_array_equal(got["faces_info"], ref["faces_info"])
+    for key in ("soft_colors", "aggrs_info"):
+        m = np.broadcast_to(finite, ref[key].shape)
+        dlt = np.abs(got[key].astype(np.float64) - ref[key])[m]
+        tol = (2e-6 + 1e-5 * np.abs(ref[key]))[m]
+        assert (dlt <= tol).all(), "%s: %d px out of tolerance, max %.3e" % (key, (dlt > tol).sum(), dlt.max())
+    ok = np.isfinite(ref["grad_faces"]) & np.isfinite(got["grad_faces"])
+    scale = np.abs(ref["grad_faces"][ok]).max()
+    assert np.abs(got["grad_faces"] - ref["grad_faces"])[ok].max() <= 1e-4 * scale

@@ -130,3 +130,24 @@ def test_resnet18_imagenet_weights_are_required_or_loaded(tmp_path):
             nets.ResNet_Encoder(str(tmp_path / "bad.pth"))
     finally:
         dino.ALLOW_RANDOM_INIT = saved
+
+
+def test_flat_gradient_views_follow_the_parameter_layout():
+    """channels_last convolution weights get channels_last gradient views (fused AdamW requires equal layouts), all views
+    tile one flat buffer, and backward accumulates into them in place"""
+    from scp_amd.parallel import FlatGradients
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 1)).to(memory_format=torch.channels_last)
+    fg = FlatGradients(net.parameters(), distributed=False)
+    fg.prepare()
+    for p in net.parameters():
+        assert p.grad.stride() == p.stride() and p.grad.shape == p.shape
+    x = torch.randn(2, 3, 5, 5)
+    net(x).square().sum().backward()
+    expect = torch.autograd.grad(net(x).square().sum(), list(net.parameters()))
+    flat = fg.finish()
+    assert flat.data_ptr() == fg.flat.data_ptr()
+    for p, e in zip(net.parameters(), expect):
+        assert p.grad.data_ptr() == fg.views[id(p)].data_ptr()
+        torch.testing.assert_close(p.grad, e)
+    assert abs(float(flat.abs().sum()) - float(sum(e.abs().sum() for e in expect))) < 1e-3 * float(flat.abs().sum())

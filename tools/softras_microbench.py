@@ -11,8 +11,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "self-corr-pose_amd"))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import scenes  # noqa: E402
+from scp_amd import synthetic as scenes  # noqa: E402
 from scp_amd.soft_renderer import functional as srf  # noqa: E402
 from scp_amd.soft_renderer.cuda import soft_rasterize as native  # noqa: E402
 
