@@ -98,6 +98,21 @@ int scp_soft_rasterize_count_pairs(const float* faces, unsigned long long* count
  * results to *mismatches (one device uint64, caller-zeroed).  Expected: 0. */
 int scp_selftest_exact_division(unsigned long long n, unsigned seed, unsigned long long* mismatches, void* stream);
 
+/* ---- DINO ViT-S/8 linear layers on the fp32 matrix cores, LayerNorm / bias / GELU / residual fused (csrc/vit_gemm.hip) ----
+ * Replaces the nn.Linear calls of third-party/zsp/zsp/method/vision_transformer_flexible.py:54-70 (Mlp: fc1, GELU, fc2),
+ * :85-101 (Attention: qkv, proj) together with the LayerNorms and residual adds of Block.forward (:126-132).
+ *   C[M,N] = epilogue(A[M,K] W[N,K]^T)        A, W, C row-major fp32, K a multiple of 32
+ *   SCP_GEMM_BIAS            C = acc + vec0[n]                                   (vec0 = bias)
+ *   SCP_GEMM_BIAS_RESIDUAL   C = acc + vec0[n] + resid[m,n]                      (resid may alias C: in-place residual stream)
+ *   SCP_GEMM_LN              C = rstd[m] * (acc - mean[m] * vec0[n]) + vec1[n]   = LayerNorm(A) Wo^T + b when W = gamma o Wo,
+ *                            vec0[n] = sum_k W[n,k], vec1[n] = sum_k beta[k] Wo[n,k] + b[n], rowstat = scp_row_mean_rstd(A)
+ *   SCP_GEMM_LN_GELU         the same followed by the erf GELU */
+enum { SCP_GEMM_BIAS = 0, SCP_GEMM_BIAS_RESIDUAL = 1, SCP_GEMM_LN = 2, SCP_GEMM_LN_GELU = 3 };
+int scp_vit_linear(const float* A, const float* W, const float* vec0, const float* vec1, const float* rowstat,
+                   const float* resid, float* C, int M, int N, int K, int epilogue, void* stream);
+/* stats[rows,2] = (mean, 1/sqrt(biased var + eps)) of every row of x[rows,C] (nn.LayerNorm's statistics), C <= 1536 */
+int scp_row_mean_rstd(const float* x, float* stats, int rows, int C, float eps, void* stream);
+
 /* ---- dense correspondence: masked softmax / soft-argmax over an all-pairs score tensor ------------
  * scores S[N,P,Q], Q contiguous.  A score is "masked" (treated as the constant -1e5, like
  * model/module/correspondence.py:44 and pretrained_corr.py:86) when rowmask[n,p] <= 0 or

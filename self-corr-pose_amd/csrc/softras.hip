@@ -35,7 +35,6 @@
 
 #include "scp_hip.h"
 #include "scp_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -91,7 +90,6 @@ struct RasterArgs {
     float rcp_sigma, rcp_gamma, rcp_range, rcp_nrange;    // RN(1 / x) of the pass constants
     int const_slow;                                       // a pass constant is outside the exact-division range
     int dist_mode, alpha_mode, double_side;
-    int dbg_nopre; /*DBG*/
 };
 
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
@@ -303,7 +301,7 @@ __device__ __forceinline__ void stage_faces(const RasterArgs& a, int bn, const u
                 const float gj = sqrtf(fi[3 * j] * fi[3 * j] + fi[3 * j + 1] * fi[3 * j + 1]);
                 err += 1.8e-7f * (fabsf(fi[3 * j]) + fabsf(fi[3 * j + 1]) + fabsf(fi[3 * j + 2])) + (1.f + gj * reach) * rel_det;
             }
-            const bool usable = a.dist_mode == SCP_DIST_EUCLIDEAN && fabsf(det) > 1e-9f && fminf(fminf(e01, e12), e20) > 0.f && !a.dbg_nopre;
+            const bool usable = a.dist_mode == SCP_DIST_EUCLIDEAN && fabsf(det) > 1e-9f && fminf(fminf(e01, e12), e20) > 0.f;
             const float gn = sqrtf(fi[3 * k] * fi[3 * k] + fi[3 * k + 1] * fi[3 * k + 1]);
             const float thr = (1.02f * a.margin + 5.f * err * vmax) * gn + 1e-6f;
             rec[R_PRE + k] = (usable && thr == thr) ? thr : INFINITY;
@@ -1021,8 +1019,6 @@ int fill_args(RasterArgs& a, const scp_raster_params* p) {
     a.rcp_range = 1.0f / a.range; a.rcp_nrange = 1.0f / a.nrange;
     a.const_slow = !(fast_div_range(a.sigma) && fast_div_range(a.gamma) && fast_div_range(a.range));
     a.dist_mode = p->func_id_dist; a.alpha_mode = p->func_id_alpha; a.double_side = p->double_side != 0;
-    if (getenv("SCP_DBG_SLOW")) a.const_slow = 1;   /*DBG*/
-    if (getenv("SCP_DBG_NOPRE")) a.dbg_nopre = 1;   /*DBG*/
     return 0;
 }
 

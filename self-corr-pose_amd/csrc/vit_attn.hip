@@ -55,7 +55,7 @@ __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const float* __restrict__ qkv,
                                                                    float* __restrict__ out, int N, int H,
-                                                                   float scale_log2e, int dbg) {
+                                                                   float scale_log2e) {
     __shared__ __attribute__((aligned(16))) float k_lds[2][KT * HD];
     __shared__ __attribute__((aligned(16))) float v_lds[2][KT * HD];
 
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
     // all query groups of one (image, head) on ONE XCD so that its K/V (525 KB) is fetched into a single L2 instead
     // of up to eight (rocprofv3 FETCH_SIZE: 847 MB per launch before, against 151 MB of qkv).
     int bh = blockIdx.y, qg = blockIdx.x;
-    if ((gridDim.y & 7) == 0 && !(dbg & 64)) {
+    if ((gridDim.y & 7) == 0) {
         const int lin = blockIdx.x + gridDim.x * blockIdx.y;
         const int slot = lin >> 3;
         bh = (slot / gridDim.x) * 8 + (lin & 7);
@@ -166,10 +166,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
     auto tile_step = [&](int kt, auto ragged_tag) {
         constexpr bool RAGGED = decltype(ragged_tag)::value;
         const int buf = kt & 1;
-        if (!(dbg & 8)) {
-            // K(t+2) -> k_lds[t&1], V(t+1) -> v_lds[(t+1)&1]
-            issue_tiles(kt + 2 < ntiles, kt + 2, buf, kt + 1 < ntiles, kt + 1, buf ^ 1);
-        }
+        // K(t+2) -> k_lds[t&1], V(t+1) -> v_lds[(t+1)&1]
+        issue_tiles(kt + 2 < ntiles, kt + 2, buf, kt + 1 < ntiles, kt + 1, buf ^ 1);
         // V operands of tile t's P.V MFMAs: issued first so that their LDS latency is covered by the
         // max / rescale work below (the empty asm pins the loads here; the compiler otherwise sinks each
         // one to just before its MFMA and waits for it)
@@ -228,8 +226,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
             o_hi = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[r], s[r], o_hi, 0, 0, 0);
         }
         s = s_next;
-        if (!(dbg & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's DMA pieces have landed
-        if (!(dbg & 16)) __syncthreads();                                     // ... everybody's; ring slots may be reused
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's DMA pieces have landed
+        __syncthreads();                                     // ... everybody's; ring slots may be reused
     };
     // the key-bound mask (15 compares + selects per lane) is only needed where a tile crosses the end of the sequence:
     // peel that tile so that the steady-state loop does not carry it
@@ -255,10 +253,6 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
 
 }  // namespace
 
-extern int g_scp_attn_dbg;
-int g_scp_attn_dbg = 0;
-extern "C" void scpdbg_set_attn_flags(int f) { g_scp_attn_dbg = f; }
-
 extern "C" int scp_vit_attention_forward(const float* qkv, float* out, int B, int N, int H, int head_dim,
                                          float scale, void* stream) {
     if (B <= 0 || N <= 0 || H <= 0) return scp::fail(hipErrorInvalidValue, "vit_attention: empty problem");
@@ -268,9 +262,9 @@ extern "C" int scp_vit_attention_forward(const float* qkv, float* out, int B, in
     const int qtiles = (N + 31) / 32;
     // 3 wavefronts per workgroup when that leaves no idle wavefront (1025 tokens = 33 tiles = 11 x 3)
     if (qtiles % 3 == 0 && qtiles % 4 != 0) {
-        hipLaunchKernelGGL(vit_attention_kernel<3>, dim3(qtiles / 3, B * H), dim3(192), 0, st, qkv, out, N, H, sl, g_scp_attn_dbg);
+        hipLaunchKernelGGL(vit_attention_kernel<3>, dim3(qtiles / 3, B * H), dim3(192), 0, st, qkv, out, N, H, sl);
     } else {
-        hipLaunchKernelGGL(vit_attention_kernel<4>, dim3((qtiles + 3) / 4, B * H), dim3(256), 0, st, qkv, out, N, H, sl, g_scp_attn_dbg);
+        hipLaunchKernelGGL(vit_attention_kernel<4>, dim3((qtiles + 3) / 4, B * H), dim3(256), 0, st, qkv, out, N, H, sl);
     }
     return scp::check_launch("vit_attention");
 }

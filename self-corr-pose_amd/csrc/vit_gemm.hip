@@ -1,0 +1,328 @@
+// self-corr-pose_amd/csrc/vit_gemm.hip -- the linear layers of the frozen DINO ViT-S/8 on the gfx950 fp32 matrix cores,
+// with everything around them fused into the GEMM.
+//
+// Replaces, per transformer block (third-party/zsp/zsp/method/vision_transformer_flexible.py):
+//   :126-132  x = x + attn(norm1(x)); x = x + mlp(norm2(x))       Block.forward
+//   :85-101   qkv = Linear(dim, 3 dim)(.), proj = Linear(dim, dim)  Attention
+//   :54-70    fc2(GELU(fc1(.)))                                     Mlp (nn.GELU = erf form)
+// i.e. four GEMMs  C[M,N] = A[M,K] W[N,K]^T  (M = B*1025 tokens, K, N in {384, 1152, 1536}) plus two LayerNorms, a GELU,
+// two bias+residual adds -- eight extra passes over [M,384]...[M,1536] activations when run as separate kernels.
+//
+// Fusions (one kernel family, epilogue selected at compile time):
+//   LN prologue, folded algebraically: LayerNorm(x) W^T = rstd_m * (x (gamma o W)^T)_mn - rstd_m mu_m s_n + t_n with
+//       s_n = sum_k gamma_k W_nk,  t_n = sum_k beta_k W_nk + bias_n.  The weights are frozen, so gamma o W, s, t are built
+//       once; the GEMM streams the RAW residual stream x and applies (mu_m, rstd_m) -- one tiny row-statistics kernel per
+//       LayerNorm -- in its epilogue.  The normalised activation is never written or read.
+//   EPI_LN            qkv  = LN1(x) Wqkv^T + b
+//   EPI_LN_GELU       h    = GELU(LN2(x) W1^T + b1)
+//   EPI_BIAS_RESIDUAL x   += y W^T + b      (proj and fc2; in place on the residual stream)
+//   EPI_BIAS          plain Linear (block 9's K slice uses EPI_LN with a 384-row weight slice)
+//
+// CDNA4 mapping: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate).  Workgroup = 4 wavefronts = 128 x 128
+// output tile, wavefront = 64 x 64 = 2 x 2 MFMA tiles (64 accumulator VGPRs).  Both operands are K-contiguous, so a lane
+// (row = lane & 31, half = lane >> 5) takes its 8 k-values of a 16-wide K chunk with two ds_read_b128 and feeds them to
+// 8 MFMAs unchanged (A and W use the same k <-> (half, register) assignment; any pairing is a valid contraction order).
+// Tiles arrive by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs), a three-stage ring of SEPARATE LDS objects, one
+// barrier per K chunk; the DMA destination is lane-linear, so bank conflicts are removed by permuting the SOURCE address:
+// 16-byte chunk c of tile row r lands in slot c ^ ((r >> 2) & 3) and is read back through the same XOR (16 consecutive rows
+// hit 16 distinct 4-bank groups).  48 KiB of LDS (three stages) and <= 168 VGPRs per workgroup -> 3 workgroups per CU = 768 slots: at
+// B = 32 the 256 full row panels x {3, 9, 12} column blocks are exact multiples of 768 (no partial last round).
+// blockIdx is remapped so that the N-blocks of one 128-row panel of A run back to back on ONE XCD: A is fetched from HBM
+// once, W (<= 2.4 MB) lives in every XCD's L2.
+// Roofline: bound = fp32 MFMA (157.3 TFLOP/s); algorithmic flops 2 M N K per launch; algorithmic bytes 4 (M K + N K + M N).
+#include <hip/hip_runtime.h>
+
+#include "scp_common.h"
+#include "scp_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int THREADS = 256;
+constexpr int TILE_FLOATS = BM * BK;            // one operand tile of one stage (8 KiB)
+
+#define SCP_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define SCP_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+struct GemmArgs {
+    const float* A;        // [M, K]
+    const float* W;        // [N, K]
+    const float* vec0;     // EPI_LN*: s[N]            EPI_BIAS*: bias[N]
+    const float* vec1;     // EPI_LN*: t[N]
+    const float* rowstat;  // EPI_LN*: (mean, rstd)[M]
+    const float* resid;    // EPI_BIAS_RESIDUAL: [M, N] (may alias C)
+    float* C;              // [M, N]
+    int M, N, K;
+    int nblk_n, full_panels, rem_blocks, per_xcd;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+template <int EPI>
+__global__ __launch_bounds__(THREADS, 3) void vit_gemm_kernel(const GemmArgs g) {
+    // one LDS object per (operand, stage): the compiler's wait-count insertion tracks LDS-DMA writes per object, so a
+    // ds_read of stage 0 does not have to wait for the DMA that is filling stage 1 (with a_lds[2][..] it inserted
+    // s_waitcnt vmcnt(0) in front of every read and serialised prefetch and compute)
+    __shared__ __attribute__((aligned(16))) float a_lds0[TILE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float a_lds1[TILE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float a_lds2[TILE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float w_lds0[TILE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float w_lds1[TILE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float w_lds2[TILE_FLOATS];
+
+    // Block order.  (1) Full 128-row panels in an XCD-aware order: workgroup b runs on XCD b % 8, consecutive logical ids of
+    // one XCD (adjacent in time) walk the N-blocks of one A panel, and every XCD gets the same number of full blocks -- with
+    // 3 resident workgroups per CU (96 per XCD) a single extra full block on an XCD ran as a lonely second round (+0.1 ms
+    // per launch).  (2) The N-blocks of the SHORT last panel (M = B * 1025 tokens leaves 32 rows) come last and spread their
+    // one 32-row strip over the four wavefronts (32 x 32 each), so the tail they add is an eighth of a block's time.
+    int bm, bn;
+    const int full_slots = g.per_xcd * 8;
+    const bool rem = (int)blockIdx.x >= full_slots;
+    if (rem) {
+        bn = blockIdx.x - full_slots;
+        if (bn >= g.rem_blocks) return;
+        bm = g.full_panels;
+    } else {
+        const int lid = (blockIdx.x & 7) * g.per_xcd + (blockIdx.x >> 3);
+        if (lid >= g.full_panels * g.nblk_n) return;
+        bm = lid / g.nblk_n;
+        bn = lid - bm * g.nblk_n;
+    }
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    // wavefront's sub-tile: rows row_base + 32 i, columns col_base + 32 j.  Full panel: 64 x 64 (2 x 2 MFMA tiles);
+    // remainder panel: the strip's 32 rows x 32 columns per wavefront
+    const int row_base = rem ? 0 : 64 * (wave >> 1);
+    const int col_base = rem ? 32 * wave : 64 * (wave & 1);
+
+    // ---- LDS-DMA pieces.  An operand tile of one stage is 128 rows x 64 B = 8 instructions of 1 KiB (16 rows each); the 16
+    // pieces of (A tile, W tile) are dealt to the 4 wavefronts: wavefront w moves A pieces 2w, 2w+1 and W pieces alike.
+    // Per piece the per-lane part of the source address (row, swizzled chunk) is loop invariant.
+    const int prow = lane >> 2, pslot = lane & 3;
+    unsigned a_off[2], w_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int r = 16 * (2 * wave + i) + prow;                      // tile row 0..127
+        const int chunk = pslot ^ ((r >> 2) & 3);
+        a_off[i] = (unsigned)min(m0 + r, g.M - 1) * (unsigned)g.K + 4u * chunk;
+        w_off[i] = (unsigned)min(n0 + r, g.N - 1) * (unsigned)g.K + 4u * chunk;
+    }
+    auto issue_stage = [&](int kc, float* a_dst, float* w_dst) {
+        const float* ap = g.A + kc * BK;
+        const float* wp = g.W + kc * BK;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            __builtin_amdgcn_global_load_lds(SCP_GLOBAL_PTR(ap + a_off[i]), SCP_LDS_PTR(a_dst + (2 * wave + i) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(SCP_GLOBAL_PTR(wp + w_off[i]), SCP_LDS_PTR(w_dst + (2 * wave + i) * 256), 16, 0, 0);
+        }
+    };
+    const bool tile_live[2] = {true, !rem};      // [i] and [j] alike: the remainder strip is one MFMA tile per wavefront
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    // lane's read offsets (floats) inside a stage: rows row_base + 32*i + l31 of A, col_base + 32*j + l31 of W; chunk 2*half + c
+    int a_rd[2][2], w_rd[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int ra = row_base + 32 * i + l31, rw = col_base + 32 * i + l31;
+            a_rd[i][c] = ra * BK + 4 * ((2 * half + c) ^ ((ra >> 2) & 3));
+            w_rd[i][c] = rw * BK + 4 * ((2 * half + c) ^ ((rw >> 2) & 3));
+        }
+    auto compute_stage = [&](const float* as, const float* ws) {
+        float4 av[2][2], wv[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                av[i][c] = *reinterpret_cast<const float4*>(as + a_rd[i][c]);
+                wv[i][c] = *reinterpret_cast<const float4*>(ws + w_rd[i][c]);
+            }
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                if (!tile_live[i]) continue;                       // wavefront-uniform
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    if (!tile_live[j]) continue;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][c].x, wv[j][c].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][c].y, wv[j][c].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][c].z, wv[j][c].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][c].w, wv[j][c].w, acc[i][j], 0, 0, 0);
+                }
+            }
+    };
+
+    // three-stage ring, prefetch distance two chunks: while chunk kc is multiplied, kc+1 has been in flight for a whole
+    // chunk time and kc+2 is issued.  Each stage issue is 4 DMA instructions per wavefront, so "chunk kc has landed" is
+    // vmcnt(4) while a younger chunk is outstanding and vmcnt(0) at the tail.
+    const int nk = g.K / BK;
+    issue_stage(0, a_lds0, w_lds0);
+    if (nk > 1) issue_stage(1, a_lds1, w_lds1);
+    auto step = [&](int kc, const float* as, const float* ws, float* a_next, float* w_next) {
+        if (kc + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();        // chunk kc visible to all; every wavefront is done with chunk kc-1, whose stage is refilled now
+        if (kc + 2 < nk) issue_stage(kc + 2, a_next, w_next);
+        compute_stage(as, ws);
+    };
+    for (int kc = 0; kc < nk; kc += 3) {
+        step(kc, a_lds0, w_lds0, a_lds2, w_lds2);
+        if (kc + 1 < nk) step(kc + 1, a_lds1, w_lds1, a_lds0, w_lds0);
+        if (kc + 2 < nk) step(kc + 2, a_lds2, w_lds2, a_lds1, w_lds1);
+    }
+
+    // ---- epilogue.  MFMA layout: A operand rows -> accumulator rows acc_row(reg, half), B operand rows (W rows = output
+    // columns) -> lane & 31: lane holds C[m][n = n_base + l31] for 16 rows m -> 32 consecutive floats per row per half-wave.
+    // All loads of a 32 x 32 tile are issued before its stores (resid may alias C element for element; every element is read
+    // and written by the same lane only).
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        if (!tile_live[i]) continue;
+        const int mb = m0 + row_base + 32 * i;
+        float mean[16], rstd[16];
+        if (EPI == SCP_GEMM_LN || EPI == SCP_GEMM_LN_GELU) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = min(mb + acc_row(r, half), g.M - 1);
+                const float2 st = *reinterpret_cast<const float2*>(g.rowstat + 2 * (size_t)m);
+                mean[r] = st.x;
+                rstd[r] = st.y;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            if (!tile_live[j]) continue;
+            const int n = n0 + col_base + 32 * j + l31;
+            const bool n_ok = n < g.N;
+            const int nc = min(n, g.N - 1);
+            const float v0 = g.vec0[nc];
+            float v1 = 0.f;
+            if (EPI == SCP_GEMM_LN || EPI == SCP_GEMM_LN_GELU) v1 = g.vec1[nc];
+            float res[16];
+            if (EPI == SCP_GEMM_BIAS_RESIDUAL) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = min(mb + acc_row(r, half), g.M - 1);
+                    res[r] = g.resid[(size_t)m * g.N + nc];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mb + acc_row(r, half);
+                float x = acc[i][j][r];
+                if (EPI == SCP_GEMM_LN || EPI == SCP_GEMM_LN_GELU) {
+                    x = rstd[r] * (x - mean[r] * v0) + v1;
+                    if (EPI == SCP_GEMM_LN_GELU) x = gelu_erf(x);
+                } else {
+                    x += v0;
+                    if (EPI == SCP_GEMM_BIAS_RESIDUAL) x += res[r];
+                }
+                if (m < g.M && n_ok) g.C[(size_t)m * g.N + n] = x;
+            }
+        }
+    }
+}
+
+// per-row LayerNorm statistics (mean, rstd = 1 / sqrt(var + eps)), biased variance as nn.LayerNorm, two-pass over registers.
+// One wavefront handles 4 rows at a time with all of their loads in flight (C <= 1536, C % 4 == 0: <= 6 float4 per lane).
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int rows,
+                                                        int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (row0 >= rows) return;
+    const int nq = C >> 2;
+    float4 v[4][6];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)min(row0 + r, rows - 1) * C);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int q = lane + 64 * i;
+            v[r][i] = q < nq ? xr[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) s += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m);
+        const float mean = s / C;
+        float q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            if (lane + 64 * i < nq) {
+                const float dx = v[r][i].x - mean, dy = v[r][i].y - mean, dz = v[r][i].z - mean, dw = v[r][i].w - mean;
+                q2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) q2 += __shfl_xor(q2, m);
+        if (lane == 0 && row0 + r < rows) {
+            stats[2 * (size_t)(row0 + r)] = mean;
+            stats[2 * (size_t)(row0 + r) + 1] = 1.f / sqrtf(q2 / C + eps);
+        }
+    }
+}
+
+template <int EPI>
+void launch(const GemmArgs& g, hipStream_t st) {
+    hipLaunchKernelGGL(vit_gemm_kernel<EPI>, dim3(g.per_xcd * 8 + g.rem_blocks), dim3(THREADS), 0, st, g);
+}
+
+}  // namespace
+
+extern "C" int scp_vit_linear(const float* A, const float* W, const float* vec0, const float* vec1, const float* rowstat,
+                              const float* resid, float* C, int M, int N, int K, int epilogue, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return scp::fail(hipErrorInvalidValue, "vit_linear: empty problem");
+    if (K % (2 * BK) != 0) return scp::fail(hipErrorInvalidValue, "vit_linear: K must be a multiple of 32");
+    if ((size_t)M * (size_t)K >= (1ull << 32) || (size_t)N * (size_t)K >= (1ull << 32))
+        return scp::fail(hipErrorInvalidValue, "vit_linear: operand larger than 2^32 elements");
+    const bool ln = epilogue == SCP_GEMM_LN || epilogue == SCP_GEMM_LN_GELU;
+    if (!vec0 || (ln && (!vec1 || !rowstat)) || (epilogue == SCP_GEMM_BIAS_RESIDUAL && !resid))
+        return scp::fail(hipErrorInvalidValue, "vit_linear: missing epilogue operand");
+    GemmArgs g{};
+    g.A = A; g.W = W; g.vec0 = vec0; g.vec1 = vec1; g.rowstat = rowstat; g.resid = resid; g.C = C;
+    g.M = M; g.N = N; g.K = K;
+    g.nblk_n = (N + BN - 1) / BN;
+    // a last panel of <= 32 rows (M = B * 1025 tokens at B = 32 k) runs in strip mode; a longer one is an ordinary panel with
+    // clamped loads and masked stores
+    const int tail_rows = M % BM;
+    g.full_panels = M / BM + (tail_rows > 32 ? 1 : 0);
+    g.rem_blocks = (tail_rows > 0 && tail_rows <= 32) ? g.nblk_n : 0;
+    g.per_xcd = (g.full_panels * g.nblk_n + 7) / 8;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (epilogue) {
+        case SCP_GEMM_BIAS: launch<SCP_GEMM_BIAS>(g, st); break;
+        case SCP_GEMM_BIAS_RESIDUAL: launch<SCP_GEMM_BIAS_RESIDUAL>(g, st); break;
+        case SCP_GEMM_LN: launch<SCP_GEMM_LN>(g, st); break;
+        case SCP_GEMM_LN_GELU: launch<SCP_GEMM_LN_GELU>(g, st); break;
+        default: return scp::fail(hipErrorInvalidValue, "vit_linear: unknown epilogue");
+    }
+    return scp::check_launch("vit_linear");
+}
+
+extern "C" int scp_row_mean_rstd(const float* x, float* stats, int rows, int C, float eps, void* stream) {
+    if (rows <= 0) return 0;
+    if (C <= 0 || C > 1536 || (C & 3)) return scp::fail(hipErrorInvalidValue, "row_mean_rstd: C must be a multiple of 4 in 4..1536");
+    hipLaunchKernelGGL(row_stats_kernel, dim3((rows + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), x, stats, rows,
+                       C, eps);
+    return scp::check_launch("row_mean_rstd");
+}

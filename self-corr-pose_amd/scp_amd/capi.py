@@ -47,6 +47,8 @@ SYMBOLS = {
     "scp_soft_rasterize_count_pairs": (ctypes.c_int, [_P, _P, _RP, _P]),
     "scp_soft_rasterize_forward_dual": (ctypes.c_int, [_P] * 8 + [_RP, _P]),
     "scp_selftest_exact_division": (ctypes.c_int, [ctypes.c_ulonglong, ctypes.c_uint, _P, _P]),
+    "scp_vit_linear": (ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 4 + [_P]),
+    "scp_row_mean_rstd": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, _P]),
     "scp_softargmax_cols_workspace": (ctypes.c_size_t, [_I, _I, _I]),
     "scp_softargmax_cols_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P, _P, _P, ctypes.c_size_t, _P]),
     "scp_softmax_rows_weighted_forward": (ctypes.c_int, [_P, _P, _I, _F, _I, _I, _I, _P, _P, _P]),

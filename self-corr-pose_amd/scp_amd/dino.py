@@ -12,6 +12,9 @@ MI355X-first differences, all output-preserving:
     [n,6,1025,1025] attention of blocks 9 and 11) -- SURVEY F5;
   * attention never materialises the score matrix (fused kernel), the bicubic-interpolated
     positional embedding is computed once per input size and cached;
+  * every linear layer runs on the hand-written fp32-MFMA GEMM of csrc/vit_gemm.hip with its neighbours fused in:
+    LayerNorm folded into the qkv / fc1 GEMMs (frozen weights: gamma o W precomputed, per-row mean / rstd applied in the
+    epilogue), erf-GELU in fc1's epilogue, bias + residual add in proj's and fc2's (in place on the residual stream);
   * callers pass each unique image once; there is no empty_cache()/chunking.
 The module tree and parameter names equal the DINO checkpoint's, so
 `pretrain/dino_deitsmall8_pretrain.pth` loads with strict=True and MeshNet's state_dict keys are
@@ -126,6 +129,47 @@ def add_layernorm(x, branch, norm):
     return x, y
 
 
+GEMM_BIAS, GEMM_BIAS_RESIDUAL, GEMM_LN, GEMM_LN_GELU = 0, 1, 2, 3      # include/scp_hip.h SCP_GEMM_*
+
+
+def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilogue=GEMM_BIAS):
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T) on the fp32 matrix cores (csrc/vit_gemm.hip, include/scp_hip.h
+    scp_vit_linear); `resid` may be `out` itself (in-place residual stream).  Forward only, GPU tensors only."""
+    from . import capi
+    if torch.is_grad_enabled() and (a.requires_grad or w.requires_grad):
+        raise RuntimeError("scp_amd.dino.vit_linear is forward-only (frozen ViT)")
+    m, k = a.shape
+    n = w.shape[0]
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    code = capi.lib().scp_vit_linear(capi.dev_ptr(a, "a"), capi.dev_ptr(w, "w"), capi.dev_ptr(vec0, "vec0"),
+                                     capi.opt_ptr(vec1, "vec1"), capi.opt_ptr(rowstat, "rowstat"),
+                                     capi.opt_ptr(resid, "resid"), capi.dev_ptr(out, "out"), m, n, k, epilogue,
+                                     capi.current_stream())
+    capi.check(code, "scp_vit_linear")
+    return out
+
+
+def row_mean_rstd(x, eps):
+    """[M,2] (mean, 1/sqrt(biased var + eps)) per row of x[M,C] -- nn.LayerNorm's statistics (csrc/vit_gemm.hip)"""
+    from . import capi
+    m, c = x.shape
+    st = torch.empty(m, 2, dtype=torch.float32, device=x.device)
+    capi.check(capi.lib().scp_row_mean_rstd(capi.dev_ptr(x, "x"), capi.dev_ptr(st, "stats"), m, c, float(eps),
+                                            capi.current_stream()), "scp_row_mean_rstd")
+    return st
+
+
+def fold_layernorm(norm, weight, bias):
+    """LayerNorm(x) W^T + b = rstd * (x (gamma o W)^T - mean * s) + t  with s = rowsum(gamma o W), t = W beta + b.
+    The ViT is frozen, so this is computed once per weight version (float64 sums, stored fp32)."""
+    w64 = weight.double()
+    wg = (w64 * norm.weight.double()[None]).float().contiguous()
+    s = wg.double().sum(1).float().contiguous()
+    t = (w64 @ norm.bias.double() + bias.double()).float().contiguous()
+    return wg, s, t
+
+
 class _Block(nn.Module):
     def __init__(self, dim, num_heads, mlp_ratio=4.):
         super().__init__()
@@ -140,6 +184,38 @@ class _Block(nn.Module):
         x, y = add_layernorm(x, pending, self.norm1)
         x, y = add_layernorm(x, self.attn(y), self.norm2)
         return x, self.mlp(y)
+
+    # ---- fused path (fp32, GPU): four GEMM launches + two row-statistics launches + attention per block -------------
+    def _folded(self):
+        """(gamma1 o Wqkv, s, t), (gamma2 o W1, s, t), rebuilt when any of the frozen tensors changes (load_state_dict)"""
+        src = (self.norm1.weight, self.norm1.bias, self.attn.qkv.weight, self.attn.qkv.bias,
+               self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias)
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in src)
+        if getattr(self, "_fold_key", None) != key:
+            with torch.no_grad():
+                self._fold = (fold_layernorm(self.norm1, self.attn.qkv.weight, self.attn.qkv.bias),
+                              fold_layernorm(self.norm2, self.mlp.fc1.weight, self.mlp.fc1.bias))
+            self._fold_key = key
+        return self._fold
+
+    def forward_fused(self, x2d, b, n):
+        """x2d [b*n, dim] residual stream, updated IN PLACE:  x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x)))
+        (vision_transformer_flexible.py:126-132)."""
+        (wq, sq, tq), (w1, s1, t1) = self._folded()
+        a = self.attn
+        qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN)
+        y = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, x2d.shape[1] // a.num_heads, a.scale)
+        vit_linear(y.view(b * n, -1), a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL)
+        h = vit_linear(x2d, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), epilogue=GEMM_LN_GELU)
+        vit_linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL)
+        return x2d
+
+    def keys_fused(self, x2d, b, n):
+        """K third of qkv(LN1(x)): [b, heads, n, d]  (the only part of block 9 the DINO features need)"""
+        (wq, sq, tq), _ = self._folded()
+        c = x2d.shape[1]
+        k = vit_linear(x2d, wq[c:2 * c], sq[c:2 * c], tq[c:2 * c], row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN)
+        return k.view(b, n, self.attn.num_heads, c // self.attn.num_heads).permute(0, 2, 1, 3)
 
 
 class _PatchEmbed(nn.Module):
@@ -194,6 +270,13 @@ class VisionTransformer(nn.Module):
 
     def key_features(self, x, layer=9):
         """keys of block `layer`: [b, heads, tokens, d]"""
+        if x.is_cuda and not MIXED_BF16:
+            tok = self.prepare_tokens(x).contiguous()
+            b, n, c = tok.shape
+            x2d = tok.view(b * n, c)
+            for blk in self.blocks[:layer]:
+                blk.forward_fused(x2d, b, n)
+            return self.blocks[layer].keys_fused(x2d, b, n)
         tok, pending = self.prepare_tokens(x).contiguous(), None
         for blk in self.blocks[:layer]:
             tok, pending = blk(tok, pending)

@@ -129,3 +129,68 @@ def test_bf16_attention_vs_fp32_oracle(B, N, H):
     assert err.max().item() < 1.5e-2 * scale, err.max().item() / scale
     assert err.mean().item() < 2e-3 * scale
     assert torch.isfinite(out).all()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fp32-MFMA linear layers with fused LayerNorm / GELU / residual (csrc/vit_gemm.hip)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N", [(1025 * 3, 384, 1152), (130, 64, 200), (32, 1536, 384), (257, 384, 1536), (1, 32, 1)])
+def test_vit_linear_epilogues_vs_float64(M, K, N):
+    """all four epilogues, ragged M (remainder panel path) and N not a multiple of the 128-column tile, against float64.
+    Tolerance 1e-5 of the output scale (fp32 accumulation over K <= 1536 in MFMA order)."""
+    from scp_amd import dino
+    g = torch.Generator().manual_seed(M + K + N)
+    a = (torch.randn(M, K, generator=g) * 1.3 + 0.4).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.06).cuda()
+    b = (torch.randn(N, generator=g) * 0.2).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    norm = torch.nn.LayerNorm(K, eps=1e-6).cuda()
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.2 * torch.randn(K, generator=g))
+        norm.bias.copy_(0.2 * torch.randn(K, generator=g))
+        a64, w64, b64 = a.double(), w.double(), b.double()
+        ln64 = torch.nn.functional.layer_norm(a64, (K,), norm.weight.double(), norm.bias.double(), 1e-6)
+        wg, s, t = dino.fold_layernorm(norm, w, b)
+        st = dino.row_mean_rstd(a, 1e-6)
+        torch.testing.assert_close(st[:, 0].double(), a64.mean(1), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(st[:, 1].double(), 1 / torch.sqrt(a64.var(1, unbiased=False) + 1e-6), rtol=1e-5, atol=0)
+        cases = {
+            "bias": (dino.vit_linear(a, w, b), a64 @ w64.t() + b64),
+            "bias+residual": (dino.vit_linear(a, w, b, resid=res, epilogue=dino.GEMM_BIAS_RESIDUAL), a64 @ w64.t() + b64 + res.double()),
+            "ln": (dino.vit_linear(a, wg, s, t, st, epilogue=dino.GEMM_LN), ln64 @ w64.t() + b64),
+            "ln+gelu": (dino.vit_linear(a, wg, s, t, st, epilogue=dino.GEMM_LN_GELU), torch.nn.functional.gelu(ln64 @ w64.t() + b64)),
+        }
+        # in place on the residual stream
+        inplace = res.clone()
+        dino.vit_linear(a, w, b, resid=inplace, out=inplace, epilogue=dino.GEMM_BIAS_RESIDUAL)
+        assert torch.equal(inplace, cases["bias+residual"][0])
+    for name, (got, ref) in cases.items():
+        err = (got.double() - ref).abs().max().item()
+        assert err <= 1e-5 * max(ref.abs().max().item(), 1.0), "%s: max err %.3e of scale %.3e" % (name, err, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(2, 1025), (3, 197)])
+def test_fused_block_matches_oracle(B, N):
+    """one transformer block through the fused path (2 row-stat + 4 GEMM + attention launches) against the oracle's
+    spelled-out Block.forward in float64; also block 9's K slice"""
+    from scp_amd import dino
+    torch.manual_seed(3)
+    blk = dino._Block(384, 6).cuda().eval()
+    with torch.no_grad():
+        for prm in blk.parameters():
+            prm.copy_(torch.randn_like(prm) * (0.05 if prm.dim() > 1 else 0.2) + (1.0 if prm.dim() == 1 and prm is blk.norm1.weight else 0.0))
+        x = (torch.randn(B, N, 384, generator=torch.Generator().manual_seed(N)) * 1.5 + 0.3).cuda()
+        prm64 = {"norm1_w": blk.norm1.weight, "norm1_b": blk.norm1.bias, "qkv_w": blk.attn.qkv.weight, "qkv_b": blk.attn.qkv.bias,
+                 "proj_w": blk.attn.proj.weight, "proj_b": blk.attn.proj.bias, "norm2_w": blk.norm2.weight, "norm2_b": blk.norm2.bias,
+                 "fc1_w": blk.mlp.fc1.weight, "fc1_b": blk.mlp.fc1.bias, "fc2_w": blk.mlp.fc2.weight, "fc2_b": blk.mlp.fc2.bias}
+        prm64 = {k: v.double().cpu() for k, v in prm64.items()}
+        ref = oracle.block_oracle(x.double().cpu(), prm64, 6)
+        ref_k = oracle.block_keys_oracle(x.double().cpu(), prm64, 6)
+        got_k = blk.keys_fused(x.view(B * N, 384).clone(), B, N).cpu().double()
+        got = blk.forward_fused(x.view(B * N, 384).clone(), B, N).view(B, N, 384).cpu().double()
+    for name, g_, r_ in (("block", got, ref), ("keys", got_k, ref_k)):
+        err, scale = (g_ - r_).abs().max().item(), r_.abs().max().item()
+        print("%s: max abs err %.3e of scale %.3e" % (name, err, scale))
+        assert err <= 2e-5 * scale

@@ -1,0 +1,15 @@
+#!/bin/bash
+# tools/step_trace.sh [tag] -- on the GPU box: rocprofv3 kernel trace of a short bench run; kernel stats of the timed window,
+# device-idle analysis (tools/profile_summary.py).  Writes gpurun_out/<tag>_{kernel_stats_timed_window.csv,idle_gaps.txt}
+tag=${1:-step}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+mkdir -p $R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/trace_$tag
+rocprofv3 --kernel-trace -d /tmp/trace_$tag --output-format csv -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${tag}_bench_under_rocprof.json 2>/dev/null
+f=$(ls /tmp/trace_$tag/*/*kernel_trace.csv | head -1)
+cd $R
+# window = after the (INIT 3 + warmup 2 + 1)-th optimizer launch, i.e. the last 5 steps
+python tools/profile_summary.py --trace $f multi_tensor_apply_kernel 6 60 > gpurun_out/${tag}_kernel_stats_timed_window.csv
+python tools/profile_summary.py --gaps $f multi_tensor_apply_kernel 6 30 > gpurun_out/${tag}_idle_gaps.txt
+head -4 gpurun_out/${tag}_kernel_stats_timed_window.csv; head -12 gpurun_out/${tag}_idle_gaps.txt
