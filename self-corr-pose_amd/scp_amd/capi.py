@@ -129,6 +129,17 @@ def dev_ptr(t, name):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def dev_ptr_any(t):
+    """raw device pointer of a dense fp32 CUDA tensor in ANY dense layout (e.g. channels_last: the kernel's NHWC view)"""
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError("expected a float32 CUDA tensor")
+    if not (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)):
+        raise RuntimeError("expected a dense (contiguous or channels_last) tensor")
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError("tensor lives on cuda:%d but the current device is cuda:%d" % (t.device.index, torch.cuda.current_device()))
+    return ctypes.c_void_p(t.data_ptr())
+
+
 def opt_ptr(t, name):
     """like dev_ptr, but None -> NULL"""
     return ctypes.c_void_p(0) if t is None else dev_ptr(t, name)
