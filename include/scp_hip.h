@@ -98,6 +98,26 @@ int scp_soft_rasterize_count_pairs(const float* faces, unsigned long long* count
  * results to *mismatches (one device uint64, caller-zeroed).  Expected: 0. */
 int scp_selftest_exact_division(unsigned long long n, unsigned seed, unsigned long long* mismatches, void* stream);
 
+/* ---- feature <-> vertex correspondence without the score tensor (csrc/corr_fused.hip) ------------------------------------
+ * Replaces model/module/correspondence.py:42-53 (pc = mesh_feat @ img_feat, mask to -1e5, softmax over pixels and over
+ * vertices, imatch = grid @ P_mesh, match = P_img @ verts) fused with the 2x2 pooling pretrained_corr.py:120-123 applies to
+ * pc (the only form in which the training step consumes it).  Restrictions: C = 64, wf = 64, hf even.
+ *   img_feat [B,64,hf*wf], mesh_feat [B,V,64], mask_down [B,hf*wf], verts [B,V,3], grid [2,hf*wf]
+ *   forward ->  pooled [B,hf*wf/4,V] (2x2 mean of the masked scores), match [B,hf*wf,3], imatch [B,2,V],
+ *               rowstat [B,hf*wf,2], colstat [B,V,2] (softmax max / sum, for the backward), workspace >= scp_fvm_workspace()
+ *   backward -> g_img_feat [B,64,hf*wf], g_mesh_feat [B,V,64] from g_match / g_imatch / g_pooled (each may be NULL = zero);
+ *               scores are recomputed on the matrix cores, nothing of size B*P*V is read or written. */
+size_t scp_fvm_workspace(int B, int hf, int V);
+int scp_fvm_forward(const float* img_feat, const float* mesh_feat, const float* mask_down, const float* verts,
+                    const float* grid, float tau_img, float tau_mesh, int B, int C, int hf, int wf, int V, float* pooled,
+                    float* match, float* imatch, float* rowstat, float* colstat, void* workspace, size_t workspace_bytes,
+                    void* stream);
+int scp_fvm_backward(const float* img_feat, const float* mesh_feat, const float* mask_down, const float* verts,
+                     const float* grid, float tau_img, float tau_mesh, int B, int C, int hf, int wf, int V,
+                     const float* match, const float* imatch, const float* rowstat, const float* colstat,
+                     const float* g_match, const float* g_imatch, const float* g_pooled, float* g_img_feat,
+                     float* g_mesh_feat, void* stream);
+
 /* ---- DINO ViT-S/8 linear layers on the fp32 matrix cores, LayerNorm / bias / GELU / residual fused (csrc/vit_gemm.hip) ----
  * Replaces the nn.Linear calls of third-party/zsp/zsp/method/vision_transformer_flexible.py:54-70 (Mlp: fc1, GELU, fc2),
  * :85-101 (Attention: qkv, proj) together with the LayerNorms and residual adds of Block.forward (:126-132).

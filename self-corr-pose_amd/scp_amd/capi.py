@@ -48,6 +48,9 @@ SYMBOLS = {
     "scp_soft_rasterize_forward_dual": (ctypes.c_int, [_P] * 8 + [_RP, _P]),
     "scp_selftest_exact_division": (ctypes.c_int, [ctypes.c_ulonglong, ctypes.c_uint, _P, _P]),
     "scp_vit_linear": (ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 4 + [_P]),
+    "scp_fvm_workspace": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "scp_fvm_forward": (ctypes.c_int, [_P] * 5 + [ctypes.c_float] * 2 + [ctypes.c_int] * 5 + [_P] * 6 + [ctypes.c_size_t, _P]),
+    "scp_fvm_backward": (ctypes.c_int, [_P] * 5 + [ctypes.c_float] * 2 + [ctypes.c_int] * 5 + [_P] * 10),
     "scp_row_mean_rstd": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, _P]),
     "scp_softargmax_cols_workspace": (ctypes.c_size_t, [_I, _I, _I]),
     "scp_softargmax_cols_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P, _P, _P, ctypes.c_size_t, _P]),

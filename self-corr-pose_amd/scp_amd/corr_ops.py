@@ -107,6 +107,68 @@ class FeatureVertexMatch(Function):
         return g_img, g_mesh, None, None, None, None, None
 
 
+def fvm_fusable(img_feat, mesh_feat, hf, wf):
+    """the fused kernels (csrc/corr_fused.hip) cover the shipped Wild6D configurations: 64 feature channels, 64x64 map"""
+    return img_feat.is_cuda and img_feat.shape[1] == 64 and wf == 64 and hf % 2 == 0 and hf >= 2 and img_feat.shape[2] == hf * wf
+
+
+class PooledScores:
+    """what Correspondence.match hands to PretrainedCorrespondence.compute_cycle_loss as `pointcorr` in training: the 2x2
+    pooled masked scores [B, hf*wf/4, V] (pretrained_corr.py:120-123 pools them first thing); the full [B, hf*wf, V] tensor is
+    never formed"""
+
+    def __init__(self, pooled, hf, wf):
+        self.pooled, self.hf, self.wf = pooled, hf, wf
+        self.shape = (pooled.shape[0], hf * wf, pooled.shape[2])
+        self.device, self.dtype = pooled.device, pooled.dtype
+
+
+class FeatureVertexMatchFused(Function):
+    """(pooled scores [B,P/4,V], match [B,P,3], imatch [B,2,V]) from unit features; scores live in registers only"""
+
+    @staticmethod
+    def forward(ctx, img_feat, mesh_feat, mask_down, verts, grid, tau_img, tau_mesh, hf, wf):
+        img_feat, mesh_feat = img_feat.contiguous().float(), mesh_feat.contiguous().float()
+        mask_down, verts, grid = _c(mask_down), _c(verts), _c(grid)
+        b, c, p = img_feat.shape
+        v = mesh_feat.shape[1]
+        dev = img_feat.device
+        L = capi.lib()
+        pooled = torch.empty(b, p // 4, v, dtype=torch.float32, device=dev)
+        match = torch.empty(b, p, 3, dtype=torch.float32, device=dev)
+        imatch = torch.empty(b, 2, v, dtype=torch.float32, device=dev)
+        rowstat = torch.empty(b, p, 2, dtype=torch.float32, device=dev)
+        colstat = torch.empty(b, v, 2, dtype=torch.float32, device=dev)
+        nbytes = L.scp_fvm_workspace(b, hf, v)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        capi.check(L.scp_fvm_forward(capi.dev_ptr(img_feat, "img_feat"), capi.dev_ptr(mesh_feat, "mesh_feat"),
+                                     capi.dev_ptr(mask_down, "mask_down"), capi.dev_ptr(verts, "verts"), capi.dev_ptr(grid, "grid"),
+                                     float(tau_img), float(tau_mesh), b, c, hf, wf, v, capi.dev_ptr(pooled, "pooled"),
+                                     capi.dev_ptr(match, "match"), capi.dev_ptr(imatch, "imatch"), capi.dev_ptr(rowstat, "rowstat"),
+                                     capi.dev_ptr(colstat, "colstat"), capi.dev_ptr(ws, "workspace"), ctypes.c_size_t(nbytes),
+                                     capi.current_stream()), "scp_fvm_forward")
+        ctx.save_for_backward(img_feat, mesh_feat, mask_down, verts, grid, match, imatch, rowstat, colstat)
+        ctx.cfg = (float(tau_img), float(tau_mesh), hf, wf)
+        return pooled, match, imatch
+
+    @staticmethod
+    def backward(ctx, g_pooled, g_match, g_imatch):
+        img_feat, mesh_feat, mask_down, verts, grid, match, imatch, rowstat, colstat = ctx.saved_tensors
+        tau_img, tau_mesh, hf, wf = ctx.cfg
+        b, c, p = img_feat.shape
+        v = mesh_feat.shape[1]
+        g_img = torch.empty_like(img_feat) if ctx.needs_input_grad[0] else None
+        g_mesh = torch.empty_like(mesh_feat) if ctx.needs_input_grad[1] else None
+        capi.check(capi.lib().scp_fvm_backward(
+            capi.dev_ptr(img_feat, "img_feat"), capi.dev_ptr(mesh_feat, "mesh_feat"), capi.dev_ptr(mask_down, "mask_down"),
+            capi.dev_ptr(verts, "verts"), capi.dev_ptr(grid, "grid"), tau_img, tau_mesh, b, c, hf, wf, v,
+            capi.dev_ptr(match, "match"), capi.dev_ptr(imatch, "imatch"), capi.dev_ptr(rowstat, "rowstat"),
+            capi.dev_ptr(colstat, "colstat"), capi.opt_ptr(_c(g_match), "g_match"), capi.opt_ptr(_c(g_imatch), "g_imatch"),
+            capi.opt_ptr(_c(g_pooled), "g_pooled"), capi.opt_ptr(g_img, "g_img"), capi.opt_ptr(g_mesh, "g_mesh"),
+            capi.current_stream()), "scp_fvm_backward")
+        return g_img, g_mesh, None, None, None, None, None, None, None
+
+
 class ColsSoftArgmax(Function):
     """out [N,2,Q] = grid @ softmax_P(tau * masked(scores))"""
 

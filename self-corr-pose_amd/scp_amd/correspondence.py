@@ -38,8 +38,16 @@ class Correspondence:
     def match(self, img_feat, mesh_feat, mask, pred_v):
         bsz, h, w = mask.shape
         mask_down = F.interpolate(mask[:, None], (self.hf, self.wf), mode="nearest").reshape(bsz, -1)
-        pointcorr, match, imatch = ops.feature_vertex_match(
-            img_feat, mesh_feat, mask_down, pred_v.detach(), self.meshgrid, self.tau_img, self.tau_mesh)
+        fused = None
+        if self.opts.train and img_feat.is_cuda and getattr(self, "fuse_scores", True):
+            # training consumes the scores only 2x2-pooled (pretrained_corr.py:120-123): fused kernels, no [B,P,V] tensor
+            fused = ops.feature_vertex_match_pooled(img_feat, mesh_feat, mask_down, pred_v.detach(), self.meshgrid,
+                                                    self.tau_img, self.tau_mesh, self.hf, self.wf)
+        if fused is not None:
+            pointcorr, match, imatch = fused
+        else:
+            pointcorr, match, imatch = ops.feature_vertex_match(
+                img_feat, mesh_feat, mask_down, pred_v.detach(), self.meshgrid, self.tau_img, self.tau_mesh)
 
         if self.opts.train:
             match_conf = None

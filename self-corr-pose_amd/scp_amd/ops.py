@@ -41,6 +41,18 @@ def feature_vertex_match(img_feat, mesh_feat, mask_down, verts, grid, tau_img, t
     return corr_ops.FeatureVertexMatch.apply(img_feat, mesh_feat, mask_down, verts, grid, tau_img, tau_mesh)
 
 
+def feature_vertex_match_pooled(img_feat, mesh_feat, mask_down, verts, grid, tau_img, tau_mesh, hf, wf):
+    """training form of feature_vertex_match: the scores are consumed only 2x2-pooled (pretrained_corr.py:120-123), so they
+    are produced that way and never stored at full resolution.  -> (PooledScores, match [B,P,3], imatch [B,2,V]);
+    None when the shape is outside what the fused kernels cover (caller falls back to feature_vertex_match)."""
+    _require_gpu(img_feat, "feature_vertex_match_pooled")
+    if not corr_ops.fvm_fusable(img_feat, mesh_feat, hf, wf):
+        return None
+    pooled, match, imatch = corr_ops.FeatureVertexMatchFused.apply(img_feat, mesh_feat, mask_down, verts, grid, tau_img,
+                                                                   tau_mesh, hf, wf)
+    return corr_ops.PooledScores(pooled, hf, wf), match, imatch
+
+
 def nearest_vertex(points, verts):
     """points [B,P,3], verts [B,V,3] -> index [B,P] of the nearest vertex (L2); eval only"""
     d = points.pow(2).sum(-1)[:, :, None] - 2 * points.bmm(verts.transpose(1, 2)) + verts.pow(2).sum(-1)[:, None, :]
@@ -67,6 +79,9 @@ def pool2x2_scores(pc, hf, wf):
     The reference reaches it through a bilinear F.interpolate to half resolution of the permuted
     [B,V,hf,wf] view (pretrained_corr.py:120-123), which for an exact factor 2 with
     align_corners=False is this mean."""
+    if isinstance(pc, corr_ops.PooledScores):          # produced pooled by the fused kernels (feature_vertex_match_pooled)
+        assert (pc.hf, pc.wf) == (hf, wf)
+        return pc.pooled
     b, _, v = pc.shape
     # one reduction forward, one broadcast backward; equals the bilinear form up to the order of the four
     # additions (last ulp)

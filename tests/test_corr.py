@@ -273,3 +273,81 @@ def test_hip_mutual_argmax_vs_oracle(N, C, P, Q):
     assert torch.equal(bw, bw_ref) and torch.equal(fw, fw_ref)
     bw2, fw2 = corr_ops.mutual_argmax(pc.cuda(), None, None)
     assert torch.equal(bw2.cpu(), pc.max(1).indices) and torch.equal(fw2.cpu(), pc.max(2).indices)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,hf,V", [(2, 64, 642), (3, 8, 37), (1, 16, 995), (2, 4, 64)])
+def test_fused_feature_vertex_match_vs_oracle(B, hf, V):
+    """csrc/corr_fused.hip (scores never stored) against the materialised oracle: pooled scores, match, imatch and the
+    gradients w.r.t. both feature sets under random upstream gradients on all three outputs; V not a multiple of 32,
+    one image fully masked, one fully visible"""
+    from scp_amd import ops
+    wf, C = 64, 64
+    P = hf * wf
+    g = torch.Generator().manual_seed(B * 100 + V)
+    img = torch.nn.functional.normalize(torch.randn(B, C, P, generator=g), 2, 1)
+    mesh = torch.nn.functional.normalize(torch.randn(B, V, C, generator=g), 2, 2)
+    verts = torch.randn(B, V, 3, generator=g)
+    xs, ys = (torch.arange(float(wf)) + 0.5) / (wf / 2) - 1, (torch.arange(float(hf)) + 0.5) / (wf / 2) - 1
+    grid = torch.stack((xs.repeat(hf), ys.repeat_interleave(wf)))
+    mask = (torch.rand(B, P, generator=g) > 0.4).float()
+    mask[0] = 0.
+    if B > 1:
+        mask[1] = 1.
+    w_p, w_m, w_i = torch.randn(B, P // 4, V, generator=g), torch.randn(B, P, 3, generator=g), torch.randn(B, 2, V, generator=g)
+
+    def run_ref():
+        a, b = img.clone().requires_grad_(True), mesh.clone().requires_grad_(True)
+        pc, match, imatch = oracle.match_oracle(a, b, mask, verts, grid, 10., 10.)
+        pooled = ops.pool2x2_scores(pc, hf, wf)
+        live = (pooled.detach() > -1e4).float()           # cells with a masked pixel hold -2.5e4 ...: compare finite cells
+        ((pooled * w_p * live).sum() * 1e-2 + (match * w_m).sum() + (imatch * w_i).sum()).backward()
+        return pooled, match, imatch, a.grad, b.grad
+
+    def run_hip():
+        a, b = img.clone().cuda().requires_grad_(True), mesh.clone().cuda().requires_grad_(True)
+        out = ops.feature_vertex_match_pooled(a, b, mask.cuda(), verts.cuda(), grid.cuda(), 10., 10., hf, wf)
+        assert out is not None
+        pc, match, imatch = out
+        pooled = ops.pool2x2_scores(pc, hf, wf)
+        assert pooled.shape == (B, P // 4, V)
+        live = (pooled.detach() > -1e4).float()
+        ((pooled * w_p.cuda() * live).sum() * 1e-2 + (match * w_m.cuda()).sum() + (imatch * w_i.cuda()).sum()).backward()
+        return pooled, match, imatch, a.grad, b.grad
+
+    ref, got = run_ref(), run_hip()
+    # pooled: cells containing masked pixels are sums with -1e5 terms (absolute error ~1e-2 at that magnitude): relative
+    np.testing.assert_allclose(got[0].detach().cpu().numpy(), ref[0].detach().numpy(), rtol=2e-6, atol=2e-6)
+    _close(got[1], ref[1].detach().numpy())
+    _close(got[2], ref[2].detach().numpy())
+    _grad_close(got[3], ref[3].numpy())
+    _grad_close(got[4], ref[4].numpy())
+
+
+@pytest.mark.gpu
+def test_fused_match_in_training_step_equals_unfused():
+    """Correspondence.match (train mode) through the fused kernels vs the round-1 path (rocBLAS scores + reductions): same
+    match / imatch, same pooled scores, same feature gradients"""
+    from scp_amd import ops
+    from scp_amd.correspondence import Correspondence
+    from scp_amd.flags import Options
+    opts = Options("laptop_wild6d", train=True)
+    g = torch.Generator().manual_seed(5)
+    B, V = 4, 642
+    img = torch.nn.functional.normalize(torch.randn(B, 64, 4096, generator=g), 2, 1).cuda()
+    mesh = torch.nn.functional.normalize(torch.randn(B, V, 64, generator=g), 2, 2).cuda()
+    pred_v = torch.randn(B, V, 3, generator=g).cuda()
+    mask = (torch.rand(B, 256, 256, generator=g) > 0.3).float().cuda()
+    outs = []
+    for fuse in (True, False):
+        corr = Correspondence(opts, "cuda")
+        corr.fuse_scores = fuse
+        a, b = img.clone().requires_grad_(True), mesh.clone().requires_grad_(True)
+        pc, match, imatch, _ = corr.match(a, b, mask, pred_v)
+        pooled = ops.pool2x2_scores(pc, 64, 64)
+        live = (pooled.detach() > -1e4).float()
+        ((pooled * live).sum() * 1e-3 + match.square().sum() + imatch.square().sum()).backward()
+        outs.append((pooled.detach(), match.detach(), imatch.detach(), a.grad, b.grad))
+    for x, y in zip(*outs):
+        scale = y.abs().max().item()
+        assert (x - y).abs().max().item() <= 2e-5 * scale, ((x - y).abs().max().item(), scale)
