@@ -13,15 +13,16 @@ ImageNet / DINO checkpoints).  Weak scaling: every rank processes its own 32 ima
 32-image iterations completed by all ranks per second.
 
 Extra JSON objects (tier contract):
-  roofline      the dominant hand-written kernel of the step = the fp32-MFMA flash attention of the
-                DINO ViT (9 launches, ~5.5 ms of a step; csrc/vit_attn.hip).  bound "mfma":
-                `achieved` = algorithmic flops of one launch (4 N^2 d per image and head) / its mean
-                duration measured with HIP events on the launch stream inside the timed region; peak
-                = 157.3 TFLOP/s (fp32 matrix = fp32 vector peak).  The second hand-written hot kernel,
-                the SoftRas backward of the sigma=1e-3 texture pass, is reported under "raster_backward"
-                (fp32-VALU bound on active (pixel,face) pairs; HBM figure for the record).
-  cpu_baseline  the same step on the host CPU cores (torch CPU + the C oracle rasteriser), rank 0,
-                N=1 only, on a bounded sample (one B=4 iteration), scaled to 32-image iterations/s.
+  roofline      the dominant hand-written kernel family of the step = vit_gemm_kernel (csrc/vit_gemm.hip: the 37 linear
+                layers of the DINO ViT on the fp32 matrix cores with LayerNorm / GELU / residual fused, ~8 ms of a step).
+                bound "mfma": `achieved` = algorithmic flops of the launches (2 M N K each) / their duration, both summed
+                over the timed region and measured with HIP events on the launch stream; peak = 157.3 TFLOP/s (fp32 MFMA).
+                `traffic` = HBM bytes per step of those launches from rocprofv3 FETCH_SIZE / WRITE_SIZE passes, read from
+                profiles/r02_traffic.json when that file matches the problem size, else null.
+                "others": the ViT attention kernel (mfma), the SoftRas backward of the sigma=1e-3 pass (fp32 VALU on active
+                (pixel,face) pairs; HBM figure for the record) and the fused correspondence kernels, same method.
+  cpu_baseline  the same step on the host CPU cores (torch CPU + the C oracle rasteriser), rank 0, N=1 only: ONE full
+                B=32 training step (the bench batch itself, ~1 min), after a B=2 warm-up step.
 """
 import argparse
 import json
@@ -54,12 +55,12 @@ class KernelTimer:
         self.enabled = False
 
     def __enter__(self):
-        def wrapped(*args):
-            if not (self.enabled and self.select(*args)):
-                return self.orig(*args)
+        def wrapped(*args, **kwargs):
+            if not (self.enabled and self.select(*args, **kwargs)):
+                return self.orig(*args, **kwargs)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = self.orig(*args)
+            out = self.orig(*args, **kwargs)
             e1.record()
             self.events.append((e0, e1))
             return out
@@ -72,9 +73,24 @@ class KernelTimer:
     def mean_ms(self):
         return float(np.mean([a.elapsed_time(b) for a, b in self.events])) if self.events else None
 
+    def total_ms(self):
+        return float(np.sum([a.elapsed_time(b) for a, b in self.events])) if self.events else None
+
 
 INIT_STEPS = 3
-ATTN_TRAFFIC_BYTES = (76188 * 2 + 49200) * 1000.0   # KB as reported by rocprofv3
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")   # written by tools/traffic_report.py from rocprofv3 PMC passes
+
+
+def measured_traffic(key, size_tag):
+    """HBM bytes (FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE, rocprofv3 --pmc, separate passes) recorded for
+    this kernel at this problem size, or None"""
+    try:
+        with open(TRAFFIC_FILE) as fh:
+            rec = json.load(fh)
+        e = rec.get(key)
+        return float(e["bytes"]) if e and e.get("size") == size_tag else None
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def isolated_attention(B, n_tok, heads, hd, flops, iters=30):
@@ -108,7 +124,7 @@ def build_trainer(device, world, batch_size=8, repeat=4, seed=0, mixed_bf16=None
     return Trainer(opts, prior=synthetic.bottle_like(3), device=device), opts
 
 
-def cpu_baseline(sample_bs=2, sample_repeat=2):
+def cpu_baseline(sample_bs=8, sample_repeat=4):
     """the step on the host cores: torch-CPU for the stock networks, the CPU oracle (oracle/: C rasteriser,
     torch restatements of the correspondence / ViT pieces) in place of every HIP kernel
     (oracle/backend.py).  Checker code, used here only as the thing being timed for the baseline --
@@ -132,9 +148,10 @@ def cpu_baseline(sample_bs=2, sample_repeat=2):
     oracle_backend.install(patch)
     try:
         threads = torch.get_num_threads()
+        tr, _ = build_trainer("cpu", 1, 1, 2)
+        tr.step(synth.make_batch(1, 2, 256, seed=0, device="cpu"))      # warm-up (allocator, oneDNN primitive caches)
         tr, _ = build_trainer("cpu", 1, sample_bs, sample_repeat)
-        data = synth.make_batch(sample_bs, sample_repeat, 256, seed=0, device="cpu")
-        tr.step(data)  # warm-up (allocator, oneDNN primitive caches)
+        data = synth.make_batch(sample_bs, sample_repeat, 256, seed=100, device="cpu")
         t0 = time.perf_counter()
         tr.step(data)
         dt = time.perf_counter() - t0
@@ -142,8 +159,8 @@ def cpu_baseline(sample_bs=2, sample_repeat=2):
         patch.undo()
     n_img = sample_bs * sample_repeat
     return {"value": (n_img / 32.0) / dt, "unit": "train iters/sec (32-image iterations)", "cores": threads,
-            "kind": "port", "sample": "1 full training step at B=%d (256x256, 642v/1280f), %.2f s, scaled by %d/32"
-                                      % (n_img, dt, n_img)}
+            "kind": "port", "sample": "1 full training step at B=%d (batch_size %d x repeat %d, 256x256, 642v/1280f) = the bench "
+                                      "batch itself, %.1f s" % (n_img, sample_bs, sample_repeat, dt)}
 
 
 def bench_posefit(args):
@@ -227,11 +244,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # hand-written hot kernels timed live: ViT attention (dominant) and the sigma=1e-3 raster backward
+    # hand-written hot kernels timed live (HIP events on the stream each one is launched on)
     import scp_amd.dino as dino_mod
     is_softtex = lambda *a: abs(a[12] - 1e-3) < 1e-9   # sigma_val of backward_soft_rasterize(...)
+    gemm_flops = []
+
+    def count_gemm(a, w, *rest, **kw):
+        gemm_flops.append(2.0 * a.shape[0] * a.shape[1] * w.shape[0])
+        return True
     with KernelTimer(native, "backward_soft_rasterize", is_softtex) as kt, \
-            KernelTimer(dino_mod, "fused_attention", lambda *a: True) as at:
+            KernelTimer(dino_mod, "fused_attention", lambda *a: True) as at, \
+            KernelTimer(dino_mod, "vit_linear", count_gemm) as gt:
         # initialisation, not measurement: the first iterations run MIOpen's solver search (cudnn.benchmark, once per
         # convolution shape and process) and fill the caching allocator -- the counterpart of a compile step.  Done
         # before the W warm-up steps so that a small --warmup still times steady-state iterations.
@@ -241,15 +264,16 @@ def main():
         for _ in range(args.warmup):
             tr.step(data)
         sync()
-        kt.enabled = at.enabled = True
+        kt.enabled = at.enabled = gt.enabled = True
         t0 = time.perf_counter()
         for _ in range(args.steps):
             tr.step(data)
         sync()
         elapsed = time.perf_counter() - t0
-        kt.enabled = at.enabled = False
+        kt.enabled = at.enabled = gt.enabled = False
         kernel_ms = kt.mean_ms()
         attn_ms = at.mean_ms()
+        gemm_total_ms, gemm_launches = gt.total_ms(), len(gt.events)
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
@@ -258,13 +282,12 @@ def main():
 
     if rank == 0:
         B, S = opts.batch_size * opts.repeat, opts.img_size
-        # algorithmic bytes of one softtex backward launch: faces + textures +
-        # faces_info in, soft_colors + aggrs_info + grad_soft_colors in, grad_faces + grad_textures out
-        alg_bytes = 4.0 * B * (n_faces * (9 + 9 + 27) + S * S * (4 + 2 + 4) + n_faces * (9 + 9))
-        roofline = None
-        raster = None
+        size_tag = "B%d_S%d_V%d" % (B, S, n_verts)
+        others = {}
         if kernel_ms:
-            fv = None
+            # algorithmic bytes of one softtex backward launch: faces + textures + faces_info in,
+            # soft_colors + aggrs_info + grad_soft_colors in, grad_faces + grad_textures out
+            alg_bytes = 4.0 * B * (n_faces * (9 + 9 + 27) + S * S * (4 + 2 + 4) + n_faces * (9 + 9))
             pairs = None
             try:  # pairs_active of this batch for the VALU-side figure
                 with torch.no_grad():
@@ -276,36 +299,47 @@ def main():
                     pv = torch.stack((pv[..., 0], pv[..., 1], pv[..., 2] + 2.7320508), -1)
                     fv = pv[:, m.mesh.faces].reshape(B, n_faces, 9).contiguous()
                     pairs = native.count_pairs(fv, S, 1e-3, float(np.log(1. / 1e-4 - 1.)))
-            except Exception as e:  # instrumentation only
+            except Exception:  # instrumentation only
                 pairs = None
             achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
             raster = {"kernel": "raster_backward_kernel<softmax,vertex> (sigma=1e-3 texture pass)",
-                        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                        "avg_launch_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes}
+                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic("raster_backward", size_tag),
+                      "avg_launch_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes}
             if pairs:
                 tf = pairs * FLOP_PER_PAIR_BWD / (kernel_ms * 1e-3) / 1e12
-                raster["valu"] = {"pairs_active": pairs, "flop_per_pair": FLOP_PER_PAIR_BWD,
-                                    "achieved_TFLOPs": tf, "peak_TFLOPs": FP32_VALU_PEAK_TF,
-                                    "frac": tf / FP32_VALU_PEAK_TF}
+                raster["valu"] = {"pairs_active": pairs, "flop_per_pair": FLOP_PER_PAIR_BWD, "achieved_TFLOPs": tf,
+                                  "peak_TFLOPs": FP32_VALU_PEAK_TF, "frac": tf / FP32_VALU_PEAK_TF}
+            others["raster_backward"] = raster
         if attn_ms:
             n_tok, heads, hd = (S // 8) ** 2 + 1, 6, 64
             flops = 4.0 * B * heads * n_tok * n_tok * hd
             tf = flops / (attn_ms * 1e-3) / 1e12
-            roofline = {"kernel": "vit_attention_kernel (fp32 MFMA flash attention, N=%d, 6x64, B=%d)" % (n_tok, B),
-                        "bound": "mfma", "achieved": tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": tf / FP32_VALU_PEAK_TF,
-                        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
-                        # measured offline at this exact problem size: profiles/r01_pmc_attention.txt
-                        "traffic": ATTN_TRAFFIC_BYTES if (n_tok, heads, B) == (1025, 6, 32) else None,
-                        "traffic_source": "profiles/r01_pmc_attention.txt", "avg_launch_ms": attn_ms,
-                        "algorithmic_flops_per_launch": flops, "launches_per_step": 9,
-                        # the live figure above is taken while the encoder / render streams share the device; the same
-                        # kernel alone on an idle device, for reference (not the roofline claim):
-                        "isolated": isolated_attention(B, n_tok, heads, hd, flops),
-                        "raster_backward": raster}
-        else:
-            roofline = raster
+            others["vit_attention"] = {
+                "kernel": "vit_attention_kernel (fp32 MFMA flash attention, N=%d, 6x64, B=%d)" % (n_tok, B), "bound": "mfma",
+                "achieved": tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TF,
+                "traffic": measured_traffic("vit_attention", size_tag), "avg_launch_ms": attn_ms,
+                "algorithmic_flops_per_launch": flops, "launches_per_step": 9,
+                # the live figure is taken while the encoder / render streams share the device; the same kernel alone on
+                # an idle device, for reference (not the roofline claim):
+                "isolated": isolated_attention(B, n_tok, heads, hd, flops)}
+        roofline = None
+        if gemm_total_ms:
+            fl = float(np.sum(gemm_flops[-gemm_launches:]))
+            tf = fl / (gemm_total_ms * 1e-3) / 1e12
+            per_step = gemm_launches / args.steps
+            roofline = {"kernel": "vit_gemm_kernel family (fp32 MFMA GEMM + fused LayerNorm / GELU / bias+residual epilogues; "
+                                  "%d launches per step, M = %d tokens)" % (per_step, B * ((S // 8) ** 2 + 1)),
+                        "bound": "mfma", "achieved": tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TF,
+                        "traffic": measured_traffic("vit_gemm", size_tag), "traffic_source": "profiles/r02_traffic.json (per step)",
+                        "avg_launch_ms": gemm_total_ms / gemm_launches, "algorithmic_flops_per_launch": fl / gemm_launches,
+                        "launches_per_step": per_step, "ms_per_step": gemm_total_ms / args.steps,
+                        # per block: qkv (r 384, w 1152), proj (r 384 + 384 residual, w 384), fc1 (r 384, w 1536), fc2 (r 1536 + 384,
+                        # w 384) floats per token = 6912; + block 9's K slice (r 384, w 384); + the weights once per launch
+                        "algorithmic_bytes_per_step": 4.0 * (B * ((S // 8) ** 2 + 1) * (9 * 6912 + 768) + 9 * 4608 * 384 + 384 * 384),
+                        "others": others}
+        elif others:
+            roofline = dict(next(iter(others.values())), others=others)
         out = {
             "metric": "train iters/sec (batch=32, 256x256, 1280-face/642-vert mesh)",
             "value": world * args.steps / elapsed, "unit": "iters/sec", "n_gpus": world, "steps": args.steps,

@@ -78,6 +78,17 @@ int scp_soft_rasterize_forward_dual(const float* faces, const float* textures, f
                                     float* aggrs_info_hard, float* soft_colors_hard,
                                     const scp_raster_params* p, void* stream);
 
+/* The double instantiation of the two entry points (the reference dispatches over float and double:
+ * AT_DISPATCH_FLOATING_TYPES, soft_rasterize_cuda_kernel.cu:701,716,779).  Same buffers and protocol with double elements; the
+ * scalars stay float as in the reference's signature.  Plain per-pixel kernels (csrc/softras_f64.hip) -- the training
+ * step never uses double. */
+int scp_soft_rasterize_forward_f64(const double* faces, const double* textures, double* faces_info, double* aggrs_info,
+                                   double* soft_colors, const scp_raster_params* p, void* stream);
+int scp_soft_rasterize_backward_f64(const double* faces, const double* textures, const double* soft_colors,
+                                    const double* faces_info, const double* aggrs_info, double* grad_faces,
+                                    double* grad_textures, const double* grad_soft_colors, const scp_raster_params* p,
+                                    void* stream);
+
 /* Replaces backward_soft_rasterize (cpp:94-132).
  *   grad_faces [B,F,9], grad_textures [B,F,T,3]: caller-zeroed, accumulated into.
  *   grad_soft_colors [B,4,S,S] contiguous. */

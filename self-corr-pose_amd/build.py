@@ -19,7 +19,7 @@ ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-munsafe-fp-atomics",
           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function"]
 # per-file extra flags
-EXTRA = {"softras.hip": ["-ffp-contract=off"] + (["-DSCP_FAST_GRAD_DIV"] if os.environ.get("SCP_FAST_GRAD_DIV") == "1" else []), "imgops.hip": ["-ffp-contract=off"]}
+EXTRA = {"softras.hip": ["-ffp-contract=off"] + (["-DSCP_FAST_GRAD_DIV"] if os.environ.get("SCP_FAST_GRAD_DIV") == "1" else []), "imgops.hip": ["-ffp-contract=off"], "softras_f64.hip": ["-ffp-contract=off"]}
 
 
 def sources():

@@ -46,6 +46,8 @@ SYMBOLS = {
     "scp_soft_rasterize_backward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _RP, _P]),
     "scp_soft_rasterize_count_pairs": (ctypes.c_int, [_P, _P, _RP, _P]),
     "scp_soft_rasterize_forward_dual": (ctypes.c_int, [_P] * 8 + [_RP, _P]),
+    "scp_soft_rasterize_forward_f64": (ctypes.c_int, [_P] * 5 + [_RP, _P]),
+    "scp_soft_rasterize_backward_f64": (ctypes.c_int, [_P] * 8 + [_RP, _P]),
     "scp_selftest_exact_division": (ctypes.c_int, [ctypes.c_ulonglong, ctypes.c_uint, _P, _P]),
     "scp_vit_linear": (ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 4 + [_P]),
     "scp_fvm_workspace": (ctypes.c_size_t, [ctypes.c_int] * 3),
@@ -129,6 +131,19 @@ def dev_ptr(t, name):
     if t.device.index != torch.cuda.current_device():
         raise RuntimeError("%s lives on cuda:%d but the current device is cuda:%d (torch.cuda.set_device first)"
                            % (name, t.device.index, torch.cuda.current_device()))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def dev_ptr64(t, name):
+    """dev_ptr for the double entry points (scp_soft_rasterize_*_f64)"""
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    if t.dtype != torch.float64:
+        raise RuntimeError("%s must be float64 like the other tensors of this call" % name)
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError("%s lives on cuda:%d but the current device is cuda:%d" % (name, t.device.index, torch.cuda.current_device()))
     return ctypes.c_void_p(t.data_ptr())
 
 

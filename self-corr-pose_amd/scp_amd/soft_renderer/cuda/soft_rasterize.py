@@ -4,7 +4,7 @@ Replaces the pybind module of third-party/softras/soft_renderer/cuda/soft_raster
 (:59-91 forward_soft_rasterize, :94-132 backward_soft_rasterize, :135-138 module def): same
 positional arguments, same in-place/return behaviour (caller allocates and pre-initialises every
 buffer, the same tensors are returned), same RuntimeError on CPU / non-contiguous tensors.  The
-work is done by the HIP kernels in csrc/softras.hip through the C ABI of include/scp_hip.h, on
+work is done by the HIP kernels in csrc/softras.hip (float) / csrc/softras_f64.hip (double) through the C ABI of include/scp_hip.h, on
 torch's current stream (the reference launches on the legacy default stream).
 Difference: launch failures raise instead of being printf'd (kernel.cu:710-712).
 """
@@ -19,15 +19,22 @@ def _params(faces, textures, image_size, near, far, eps, sigma_val, func_id_dist
                              int(texture_sample_type), int(bool(double_side)))
 
 
+def _is_double(t):
+    """AT_DISPATCH_FLOATING_TYPES (soft_rasterize_cuda_kernel.cu:701): float -> the tuned kernels, double -> csrc/softras_f64.hip"""
+    import torch
+    return t.dtype == torch.float64
+
+
 def forward_soft_rasterize(faces, textures, faces_info, aggrs_info, soft_colors, image_size, near,
                            far, eps, sigma_val, func_id_dist, dist_eps, gamma_val, func_id_rgb,
                            func_id_alpha, texture_sample_type, double_side):
     p = _params(faces, textures, image_size, near, far, eps, sigma_val, func_id_dist, dist_eps,
                 gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side)
-    code = capi.lib().scp_soft_rasterize_forward(
-        capi.dev_ptr(faces, "faces"), capi.dev_ptr(textures, "textures"),
-        capi.dev_ptr(faces_info, "faces_info"), capi.dev_ptr(aggrs_info, "aggrs_info"),
-        capi.dev_ptr(soft_colors, "soft_colors"), p, capi.current_stream())
+    f64 = _is_double(faces)
+    ptr = capi.dev_ptr64 if f64 else capi.dev_ptr
+    fn = capi.lib().scp_soft_rasterize_forward_f64 if f64 else capi.lib().scp_soft_rasterize_forward
+    code = fn(ptr(faces, "faces"), ptr(textures, "textures"), ptr(faces_info, "faces_info"), ptr(aggrs_info, "aggrs_info"),
+              ptr(soft_colors, "soft_colors"), p, capi.current_stream())
     capi.check(code, "scp_soft_rasterize_forward")
     return [faces_info, aggrs_info, soft_colors]
 
@@ -56,12 +63,12 @@ def backward_soft_rasterize(faces, textures, soft_colors, faces_info, aggrs_info
                             texture_sample_type, double_side):
     p = _params(faces, textures, image_size, near, far, eps, sigma_val, func_id_dist, dist_eps,
                 gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side)
-    code = capi.lib().scp_soft_rasterize_backward(
-        capi.dev_ptr(faces, "faces"), capi.dev_ptr(textures, "textures"),
-        capi.dev_ptr(soft_colors, "soft_colors"), capi.dev_ptr(faces_info, "faces_info"),
-        capi.dev_ptr(aggrs_info, "aggrs_info"), capi.dev_ptr(grad_faces, "grad_faces"),
-        capi.dev_ptr(grad_textures, "grad_textures"), capi.dev_ptr(grad_soft_colors, "grad_soft_colors"),
-        p, capi.current_stream())
+    f64 = _is_double(faces)
+    ptr = capi.dev_ptr64 if f64 else capi.dev_ptr
+    fn = capi.lib().scp_soft_rasterize_backward_f64 if f64 else capi.lib().scp_soft_rasterize_backward
+    code = fn(ptr(faces, "faces"), ptr(textures, "textures"), ptr(soft_colors, "soft_colors"), ptr(faces_info, "faces_info"),
+              ptr(aggrs_info, "aggrs_info"), ptr(grad_faces, "grad_faces"), ptr(grad_textures, "grad_textures"),
+              ptr(grad_soft_colors, "grad_soft_colors"), p, capi.current_stream())
     capi.check(code, "scp_soft_rasterize_backward")
     return [grad_faces, grad_textures]
 

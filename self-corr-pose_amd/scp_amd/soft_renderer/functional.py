@@ -44,11 +44,11 @@ class SoftRasterizeFunction(Function):
                        bool(fill_back))
         nb, nf = face_vertices.shape[:2]
         fv = face_vertices.detach().reshape(nb, nf, 9).contiguous()
-        tex = textures.detach().reshape(nb, nf, -1, 3).contiguous()
-        dev = fv.device
-        faces_info = torch.zeros(nb, nf, 27, dtype=torch.float32, device=dev)
-        aggrs_info = torch.zeros(nb, 2, image_size, image_size, dtype=torch.float32, device=dev)
-        soft_colors = torch.ones(nb, 4, image_size, image_size, dtype=torch.float32, device=dev)
+        tex = textures.detach().reshape(nb, nf, -1, 3).contiguous().to(fv.dtype)
+        dev, dt = fv.device, fv.dtype           # float or double, like the reference (AT_DISPATCH_FLOATING_TYPES)
+        faces_info = torch.zeros(nb, nf, 27, dtype=dt, device=dev)
+        aggrs_info = torch.zeros(nb, 2, image_size, image_size, dtype=dt, device=dev)
+        soft_colors = torch.ones(nb, 4, image_size, image_size, dtype=dt, device=dev)
         for k in range(3):
             if background_color[k] != 1:
                 soft_colors[:, k].fill_(float(background_color[k]))
