@@ -12,6 +12,10 @@ sys.path.insert(0, os.path.join(ROOT, "self-corr-pose_amd"))
 from scp_amd import capi  # noqa: E402
 
 L = capi.lib()
+if os.environ.get("GEMM_LIB"):          # an ablation build of csrc/vit_gemm.hip (tools/probes), timing only
+    L0, L = L, ctypes.CDLL(os.environ["GEMM_LIB"])
+    for f in ("scp_vit_linear", "scp_row_mean_rstd"):
+        getattr(L, f).argtypes, getattr(L, f).restype = getattr(L0, f).argtypes, getattr(L0, f).restype
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
