@@ -110,6 +110,33 @@ def isolated_attention(B, n_tok, heads, hd, flops, iters=30):
     return {"avg_launch_ms": ms, "achieved": tf, "frac": tf / FP32_VALU_PEAK_TF}
 
 
+def isolated_gemms(M, C=384, iters=20):
+    """the four linear layers of one ViT-S block (qkv, proj, fc1, fc2) alone on an idle device: launch-weighted TFLOP/s"""
+    import scp_amd.dino as dino_mod
+    ms_total, fl_total = 0.0, 0.0
+    for K, N, epi in ((C, 3 * C, dino_mod.GEMM_LN), (C, C, dino_mod.GEMM_BIAS_RESIDUAL), (C, 4 * C, dino_mod.GEMM_LN_GELU),
+                      (4 * C, C, dino_mod.GEMM_BIAS_RESIDUAL)):
+        a = torch.randn(M, K, device="cuda")
+        w = torch.randn(N, K, device="cuda") * 0.05
+        v0, v1 = torch.randn(N, device="cuda"), torch.randn(N, device="cuda")
+        st = torch.rand(M, 2, device="cuda")
+        out = torch.randn(M, N, device="cuda")
+        run = lambda: dino_mod.vit_linear(a, w, v0, v1, st, out, out=out, epilogue=epi)
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms_total += e0.elapsed_time(e1) / iters
+        fl_total += 2.0 * M * N * K
+    tf = fl_total / (ms_total * 1e-3) / 1e12
+    return {"block_ms": ms_total, "achieved": tf, "frac": tf / FP32_VALU_PEAK_TF}
+
+
 def build_trainer(device, world, batch_size=8, repeat=4, seed=0, mixed_bf16=None):
     if mixed_bf16 is None:      # tools/*.py reuse this builder; SCP_MIXED_BF16=1 switches them to configs[4] precision
         mixed_bf16 = os.environ.get("SCP_MIXED_BF16", "0") == "1"
@@ -337,6 +364,9 @@ def main():
                         # per block: qkv (r 384, w 1152), proj (r 384 + 384 residual, w 384), fc1 (r 384, w 1536), fc2 (r 1536 + 384,
                         # w 384) floats per token = 6912; + block 9's K slice (r 384, w 384); + the weights once per launch
                         "algorithmic_bytes_per_step": 4.0 * (B * ((S // 8) ** 2 + 1) * (9 * 6912 + 768) + 9 * 4608 * 384 + 384 * 384),
+                        # the live figure is taken while the encoder / render streams share the device; the four layer
+                        # shapes alone on an idle device, for reference (not the roofline claim):
+                        "isolated": isolated_gemms(B * ((S // 8) ** 2 + 1)),
                         "others": others}
         elif others:
             roofline = dict(next(iter(others.values())), others=others)
