@@ -228,28 +228,30 @@ int scp_color_jitter_normalize(const float* img, int N, int H, int W, const int*
  *   save_{mean,invstd,scale,shift} [C]: written by forward, consumed by backward.
  *   backward: relu/has_skip as in forward; y (the forward output) and dskip are required when both are set
  *   (dskip receives the ReLU-masked gradient; otherwise the skip gradient is dy itself and dskip is unused);
- *   dgamma / dbeta may be NULL.  workspace >= scp_batchnorm_workspace(R, C) bytes. */
+ *   dgamma / dbeta may be NULL.  workspace >= scp_batchnorm_workspace(R, C) bytes.
+ *   ticket: one 32-bit device word owned by this call until it completes, ZERO on entry and left zero: the workgroup that
+ *   arrives last folds the per-block partials (no second launch).  Required when training (forward) and always (backward). */
 size_t scp_batchnorm_workspace(long R, int C);
 int scp_batchnorm_act_forward(const float* x, const float* skip, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, long long* batches_tracked, float momentum,
                               float eps, long R, int C, int relu, int training, float* y, float* save_mean,
                               float* save_invstd, float* save_scale, float* save_shift, void* workspace,
-                              size_t workspace_bytes, void* stream);
+                              size_t workspace_bytes, unsigned* ticket, void* stream);
 int scp_batchnorm_act_backward(const float* dy, const float* x, const float* y, const float* save_mean,
                                const float* save_invstd, const float* save_scale, const float* save_shift, long R,
                                int C, int relu, int has_skip, int training, float* dx, float* dskip, float* dgamma,
-                               float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+                               float* dbeta, void* workspace, size_t workspace_bytes, unsigned* ticket, void* stream);
 /* the same two with bf16 activation storage (x, skip, y, dy, dx, dskip; BASELINE configs[4] precision) -- parameters,
  * statistics, saved vectors and workspace stay fp32, arithmetic is fp32 */
 int scp_batchnorm_act_forward_bf16(const void* x, const void* skip, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, long long* batches_tracked, float momentum,
                                    float eps, long R, int C, int relu, int training, void* y, float* save_mean,
                                    float* save_invstd, float* save_scale, float* save_shift, void* workspace,
-                                   size_t workspace_bytes, void* stream);
+                                   size_t workspace_bytes, unsigned* ticket, void* stream);
 int scp_batchnorm_act_backward_bf16(const void* dy, const void* x, const void* y, const float* save_mean,
                                     const float* save_invstd, const float* save_scale, const float* save_shift, long R,
                                     int C, int relu, int has_skip, int training, void* dx, void* dskip, float* dgamma,
-                                    float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+                                    float* dbeta, void* workspace, size_t workspace_bytes, unsigned* ticket, void* stream);
 
 /* ---- test-time pose fitting: batched RANSAC + Umeyama similarity fit -----------------------------------
  * Replaces model/util/umeyama.py (estimateSimilarityTransform :9-38, getRANSACInliers :97-121,

@@ -60,6 +60,15 @@ __device__ __forceinline__ void st4(__bf16* p, float4 v) {
 }
 __device__ __forceinline__ float bn_apply(float x, float scale, float shift) { return fmaf(x, scale, shift); }
 
+// write-through stores (sc1): visible to the other XCDs once complete, without a release fence -- a release fence at agent
+// scope writes back the WHOLE L2 of the XCD (buffer_wbl2), per workgroup, which cost more than the launch it was meant to save
+__device__ __forceinline__ void st4_agent(float* p, float4 v) {
+    __hip_atomic_store(p + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // folds the row lanes of a block in a fixed order and stores the block's partial for 4 channels
 __device__ __forceinline__ void fold_rows(float4 a, float4 b, int tc_n, int ri_n, float* pa, float* pb, int C,
                                           float4* lds) {
@@ -74,15 +83,110 @@ __device__ __forceinline__ void fold_rows(float4 a, float4 b, int tc_n, int ri_n
             sa.x += u.x; sa.y += u.y; sa.z += u.z; sa.w += u.w;
             sb.x += v.x; sb.y += v.y; sb.z += v.z; sb.w += v.w;
         }
-        st4(pa + (size_t)blockIdx.x * C + 4 * tc, sa);
-        st4(pb + (size_t)blockIdx.x * C + 4 * tc, sb);
+        st4_agent(pa + (size_t)blockIdx.x * C + 4 * tc, sa);
+        st4_agent(pb + (size_t)blockIdx.x * C + 4 * tc, sb);
     }
+}
+
+// ---- last-block finalisation.  The per-(block, channel) fp32 partials are folded in fp64 by whichever workgroup of the
+// SAME launch arrives last at a ticket counter (write-through partials -> atomic ticket -> acquire fence), not by a second tiny
+// launch: inside the training step such a launch (<= 256 workgroups of work for a few microseconds) waited 37-57 us in the
+// dispatcher behind the other streams' kernels, 84 times per step.  The fold order depends only on (blocks, C), never on
+// which workgroup happens to be last, so results stay deterministic.  The ticket word is zero on entry and is re-armed
+// (zeroed) by the last workgroup.
+__device__ __forceinline__ bool last_block_arrived(unsigned* ticket) {
+    __shared__ int is_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this thread's write-through partial stores have completed ...
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the ticket
+        is_last = t == gridDim.x - 1;
+        if (is_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!is_last) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // one workgroup: drop what this XCD's L2 may hold of the partial buffers
+    return true;
+}
+
+// all BN_THREADS threads: thread (tc, ri) strides over the blocks k = ri, ri + ri_n, ... with up to 16 independent float4
+// loads in flight, accumulates in fp64, then the ri_n lanes of a channel quad are added in lane order.  Returns true in the
+// threads (ri == 0) that hold the totals of channels 4*tc .. 4*tc+3.
+__device__ __forceinline__ bool fold_partials(const float* __restrict__ pa, const float* __restrict__ pb, int blocks, int C,
+                                              int tc_n, double (&sa)[4], double (&sb)[4]) {
+    __shared__ double fl[2][BN_THREADS][4];
+    const int ri_n = BN_THREADS / tc_n;
+    const int tc = threadIdx.x % tc_n, ri = threadIdx.x / tc_n;
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = ri; k0 < blocks; k0 += 8 * ri_n) {
+        float4 u[8], v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = k0 + j * ri_n;
+            const size_t o = (size_t)(k < blocks ? k : k0) * C + 4 * tc;
+            u[j] = ld4(pa + o);
+            v[j] = ld4(pb + o);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (k0 + j * ri_n < blocks) {
+                a[0] += (double)u[j].x; a[1] += (double)u[j].y; a[2] += (double)u[j].z; a[3] += (double)u[j].w;
+                b[0] += (double)v[j].x; b[1] += (double)v[j].y; b[2] += (double)v[j].z; b[3] += (double)v[j].w;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { fl[0][threadIdx.x][i] = a[i]; fl[1][threadIdx.x][i] = b[i]; }
+    __syncthreads();
+    if (ri != 0) return false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { sa[i] = 0.0; sb[i] = 0.0; }
+    for (int k = 0; k < ri_n; k++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) { sa[i] += fl[0][k * tc_n + tc][i]; sb[i] += fl[1][k * tc_n + tc][i]; }
+    return true;
+}
+
+struct FwdFinalize {
+    long R;
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    long long* batches_tracked;
+    float momentum, eps;
+    float *mean_out, *invstd_out, *scale_out, *shift_out;
+};
+
+// per channel: batch statistics -> (mean, invstd, scale, shift) and the running-stat update
+__device__ __forceinline__ void finalize_channel(const FwdFinalize& f, int c, bool training, double s, double q) {
+    float mean, invstd;
+    if (training) {
+        const double m = s / (double)f.R;
+        double var = q / (double)f.R - m * m;
+        if (var < 0.0) var = 0.0;
+        mean = (float)m;
+        invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+        if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mean;
+        if (f.running_var) {
+            const double unbiased = f.R > 1 ? var * ((double)f.R / (double)(f.R - 1)) : var;
+            f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
+        }
+    } else {
+        mean = f.running_mean[c];
+        invstd = 1.f / sqrtf(f.running_var[c] + f.eps);
+    }
+    const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+    const float scale = g * invstd;
+    f.mean_out[c] = mean;
+    f.invstd_out[c] = invstd;
+    f.scale_out[c] = scale;
+    f.shift_out[c] = b - mean * scale;
 }
 
 template <typename T>
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restrict__ x, long R, int C, int tc_n,
                                                               int rows_per_block, float* __restrict__ psum,
-                                                              float* __restrict__ psq) {
+                                                              float* __restrict__ psq, unsigned* __restrict__ ticket,
+                                                              const FwdFinalize fin) {
     __shared__ float4 lds[2 * BN_THREADS];
     const int ri_n = BN_THREADS / tc_n;
     const int tc = threadIdx.x % tc_n, ri = threadIdx.x / tc_n;
@@ -95,80 +199,18 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restric
         q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
     }
     fold_rows(s, q, tc_n, ri_n, psum, psq, C, lds);
-}
-
-// Folds the per-block partials of two quantities for FIN_CH channels per workgroup: FIN_LANES lanes per
-// channel stride over the blocks in fp64, then lane 0 adds the lanes in a fixed order (deterministic).
-// (64 lanes per channel and four independent fp64 partial sums per lane: with <= 1024 blocks a lane has at most 16 loads,
-// issued four at a time -- the fold used to be a chain of up to 64 dependent load+add steps, 27 us per launch, 84 launches
-// per training step.)
-// 256-thread workgroups (4 channels x 64 lanes): a 1024-thread workgroup has to find 16 free wavefront slots on ONE CU and
-// sat in the dispatcher behind the other streams' kernels (57 us per launch measured).
-constexpr int FIN_CH = 4, FIN_LANES = 64;
-
-__device__ __forceinline__ bool fold_blocks(const float* __restrict__ pa, const float* __restrict__ pb, int blocks,
-                                            int C, double& sa, double& sb, int& c) {
-    __shared__ double lds[2][FIN_LANES][FIN_CH];
-    const int ch = threadIdx.x % FIN_CH, lane = threadIdx.x / FIN_CH;
-    c = blockIdx.x * FIN_CH + ch;
-    double a = 0.0, b = 0.0;
-    if (c < C) {
-        double a4[4] = {0.0, 0.0, 0.0, 0.0}, b4[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int k0 = lane; k0 < blocks; k0 += 4 * FIN_LANES) {
+    if (!last_block_arrived(ticket)) return;
+    if (threadIdx.x == 0 && fin.batches_tracked) *fin.batches_tracked += 1;
+    double sa[4], sb[4];
+    if (!fold_partials(psum, psq, (int)gridDim.x, C, tc_n, sa, sb)) return;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int k = k0 + u * FIN_LANES;
-                if (k < blocks) {
-                    a4[u] += (double)pa[(size_t)k * C + c];
-                    b4[u] += (double)pb[(size_t)k * C + c];
-                }
-            }
-        }
-        a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-        b = (b4[0] + b4[1]) + (b4[2] + b4[3]);
-    }
-    lds[0][lane][ch] = a;
-    lds[1][lane][ch] = b;
-    __syncthreads();
-    if (lane != 0 || c >= C) return false;
-    sa = 0.0; sb = 0.0;
-    for (int k = 0; k < FIN_LANES; k++) { sa += lds[0][k][ch]; sb += lds[1][k][ch]; }
-    return true;
+    for (int i = 0; i < 4; i++) finalize_channel(fin, 4 * tc + i, true, sa[i], sb[i]);
 }
 
-// per channel: batch statistics -> (mean, invstd, scale, shift) and the running-stat update
-__global__ void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int blocks, long R,
-                                   int C, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   long long* __restrict__ batches_tracked, float momentum, float eps, int training,
-                                   float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && training && batches_tracked) *batches_tracked += 1;
-    int c;
-    double s = 0.0, q = 0.0;
-    if (!fold_blocks(psum, psq, training ? blocks : 0, C, s, q, c)) return;
-    float mean, invstd;
-    if (training) {
-        const double m = s / (double)R;
-        double var = q / (double)R - m * m;
-        if (var < 0.0) var = 0.0;
-        mean = (float)m;
-        invstd = (float)(1.0 / sqrt(var + (double)eps));
-        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        if (running_var) {
-            const double unbiased = R > 1 ? var * ((double)R / (double)(R - 1)) : var;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-        }
-    } else {
-        mean = running_mean[c];
-        invstd = 1.f / sqrtf(running_var[c] + eps);
-    }
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    const float scale = g * invstd;
-    mean_out[c] = mean;
-    invstd_out[c] = invstd;
-    scale_out[c] = scale;
-    shift_out[c] = b - mean * scale;
+// eval mode: no batch statistics, one thread per channel
+__global__ void bn_eval_finalize_kernel(int C, const FwdFinalize fin) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) finalize_channel(fin, c, false, 0.0, 0.0);
 }
 
 template <typename T, bool SKIP, bool RELU>
@@ -198,7 +240,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y, long R, int C, int tc_n,
     int rows_per_block, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ scale, const float* __restrict__ shift, T* __restrict__ g_out,
-    float* __restrict__ pg, float* __restrict__ pgx) {
+    float* __restrict__ pg, float* __restrict__ pgx, unsigned* __restrict__ ticket, int training, float* __restrict__ c1,
+    float* __restrict__ c2, float* __restrict__ dgamma, float* __restrict__ dbeta) {
     __shared__ float4 lds[2 * BN_THREADS];
     const int ri_n = BN_THREADS / tc_n;
     const int tc = threadIdx.x % tc_n, ri = threadIdx.x / tc_n;
@@ -232,19 +275,18 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
         q.w = fmaf(g.w, (v.w - mu.w) * is.w, q.w);
     }
     fold_rows(s, q, tc_n, ri_n, pg, pgx, C, lds);
-}
-
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ pg, const float* __restrict__ pgx, int blocks, long R,
-                                       int C, int training, float* __restrict__ c1, float* __restrict__ c2,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    int c;
-    double s = 0.0, q = 0.0;
-    if (!fold_blocks(pg, pgx, blocks, C, s, q, c)) return;
-    if (dgamma) dgamma[c] = (float)q;
-    if (dbeta) dbeta[c] = (float)s;
-    // eval mode: the statistics are constants, dx = scale * g
-    c1[c] = training ? (float)(s / (double)R) : 0.f;
-    c2[c] = training ? (float)(q / (double)R) : 0.f;
+    if (!last_block_arrived(ticket)) return;
+    double sa[4], sb[4];
+    if (!fold_partials(pg, pgx, (int)gridDim.x, C, tc_n, sa, sb)) return;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = 4 * tc + i;
+        if (dgamma) dgamma[c] = (float)sb[i];
+        if (dbeta) dbeta[c] = (float)sa[i];
+        // eval mode: the statistics are constants, dx = scale * g
+        c1[c] = training ? (float)(sa[i] / (double)R) : 0.f;
+        c2[c] = training ? (float)(sb[i] / (double)R) : 0.f;
+    }
 }
 
 template <typename T, int MODE>
@@ -293,9 +335,9 @@ template <typename T>
 int bn_forward_impl(const T* x, const T* skip, const float* gamma, const float* beta, float* running_mean, float* running_var,
                     long long* batches_tracked, float momentum, float eps, long R, int C, int relu, int training, T* y,
                     float* save_mean, float* save_invstd, float* save_scale, float* save_shift, void* workspace,
-                    size_t workspace_bytes, void* stream) {
+                    size_t workspace_bytes, unsigned* ticket, void* stream) {
     if (bad_shape(R, C)) return scp::fail(hipErrorInvalidValue, "batchnorm: C must be a power of two in [16,1024], R > 0");
-    if (!x || !y || !save_mean || !save_invstd || !save_scale || !save_shift)
+    if (!x || !y || !save_mean || !save_invstd || !save_scale || !save_shift || (training && !ticket))
         return scp::fail(hipErrorInvalidValue, "batchnorm: null argument");
     if (!training && (!running_mean || !running_var))
         return scp::fail(hipErrorInvalidValue, "batchnorm: eval mode needs running statistics");
@@ -304,14 +346,16 @@ int bn_forward_impl(const T* x, const T* skip, const float* gamma, const float* 
     const Geometry g = geometry(R, C);
     float* psum = static_cast<float*>(workspace);
     float* psq = psum + (size_t)g.blocks * C;
+    const FwdFinalize fin{R, gamma, beta, running_mean, running_var, batches_tracked, momentum, eps, save_mean, save_invstd,
+                          save_scale, save_shift};
     if (training) {
-        hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(g.blocks), dim3(BN_THREADS), 0, st, x, R, C, g.tc, g.rows_per_block, psum, psq);
+        hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(g.blocks), dim3(BN_THREADS), 0, st, x, R, C, g.tc, g.rows_per_block, psum, psq,
+                           ticket, fin);
         if (int e = scp::check_launch("batchnorm stats")) return e;
+    } else {
+        hipLaunchKernelGGL(bn_eval_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, fin);
+        if (int e = scp::check_launch("batchnorm finalize")) return e;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, psum, psq, g.blocks, R, C,
-                       gamma, beta, running_mean, running_var, batches_tracked, momentum, eps, training, save_mean, save_invstd,
-                       save_scale, save_shift);
-    if (int e = scp::check_launch("batchnorm finalize")) return e;
     const long quads = R * C / 4;
     const dim3 grid((unsigned)((quads + BN_THREADS - 1) / BN_THREADS));
 #define SCP_BN_APPLY(S, A) \
@@ -327,9 +371,10 @@ int bn_forward_impl(const T* x, const T* skip, const float* gamma, const float* 
 template <typename T>
 int bn_backward_impl(const T* dy, const T* x, const T* y, const float* save_mean, const float* save_invstd,
                      const float* save_scale, const float* save_shift, long R, int C, int relu, int has_skip, int training, T* dx,
-                     T* dskip, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+                     T* dskip, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, unsigned* ticket,
+                     void* stream) {
     if (bad_shape(R, C)) return scp::fail(hipErrorInvalidValue, "batchnorm: C must be a power of two in [16,1024], R > 0");
-    if (!dy || !x || !dx || !save_mean || !save_invstd || !save_scale || !save_shift)
+    if (!dy || !x || !dx || !save_mean || !save_invstd || !save_scale || !save_shift || !ticket)
         return scp::fail(hipErrorInvalidValue, "batchnorm backward: null argument");
     const int mode = !relu ? 0 : (has_skip ? 2 : 1);
     if (mode == 2 && (!y || !dskip)) return scp::fail(hipErrorInvalidValue, "batchnorm backward: residual form needs y and dskip");
@@ -342,15 +387,13 @@ int bn_backward_impl(const T* dy, const T* x, const T* y, const float* save_mean
     float* c2 = c1 + C;
 #define SCP_BN_REDUCE(M) \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M>), dim3(g.blocks), dim3(BN_THREADS), 0, st, dy, x, y, R, C, g.tc, \
-                       g.rows_per_block, save_mean, save_invstd, save_scale, save_shift, dskip, pg, pgx)
+                       g.rows_per_block, save_mean, save_invstd, save_scale, save_shift, dskip, pg, pgx, ticket, training, c1, c2, \
+                       dgamma, dbeta)
     if (mode == 0) SCP_BN_REDUCE(0);
     else if (mode == 1) SCP_BN_REDUCE(1);
     else SCP_BN_REDUCE(2);
 #undef SCP_BN_REDUCE
     if (int e = scp::check_launch("batchnorm backward reduce")) return e;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, st, pg, pgx, g.blocks, R, C,
-                       training, c1, c2, dgamma, dbeta);
-    if (int e = scp::check_launch("batchnorm backward finalize")) return e;
     const long quads = R * C / 4;
     const dim3 grid((unsigned)((quads + BN_THREADS - 1) / BN_THREADS));
     // with a residual the masked gradient was written to dskip by the reduce pass: read that, no mask work
@@ -370,18 +413,18 @@ extern "C" int scp_batchnorm_act_forward(const float* x, const float* skip, cons
                                          float* running_mean, float* running_var, long long* batches_tracked,
                                          float momentum, float eps, long R, int C, int relu, int training, float* y,
                                          float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
-                                         void* workspace, size_t workspace_bytes, void* stream) {
+                                         void* workspace, size_t workspace_bytes, unsigned* ticket, void* stream) {
     return bn_forward_impl<float>(x, skip, gamma, beta, running_mean, running_var, batches_tracked, momentum, eps, R, C, relu, training, y,
-                                  save_mean, save_invstd, save_scale, save_shift, workspace, workspace_bytes, stream);
+                                  save_mean, save_invstd, save_scale, save_shift, workspace, workspace_bytes, ticket, stream);
 }
 
 extern "C" int scp_batchnorm_act_backward(const float* dy, const float* x, const float* y, const float* save_mean,
                                           const float* save_invstd, const float* save_scale, const float* save_shift,
                                           long R, int C, int relu, int has_skip, int training, float* dx, float* dskip,
                                           float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
-                                          void* stream) {
+                                          unsigned* ticket, void* stream) {
     return bn_backward_impl<float>(dy, x, y, save_mean, save_invstd, save_scale, save_shift, R, C, relu, has_skip, training, dx, dskip,
-                                   dgamma, dbeta, workspace, workspace_bytes, stream);
+                                   dgamma, dbeta, workspace, workspace_bytes, ticket, stream);
 }
 
 // bf16 activation storage (BASELINE configs[4] precision); parameters, statistics and workspace are fp32 as above
@@ -389,18 +432,18 @@ extern "C" int scp_batchnorm_act_forward_bf16(const void* x, const void* skip, c
                                               float* running_mean, float* running_var, long long* batches_tracked,
                                               float momentum, float eps, long R, int C, int relu, int training, void* y,
                                               float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
-                                              void* workspace, size_t workspace_bytes, void* stream) {
+                                              void* workspace, size_t workspace_bytes, unsigned* ticket, void* stream) {
     return bn_forward_impl<__bf16>(static_cast<const __bf16*>(x), static_cast<const __bf16*>(skip), gamma, beta, running_mean, running_var,
                                    batches_tracked, momentum, eps, R, C, relu, training, static_cast<__bf16*>(y), save_mean,
-                                   save_invstd, save_scale, save_shift, workspace, workspace_bytes, stream);
+                                   save_invstd, save_scale, save_shift, workspace, workspace_bytes, ticket, stream);
 }
 
 extern "C" int scp_batchnorm_act_backward_bf16(const void* dy, const void* x, const void* y, const float* save_mean,
                                                const float* save_invstd, const float* save_scale, const float* save_shift,
                                                long R, int C, int relu, int has_skip, int training, void* dx, void* dskip,
                                                float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
-                                               void* stream) {
+                                               unsigned* ticket, void* stream) {
     return bn_backward_impl<__bf16>(static_cast<const __bf16*>(dy), static_cast<const __bf16*>(x), static_cast<const __bf16*>(y), save_mean,
                                     save_invstd, save_scale, save_shift, R, C, relu, has_skip, training, static_cast<__bf16*>(dx),
-                                    static_cast<__bf16*>(dskip), dgamma, dbeta, workspace, workspace_bytes, stream);
+                                    static_cast<__bf16*>(dskip), dgamma, dbeta, workspace, workspace_bytes, ticket, stream);
 }

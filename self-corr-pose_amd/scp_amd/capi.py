@@ -63,13 +63,13 @@ SYMBOLS = {
     "scp_color_jitter_normalize": (ctypes.c_int, [_P, _I, _I, _I, _P, _P, _P, _F, _P, _P, _I, _P, _P, ctypes.c_size_t, _P]),
     "scp_batchnorm_workspace": (ctypes.c_size_t, [ctypes.c_long, _I]),
     "scp_batchnorm_act_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _F, ctypes.c_long, _I, _I, _I, _P, _P, _P,
-                                                _P, _P, _P, ctypes.c_size_t, _P]),
+                                                _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "scp_batchnorm_act_backward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _I, _P, _P, _P, _P,
-                                                 _P, ctypes.c_size_t, _P]),
+                                                 _P, ctypes.c_size_t, _P, _P]),
     "scp_batchnorm_act_forward_bf16": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _F, ctypes.c_long, _I, _I, _I, _P, _P, _P,
-                                                     _P, _P, _P, ctypes.c_size_t, _P]),
+                                                     _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "scp_batchnorm_act_backward_bf16": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _I, _P, _P, _P, _P,
-                                                      _P, ctypes.c_size_t, _P]),
+                                                      _P, ctypes.c_size_t, _P, _P]),
     "scp_posefit_workspace": (ctypes.c_size_t, [_I, _I, _I]),
     "scp_ransac_hypotheses": (ctypes.c_int, [_P, _P, _I, _I, _P, _I, _P, _P]),
     "scp_ransac_score": (ctypes.c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P, ctypes.c_size_t, _P]),
@@ -117,6 +117,26 @@ def current_stream():
     go to the current device, so tensors must live there: Trainer / Tester call torch.cuda.set_device(their device), and
     dev_ptr() rejects a tensor from another device instead of faulting on a foreign pointer."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_TICKETS = {}
+_TICKET_WORDS = 8192
+
+
+def ticket(device):
+    """pointer to one ZEROED 32-bit device word for a kernel that elects its last workgroup (include/scp_hip.h: `ticket`);
+    the kernel leaves it zero.  A pool of 8192 words per device handed out round-robin: a word is reused only after 8191
+    later launches have been enqueued."""
+    import torch
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    pool = _TICKETS.get(key)
+    if pool is None:
+        buf = torch.zeros(_TICKET_WORDS, dtype=torch.int32, device=device)
+        torch.cuda.current_stream(device).synchronize()      # the fill must be complete before ANY stream uses a word
+        pool = _TICKETS[key] = [buf, 0]
+    i = pool[1]
+    pool[1] = (i + 1) % _TICKET_WORDS
+    return ctypes.c_void_p(pool[0].data_ptr() + 4 * i)
 
 
 def dev_ptr(t, name):

@@ -53,7 +53,7 @@ class _BatchNormAct(Function):
             _ptr(x), _ptr(skip), _ptr(weight), _ptr(bias), _ptr(bn.running_mean), _ptr(bn.running_var),
             _ptr(bn.num_batches_tracked if bn.track_running_stats else None), float(momentum), float(bn.eps), rows, c,
             int(relu), int(training), _ptr(y), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]),
-            _ptr(ws), ws_bytes, capi.current_stream()), "batchnorm_act_forward")
+            _ptr(ws), ws_bytes, capi.ticket(x.device), capi.current_stream()), "batchnorm_act_forward")
         residual_relu = relu and skip is not None
         ctx.save_for_backward(x, y if residual_relu else None, stats)
         ctx.cfg = (rows, c, bool(relu), skip is not None, bool(training), weight is not None, bias is not None)
@@ -77,7 +77,7 @@ class _BatchNormAct(Function):
         capi.check(bwd(
             _ptr(dy), _ptr(x), _ptr(y), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), rows, c,
             int(relu), int(has_skip), int(training), _ptr(dx), _ptr(dskip), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
-            ws_bytes, capi.current_stream()), "batchnorm_act_backward")
+            ws_bytes, capi.ticket(x.device), capi.current_stream()), "batchnorm_act_backward")
         if has_skip and dskip is None:
             dskip = dy
         return dx, (dskip if has_skip else None), dgamma, dbeta, None, None

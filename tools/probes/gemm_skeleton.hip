@@ -133,6 +133,7 @@ void run(const float* src, size_t n, float* out, int chunks) {
 int main() {
     const size_t n = (size_t)1 << 28;      // 1 GiB of floats
     float *src, *out; hipMalloc(&src, n * 4); hipMemset(src, 0, n * 4); hipMalloc(&out, 768 * 256 * 4);
+    for (int c : {24, 72, 96, 288}) { printf("chunks %d: ", c); run<14 + 128>(src, n, out, c); }
     const int chunks = 24 * 12;
     run<0>(src, n, out, chunks); run<1>(src, n, out, chunks); run<2>(src, n, out, chunks); run<3>(src, n, out, chunks);
     run<4>(src, n, out, chunks); run<5>(src, n, out, chunks); run<6>(src, n, out, chunks); run<7>(src, n, out, chunks);
