@@ -113,8 +113,10 @@ __device__ __forceinline__ bool last_block_arrived(unsigned* ticket) {
 // loads in flight, accumulates in fp64, then the ri_n lanes of a channel quad are added in lane order.  Returns true in the
 // threads (ri == 0) that hold the totals of channels 4*tc .. 4*tc+3.
 __device__ __forceinline__ bool fold_partials(const float* __restrict__ pa, const float* __restrict__ pb, int blocks, int C,
-                                              int tc_n, double (&sa)[4], double (&sb)[4]) {
-    __shared__ double fl[2][BN_THREADS][4];
+                                              int tc_n, double (&sa)[4], double (&sb)[4], float4* lds) {
+    // the caller's 8 KB row-fold buffer is reused as 256 x 4 doubles, once per quantity: these kernels run beside LDS-heavy
+    // kernels of the other streams and only get on a CU while their own LDS request fits into what is left
+    double(*fl)[4] = reinterpret_cast<double(*)[4]>(lds);
     const int ri_n = BN_THREADS / tc_n;
     const int tc = threadIdx.x % tc_n, ri = threadIdx.x / tc_n;
     double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
@@ -135,15 +137,27 @@ __device__ __forceinline__ bool fold_partials(const float* __restrict__ pa, cons
             }
         }
     }
+    __syncthreads();            // the row fold's reads of `lds` are complete in every wavefront
 #pragma unroll
-    for (int i = 0; i < 4; i++) { fl[0][threadIdx.x][i] = a[i]; fl[1][threadIdx.x][i] = b[i]; }
+    for (int i = 0; i < 4; i++) fl[threadIdx.x][i] = a[i];
+    __syncthreads();
+    if (ri == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) sa[i] = 0.0;
+        for (int k = 0; k < ri_n; k++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) sa[i] += fl[k * tc_n + tc][i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) fl[threadIdx.x][i] = b[i];
     __syncthreads();
     if (ri != 0) return false;
 #pragma unroll
-    for (int i = 0; i < 4; i++) { sa[i] = 0.0; sb[i] = 0.0; }
+    for (int i = 0; i < 4; i++) sb[i] = 0.0;
     for (int k = 0; k < ri_n; k++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) { sa[i] += fl[0][k * tc_n + tc][i]; sb[i] += fl[1][k * tc_n + tc][i]; }
+        for (int i = 0; i < 4; i++) sb[i] += fl[k * tc_n + tc][i];
     return true;
 }
 
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restric
     if (!last_block_arrived(ticket)) return;
     if (threadIdx.x == 0 && fin.batches_tracked) *fin.batches_tracked += 1;
     double sa[4], sb[4];
-    if (!fold_partials(psum, psq, (int)gridDim.x, C, tc_n, sa, sb)) return;
+    if (!fold_partials(psum, psq, (int)gridDim.x, C, tc_n, sa, sb, lds)) return;
 #pragma unroll
     for (int i = 0; i < 4; i++) finalize_channel(fin, 4 * tc + i, true, sa[i], sb[i]);
 }
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
     fold_rows(s, q, tc_n, ri_n, pg, pgx, C, lds);
     if (!last_block_arrived(ticket)) return;
     double sa[4], sb[4];
-    if (!fold_partials(pg, pgx, (int)gridDim.x, C, tc_n, sa, sb)) return;
+    if (!fold_partials(pg, pgx, (int)gridDim.x, C, tc_n, sa, sb, lds)) return;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int c = 4 * tc + i;

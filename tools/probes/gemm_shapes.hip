@@ -110,7 +110,12 @@ int main() {
     const size_t n = (size_t)1 << 28;
     float *src, *out; hipMalloc(&src, n * 4); hipMemset(src, 0, n * 4); hipMalloc(&out, 1024 * 1024 * 4 * 4);
     const unsigned mask = (unsigned)(n - 1) & ~3u;
-    for (int K : {1536, 4608}) {
+    for (int K : {384, 1536, 4608}) {
+        run<2, 3, 2, 4, 16, 3, 1>(src, mask, out, K);
+        run<2, 3, 2, 4, 16, 4, 1>(src, mask, out, K);
+        run<2, 3, 4, 2, 16, 3, 1>(src, mask, out, K);
+        run<2, 6, 2, 2, 16, 3, 1>(src, mask, out, K);
+        run<4, 3, 1, 4, 16, 3, 1>(src, mask, out, K);
         run<2, 2, 2, 2, 16, 3, 3>(src, mask, out, K);
         run<2, 2, 2, 2, 16, 4, 2>(src, mask, out, K);
         run<2, 2, 2, 2, 32, 2, 2>(src, mask, out, K);
