@@ -190,6 +190,60 @@ def cpu_baseline(sample_bs=8, sample_repeat=4):
                                       "batch itself, %.1f s" % (n_img, sample_bs, sample_repeat, dt)}
 
 
+def reference_kernels_same_gpu(batch=32, size=256):
+    """Baseline leg, beside cpu_baseline: the REFERENCE's own SoftRas kernels (oracle/_ref: soft_rasterize_cuda_kernel.cu
+    :22-671 compiled unchanged for gfx950, default FMA contraction like the authors' nvcc build, reference launch geometry)
+    against libscp_hip.so on the same MI355X, the four render passes of Renderer.render_all at the bench size, forward and
+    backward launch times (HIP events, 10 launches each).  None when oracle/_ref was not built (needs /root/reference)."""
+    from oracle import ref_gpu
+    if not ref_gpu.available():
+        return None
+    from scp_amd import synthetic
+    from scp_amd.soft_renderer.cuda import soft_rasterize as native
+    passes = {
+        "mask": dict(sigma_val=1e-4, gamma_val=1e-4, aggr_func_rgb="hard", texture_type="surface"),
+        "depth": dict(sigma_val=1e-4, gamma_val=1e-4, aggr_func_rgb="softmax", texture_type="vertex"),
+        "softtex": dict(sigma_val=1e-3, gamma_val=1e-2, aggr_func_rgb="softmax", texture_type="vertex"),
+        "hardtex": dict(sigma_val=1e-4, gamma_val=1e-3, aggr_func_rgb="hard", texture_type="vertex"),
+    }
+    v, f = synthetic.bottle_like(3)
+    fv_np, ftex_np = synthetic.raster_inputs(v, f, batch, seed=0)
+    fv = torch.tensor(fv_np, device="cuda").reshape(batch, -1, 9).contiguous()
+    F_ = fv.shape[1]
+
+    def timed(fn, iters=10):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    out = {}
+    for name, cfg in passes.items():
+        tex = (torch.ones(batch, F_, 1, 3, device="cuda") if name == "mask"
+               else torch.tensor(ftex_np, device="cuda").reshape(batch, F_, 3, 3).contiguous())
+        scal = ref_gpu.scalars(image_size=size, dist_func="euclidean", aggr_func_alpha="prod", **cfg)
+        info = torch.zeros(batch, F_, 27, device="cuda")
+        aggr = torch.zeros(batch, 2, size, size, device="cuda")
+        col = torch.ones(batch, 4, size, size, device="cuda")
+        gf, gt, g = torch.zeros_like(fv), torch.zeros_like(tex), torch.randn(batch, 4, size, size, device="cuda")
+        row = {}
+        for who, fwd, bwd in (("reference", lambda: ref_gpu.forward(fv, tex, info, aggr, col, *scal, variant="contract"),
+                               lambda: ref_gpu.backward(fv, tex, col, info, aggr, gf, gt, g, *scal, variant="contract")),
+                              ("own", lambda: native.forward_soft_rasterize(fv, tex, info, aggr, col, *scal),
+                               lambda: native.backward_soft_rasterize(fv, tex, col, info, aggr, gf, gt, g, *scal))):
+            aggr.zero_()
+            row[who + "_fwd_ms"] = round(timed(fwd), 4)
+            row[who + "_bwd_ms"] = round(timed(bwd), 4)
+        out[name] = row
+    return {"what": "reference SoftRas kernels (oracle/_ref, hipcc gfx950, reference launch geometry) vs libscp_hip.so, "
+                    "B=%d %dx%d %d faces, ms per launch" % (batch, size, size, F_), **out}
+
+
 def bench_posefit(args):
     """SURVEY 8f #4 beside the headline: one step = Tester.pose_fitting over a batch of 32 images (256x256, 100 RANSAC
     rounds each), inputs resident in HBM.  cpu_baseline = the numpy restatement of the reference's per-image loop
@@ -384,6 +438,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            try:        # same-GPU brute-force baseline: the reference's own rasteriser kernels (baseline leg, not the product)
+                out["cpu_baseline"]["same_gpu_reference_kernels"] = reference_kernels_same_gpu()
+            except Exception as e:  # noqa: BLE001 -- a baseline figure must not take the bench line down
+                out["cpu_baseline"]["same_gpu_reference_kernels"] = {"error": repr(e)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
