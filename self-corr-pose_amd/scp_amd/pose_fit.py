@@ -170,6 +170,12 @@ def estimateSimilarityTransform(source, target, verbose=False):
     return scale[0].reshape(-1).repeat(3), rotation[0], translation[0], transform[0]
 
 
+def _rows_times_3x3(a, m):
+    """a [B,N,3] @ m [B,3,3] spelled out with a fixed evaluation order: a BLAS batched GEMM may pick a different kernel (and
+    summation order) for a different batch size, and a frame's pose must not depend on which other frames share its batch"""
+    return a[..., 0:1] * m[:, None, 0, :] + a[..., 1:2] * m[:, None, 1, :] + a[..., 2:3] * m[:, None, 2, :]
+
+
 class PoseFitter:
     """the part of Tester that pose_fitting needs: image size and the `base_rot` flag (tester.py:130-150)"""
 
@@ -216,8 +222,8 @@ class PoseFitter:
         translation = (translation * 0.001).reshape(-1, 1, 3)
         scale_fit = (scale[:, None].repeat(1, 3) * 0.001).reshape(-1, 1, 3)
         base_rot = self.base_rot.to(pred_v.device).repeat(bsz, 1, 1)
-        pred_v = pred_v.bmm(base_rot.permute(0, 2, 1))
-        rotation = base_rot.bmm(rotation)
+        pred_v = _rows_times_3x3(pred_v, base_rot.permute(0, 2, 1))
+        rotation = _rows_times_3x3(base_rot, rotation)
         lo, hi = pred_v.min(1).values, pred_v.max(1).values
         corners = [(lo + hi) / 2]
         for sx in (lo, hi):
@@ -225,6 +231,6 @@ class PoseFitter:
                 for sz in (lo, hi):
                     corners.append(torch.stack((sx[:, 0], sy[:, 1], sz[:, 2]), -1))
         bbox = torch.stack(corners, -2)
-        bbox = (bbox * scale_fit).bmm(rotation) + translation
-        verts = (pred_v * scale_fit).bmm(rotation) + translation
+        bbox = _rows_times_3x3(bbox * scale_fit, rotation) + translation
+        verts = _rows_times_3x3(pred_v * scale_fit, rotation) + translation
         return bbox, verts, rotation, translation
