@@ -174,8 +174,17 @@ class Trainer:
         save_dir = os.path.join(opts.checkpoint_dir, opts.name)
         history, t0 = [], time.time()
         pending = []                                   # device scalars; read back only at log time (no per-step sync)
-        for i, batch in enumerate(loader):
-            total, aux, grad = self.step(self.batch_reshape(batch))
+        # one batch of look-ahead: the frozen-DINO features of batch i+1 are enqueued during the backward of batch i (step())
+        it = iter(loader)
+        nxt = next(it, None)
+        nxt_dev = self.batch_reshape(nxt) if nxt is not None else None
+        i = -1
+        while nxt is not None:
+            i += 1
+            batch, data = nxt, nxt_dev
+            nxt = next(it, None)
+            nxt_dev = self.batch_reshape(nxt) if nxt is not None else None
+            total, aux, grad = self.step(data, next_data=nxt_dev)
             pending.append(total.detach())
             if (i + 1) % opts.batch_log_interval == 0:
                 vals = torch.stack(pending).cpu().tolist()
