@@ -340,6 +340,50 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
     }
 }
 
+// C = 384 (every LayerNorm of ViT-S): 16 lanes per row (6 float4 each, 256 B contiguous per load instruction), two rows per
+// thread in flight, reductions inside the 16-lane DPP row (quad_perm / row_half_mirror / row_mirror: no LDS, no ds_bpermute
+// chains -- the generic kernel below spends most of its 50 us in 48 dependent cross-lane steps per wavefront).
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float x) {
+    x += dpp_get<0xB1>(x);      // lane ^ 1
+    x += dpp_get<0x4E>(x);      // lane ^ 2
+    x += dpp_get<0x141>(x);     // lane ^ 7 (row_half_mirror)
+    x += dpp_get<0x140>(x);     // lane ^ 15 (row_mirror)
+    return x;
+}
+__global__ __launch_bounds__(256) void row_stats384_kernel(const float* __restrict__ x, float* __restrict__ stats, int rows,
+                                                           float eps) {
+    constexpr int C = 384;
+    const int sub = threadIdx.x & 15;
+    const int row0 = blockIdx.x * 32 + (threadIdx.x >> 4);          // rows row0 and row0 + 16
+    float4 v[2][6];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)min(row0 + 16 * r, rows - 1) * C);
+#pragma unroll
+        for (int i = 0; i < 6; i++) v[r][i] = xr[sub + 16 * i];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) s += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+        const float mean = row16_sum(s) / C;
+        float q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const float dx = v[r][i].x - mean, dy = v[r][i].y - mean, dz = v[r][i].z - mean, dw = v[r][i].w - mean;
+            q2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        q2 = row16_sum(q2);
+        const int row = row0 + 16 * r;
+        if (sub == 0 && row < rows) *reinterpret_cast<float2*>(stats + 2 * (size_t)row) = make_float2(mean, 1.f / sqrtf(q2 / C + eps));
+    }
+}
+
 // resident workgroup slots of the device: 3 workgroups per CU (launch bounds), a multiple of 8 so that tile t and tile
 // t + grid land on the same XCD
 int resident_slots() {
@@ -395,7 +439,11 @@ extern "C" int scp_vit_linear(const float* A, const float* W, const float* vec0,
 extern "C" int scp_row_mean_rstd(const float* x, float* stats, int rows, int C, float eps, void* stream) {
     if (rows <= 0) return 0;
     if (C <= 0 || C > 1536 || (C & 3)) return scp::fail(hipErrorInvalidValue, "row_mean_rstd: C must be a multiple of 4 in 4..1536");
-    hipLaunchKernelGGL(row_stats_kernel, dim3((rows + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), x, stats, rows,
-                       C, eps);
+    if (C == 384)
+        hipLaunchKernelGGL(row_stats384_kernel, dim3((rows + 31) / 32), dim3(256), 0, static_cast<hipStream_t>(stream), x, stats, rows,
+                           eps);
+    else
+        hipLaunchKernelGGL(row_stats_kernel, dim3((rows + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), x, stats, rows,
+                           C, eps);
     return scp::check_launch("row_mean_rstd");
 }
