@@ -289,6 +289,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-isolated", action="store_true",
+                    help="skip the isolated-kernel reference figures (profiling runs: keeps extra launches out of the trace)")
     ap.add_argument("--mixed-bf16", action="store_true",
                     help="BASELINE configs[4] precision (bf16 convolutions / ViT linears, fp32 elsewhere); NOT the headline")
     ap.add_argument("--workload", choices=["train", "posefit"], default="train",
@@ -403,7 +405,7 @@ def main():
                 "algorithmic_flops_per_launch": flops, "launches_per_step": 9,
                 # the live figure is taken while the encoder / render streams share the device; the same kernel alone on
                 # an idle device, for reference (not the roofline claim):
-                "isolated": isolated_attention(B, n_tok, heads, hd, flops)}
+                "isolated": None if args.no_isolated else isolated_attention(B, n_tok, heads, hd, flops)}
         roofline = None
         if gemm_total_ms:
             fl = float(np.sum(gemm_flops[-gemm_launches:]))
@@ -420,7 +422,7 @@ def main():
                         "algorithmic_bytes_per_step": 4.0 * (B * ((S // 8) ** 2 + 1) * (9 * 6912 + 768) + 9 * 4608 * 384 + 384 * 384),
                         # the live figure is taken while the encoder / render streams share the device; the four layer
                         # shapes alone on an idle device, for reference (not the roofline claim):
-                        "isolated": isolated_gemms(B * ((S // 8) ** 2 + 1)),
+                        "isolated": None if args.no_isolated else isolated_gemms(B * ((S // 8) ** 2 + 1)),
                         "others": others}
         elif others:
             roofline = dict(next(iter(others.values())), others=others)
