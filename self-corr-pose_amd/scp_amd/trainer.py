@@ -80,6 +80,7 @@ class Trainer:
         self.model.train()
         self.optim = Optimizers(opts, self.model)
         self.iteration = 0
+        self._steps_done = 0                            # steps run by THIS process (the first one is the solver-search step)
         named = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad]
         self._mean_v = [p for n, p in named if "mean_v" in n]
         self._shapenerf = [p for n, p in named if "mean_v" not in n and "shapenerf" in n]
@@ -151,10 +152,24 @@ class Trainer:
         iterations; the next step finds them ready).  Per-step work is unchanged."""
         self.model.iters = self.iteration
         self.grads.prepare()                            # zero_grad: clears the flat buffer, p.grad = its views
-        total_loss, aux_output = self.model(data)
-        if next_data is not None:
-            self.model.pretrain_corr_net.prefetch_features(next_data[0])
-        total_loss.mean().backward()
+        # The first step of a process is where MIOpen's solver search (cudnn.benchmark) times its candidates for every
+        # convolution shape, forward and backward.  It runs without the side streams, so that the search measures
+        # undisturbed kernels instead of kernels sharing the device with the ViT / the second encoder pass (the winners
+        # are cached per process; a perturbed search can settle on slower solvers for the whole run).
+        serial = self._steps_done == 0 and self.device.type == "cuda"
+        if serial:
+            saved = (getattr(self.model, "overlap_dino", True), getattr(self.model, "overlap_rotation_cycle", True))
+            self.model.overlap_dino = self.model.overlap_rotation_cycle = False
+            next_data = None
+        try:
+            total_loss, aux_output = self.model(data)
+            if next_data is not None:
+                self.model.pretrain_corr_net.prefetch_features(next_data[0])
+            total_loss.mean().backward()
+        finally:
+            if serial:
+                self.model.overlap_dino, self.model.overlap_rotation_cycle = saved
+        self._steps_done += 1
         grad = self.collect_grad()
         self.optim.step(self.iteration)
         self.iteration += 1
