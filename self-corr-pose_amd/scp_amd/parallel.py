@@ -25,10 +25,13 @@ import torch.distributed as dist
 
 
 class FlatGradients:
-    def __init__(self, params, process_group=None, bucket_bytes=25 << 20, distributed=None):
+    def __init__(self, params, process_group=None, bucket_bytes=25 << 20, distributed=None, force_collectives=False):
+        """force_collectives: run the hook / communication-stream / all-reduce path even in a 1-rank group (lets the RCCL path be
+        exercised on a single GPU, tests/test_parallel.py)"""
         self.group = process_group
         self.distributed = dist.is_initialized() if distributed is None else distributed
         self.world = dist.get_world_size(process_group) if self.distributed else 1
+        self.active = self.world > 1 or (force_collectives and self.distributed)
         self.params = [p for p in params if p.requires_grad]
         assert self.params, "no trainable parameters"
         dev, dt = self.params[0].device, self.params[0].dtype
@@ -54,9 +57,9 @@ class FlatGradients:
         self._armed = False
         self._silent, self._fired = set(), set()
         self.launched_in_backward = 0          # buckets whose collective was enqueued from a hook (test / log)
-        self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" and self.world > 1 else None
+        self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" and self.active else None
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -154,7 +157,7 @@ class FlatGradients:
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
                 p.grad = v
-        if self.world > 1:
+        if self.active:
             for i in range(len(self.buckets)):
                 if self._work[i] is None:
                     self._launch(i)

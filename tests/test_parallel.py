@@ -165,3 +165,36 @@ def test_bucket_all_reduce_overlaps_backward_gloo_world2():
 
 def test_trainer_step_data_parallel_gloo_world2():
     _run(_trainer_worker)
+
+
+@pytest.mark.gpu
+def test_flat_gradients_over_rccl_single_rank():
+    """the CUDA side of the overlapped all-reduce (communication stream, events, async RCCL work objects, views with
+    channels_last strides) on ONE GPU: a 1-rank nccl group with force_collectives -- the sum over one rank must equal plain
+    autograd, buckets must go out from the hooks, and a second step must reuse the same buffers"""
+    for p in (ROOT, os.path.join(ROOT, "self-corr-pose_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from scp_amd.parallel import FlatGradients
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(16, 8, 3, padding=1),
+                                  torch.nn.Flatten(), torch.nn.Linear(8 * 16 * 16, 10)).cuda().to(memory_format=torch.channels_last)
+        x = torch.randn(4, 3, 16, 16, device="cuda").contiguous(memory_format=torch.channels_last)
+        ref = torch.autograd.grad(net(x).square().sum(), list(net.parameters()))
+        red = FlatGradients(net.parameters(), bucket_bytes=4096, distributed=True, force_collectives=True)
+        assert red.active and red.comm_stream is not None and len(red.buckets) > 1
+        for step in range(2):
+            red.prepare()
+            net(x).square().sum().backward()
+            flat = red.finish()
+            torch.cuda.synchronize()
+            assert red.launched_in_backward >= len(red.buckets) - 1, (red.launched_in_backward, len(red.buckets))
+            for p, g in zip(net.parameters(), ref):
+                assert p.grad.data_ptr() == red.views[id(p)].data_ptr() and p.grad.stride() == p.stride()
+                torch.testing.assert_close(p.grad, g, rtol=1e-5, atol=1e-6)
+            assert flat.data_ptr() == red.flat.data_ptr()
+    finally:
+        dist.destroy_process_group()
