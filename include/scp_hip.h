@@ -253,6 +253,16 @@ int scp_batchnorm_act_backward_bf16(const void* dy, const void* x, const void* y
                                     int C, int relu, int has_skip, int training, void* dx, void* dskip, float* dgamma,
                                     float* dbeta, void* workspace, size_t workspace_bytes, unsigned* ticket, void* stream);
 
+/* ---- encoder: 3x3 / stride 1 / pad 1 convolution, NHWC fp32, implicit GEMM on the fp32 matrix cores ---------------------
+ * Replaces the nn.Conv2d(k=3, s=1, p=1) calls of torchvision's BasicBlock and of the U-decoder's conv units as instantiated by
+ * model/module/network/image_encoder.py:119-193 (F.conv2d on MIOpen in the reference / round 1).
+ *   x [N,H,W,Cin], w [Cout,3,3,Cin] (= the channels_last storage of a [Cout,Cin,3,3] tensor), bias [Cout] or NULL,
+ *   y [N,H,W,Cout];  zeros64: >= 64 bytes of zeros on the device (source of the padding taps).
+ * The input gradient is the same call with dy as x, Cin <-> Cout and w transposed + flipped ([Cin,3,3,Cout], tap (2-ky, 2-kx)).
+ * Requires Cin % 16 == 0 and N*H*W % 128 == 0 (else hipErrorInvalidValue: the caller keeps its library convolution). */
+int scp_conv3x3_nhwc_forward(const float* x, const float* w, const float* bias, const float* zeros64, float* y, int N, int H,
+                             int W, int Cin, int Cout, void* stream);
+
 /* ---- test-time pose fitting: batched RANSAC + Umeyama similarity fit -----------------------------------
  * Replaces model/util/umeyama.py (estimateSimilarityTransform :9-38, getRANSACInliers :97-121,
  * evaluateModel :123-131, estimateSimilarityUmeyama :161-201) as called per image by Tester.pose_fitting
