@@ -164,3 +164,36 @@ def test_bn_act_bf16_storage(skip, relu):
         close(sg.grad, ds_ref, 1e-2)
     close(bn_g.running_mean, bn_ref.running_mean, 1e-5)
     close(bn_g.running_var, bn_ref.running_var, 1e-5)
+
+
+@pytest.mark.gpu
+def test_bn_act_on_concurrent_streams_is_deterministic():
+    """the last-workgroup fold of the statistics works through per-call ticket words: BatchNorm calls in flight on two
+    streams at once (the two encoder passes of the training step) must neither disturb each other nor depend on timing"""
+    from scp_amd.fused_bn import bn_act
+    torch.manual_seed(0)
+    shapes = [(8, 64, 32, 32), (8, 128, 16, 16), (4, 256, 8, 8), (16, 64, 64, 64)]
+    xs = [torch.randn(s, device="cuda").contiguous(memory_format=torch.channels_last) for s in shapes]
+    bns = [torch.nn.BatchNorm2d(s[1]).cuda().train() for s in shapes]
+
+    def run(x, bn):
+        xr = x.clone().requires_grad_(True)
+        y = bn_act(xr, bn, None, True)
+        (g,) = torch.autograd.grad(y.square().sum(), xr)
+        return y.detach().clone(), g.clone()
+
+    serial = [run(x, bn) for x, bn in zip(xs, bns)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(20):
+        outs = [None] * len(xs)
+        for i, (x, bn) in enumerate(zip(xs, bns)):
+            st = streams[i % 2]
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs[i] = run(x, bn)
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+        for (y, g), (y0, g0) in zip(outs, serial):
+            assert torch.equal(y, y0) and torch.equal(g, g0), rep
