@@ -86,10 +86,15 @@ class Correspondence:
         # every image gets the same rotation of the same grid: rotate one copy
         cycle_match_gt = imgops.rotate(grid[:1], angle, "nearest").expand(bsz, -1, -1, -1).reshape(bsz, 2, -1)
 
-        _, tgt_feat = encoder.encode_img(tgt_img)                                   # b,c,hf*wf (unit norm)
         src_mask_down = F.interpolate(src_mask, (hh, wh), mode="nearest").reshape(bsz, -1)
         tgt_mask_down = F.interpolate(tgt_mask, (hh, wh), mode="nearest").reshape(bsz, -1)
-        tgt_half = F.interpolate(tgt_feat.reshape(bsz, c, self.hf, self.wf), (hh, wh), mode="nearest").reshape(bsz, c, -1)
+        if getattr(encoder, "supports_half_res", False) and self.hf % 2 == 0 and self.wf % 2 == 0:
+            # nearest down-sampling by exactly 2 keeps the even pixels: ask the encoder for those only (the last decoder
+            # unit and the projection then run on a quarter of the pixels; same values)
+            _, tgt_half = encoder.encode_img(tgt_img, half_res=True)                # b,c,hh*wh (unit norm)
+        else:
+            _, tgt_feat = encoder.encode_img(tgt_img)                               # b,c,hf*wf (unit norm)
+            tgt_half = F.interpolate(tgt_feat.reshape(bsz, c, self.hf, self.wf), (hh, wh), mode="nearest").reshape(bsz, c, -1)
         src_half = F.interpolate(src_img_feat.reshape(bsz, c, self.hf, self.wf), (hh, wh), mode="nearest").reshape(bsz, c, -1)
 
         cycle_match = ops.pixel_pixel_softargmax(src_half, tgt_half, src_mask_down, tgt_mask_down,

@@ -11,6 +11,8 @@ from .nets import MeshEncoder, PosePredictor, ResNet_Decoder, ResNet_Encoder, Sh
 
 
 class Encoder(nn.Module):
+    supports_half_res = True       # encode_img(img, half_res=True), used by Correspondence.compute_rotation_cycle_loss
+
     def __init__(self, opts):
         super().__init__()
         self.opts = opts
@@ -24,7 +26,8 @@ class Encoder(nn.Module):
         self.shape_predictor = ShapePredictor(opts)
         self.pose_predictor = PosePredictor(opts, 512)
 
-    def encode_img(self, img):
+    def encode_img(self, img, half_res=False):
+        """half_res: features at the even pixels of the feature map only (nets.ResNet_Decoder.forward)"""
         x = imgops.jitter_normalize(img, self.random_jitter, self.resnet_transform)
         if x.is_cuda:
             # NHWC end to end: MIOpen's fp32 implicit-GEMM kernels and PyTorch's NHWC bilinear
@@ -34,7 +37,7 @@ class Encoder(nn.Module):
         # BASELINE configs[4]: convolutions on the bf16 matrix cores, everything after them in fp32
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(getattr(self.opts, "mixed_bf16", False)) and x.is_cuda):
             c2, c3, c4, c5 = self.backbone(x)
-            feat = self.featnet(c2, c3, c4, c5)
+            feat = self.featnet(c2, c3, c4, c5, half_res=half_res)
         img_code = c5.float().mean((2, 3))
         feat = feat.float().contiguous().reshape(img.shape[0], self.opts.n_corr_feat, -1)
         return img_code, F.normalize(feat, 2, 1)

@@ -110,8 +110,11 @@ class _ConvUnit(nn.Module):
         super().__init__()
         self.cbr_unit = nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1, bias=True), nn.LeakyReLU(0.1, inplace=True))
 
-    def forward(self, x):
-        return self.cbr_unit(x)
+    def forward(self, x, stride=1):
+        if stride == 1:
+            return self.cbr_unit(x)
+        conv = self.cbr_unit[0]            # only every `stride`-th output pixel is wanted: the same weights as a strided convolution
+        return F.leaky_relu(F.conv2d(x, conv.weight, conv.bias, stride, 1), 0.1)
 
 
 class _Upsample2x(torch.autograd.Function):
@@ -154,12 +157,17 @@ class ResNet_Decoder(nn.Module):
             return _Upsample2x.apply(x)
         return F.interpolate(x, like.shape[2:], mode="bilinear", align_corners=False)
 
-    def forward(self, c2, c3, c4, c5):
+    def forward(self, c2, c3, c4, c5, half_res=False):
+        """half_res: return the feature map at its even pixels only ([.., ::2, ::2] of the full result, exactly): the last
+        3x3 unit runs as a stride-2 convolution and the projection on a quarter of the pixels.  The rotation-cycle loss
+        (correspondence.py:91-96) subsamples the rotated images' features this way and uses nothing else of them."""
         c4 = self.iconv4(torch.cat((c4, self.upconv5(self._up(c5, c4))), 1))
         c3 = self.iconv3(torch.cat((c3, self.upconv4(self._up(c4, c3))), 1))
-        c2 = self.iconv2(torch.cat((c2, self.upconv3(self._up(c3, c2))), 1))
-        feat = c2 if self.downsample == 4 else c3
-        return self.proj(feat) if self.is_proj else feat
+        if self.downsample != 4:
+            feat = c3[:, :, ::2, ::2] if half_res else c3
+            return self.proj(feat) if self.is_proj else feat
+        c2 = self.iconv2(torch.cat((c2, self.upconv3(self._up(c3, c2))), 1), stride=2 if half_res else 1)
+        return self.proj(c2) if self.is_proj else c2
 
 
 # ------------------------------------------------------------------------------------------------

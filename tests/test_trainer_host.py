@@ -151,3 +151,42 @@ def test_flat_gradient_views_follow_the_parameter_layout():
         assert p.grad.data_ptr() == fg.views[id(p)].data_ptr()
         torch.testing.assert_close(p.grad, e)
     assert abs(float(flat.abs().sum()) - float(sum(e.abs().sum() for e in expect))) < 1e-3 * float(flat.abs().sum())
+
+
+def test_half_resolution_features_are_the_even_pixels_of_the_full_map():
+    """ResNet_Decoder.forward(half_res=True) / Encoder.encode_img(half_res=True) (used for the rotated images of the
+    rotation-cycle loss) == the full feature map at its even pixels, values and gradients"""
+    import torch
+    import scp_amd.dino as dino
+    from scp_amd.encoder import Encoder
+    from scp_amd.flags import Options
+    from scp_amd.nets import ResNet_Decoder
+    torch.manual_seed(0)
+    for downsample in (4, 8):
+        dec = ResNet_Decoder(is_proj=True, out_channel=16, downsample=downsample).double()
+        pyr = [torch.randn(2, ch, s, s, dtype=torch.float64, requires_grad=True) for ch, s in ((64, 16), (128, 8), (256, 4), (512, 2))]
+        full = dec(*pyr)[:, :, ::2, ::2]
+        half = dec(*pyr, half_res=True)
+        torch.testing.assert_close(half, full, rtol=1e-12, atol=1e-13)
+        w = torch.randn_like(half)
+        leaves = pyr + list(dec.parameters())
+        g_half = torch.autograd.grad((half * w).sum(), leaves, allow_unused=True)
+        g_full = torch.autograd.grad((full * w).sum(), leaves, allow_unused=True)
+        for a, b in zip(g_half, g_full):
+            assert (a is None) == (b is None)
+            if a is not None:
+                torch.testing.assert_close(a, b, rtol=1e-10, atol=1e-12)
+    # through the whole encoder (its output is cast to float32, hence the float32-level tolerance)
+    opts = Options("laptop_wild6d", batch_size=1, repeat=2, train=True, img_size=64)
+    old, dino.ALLOW_RANDOM_INIT = dino.ALLOW_RANDOM_INIT, True
+    try:
+        enc = Encoder(opts).eval()               # eval: BatchNorm on running statistics
+    finally:
+        dino.ALLOW_RANDOM_INIT = old
+    enc.random_jitter = torch.nn.Identity()      # no colour-jitter draw between the two calls
+    img = torch.rand(2, 3, 64, 64)
+    _, full = enc.encode_img(img)
+    _, half = enc.encode_img(img, half_res=True)
+    c = opts.n_corr_feat
+    hf = int(round(full.shape[-1] ** 0.5))
+    torch.testing.assert_close(half, full.reshape(2, c, hf, hf)[:, :, ::2, ::2].reshape(2, c, -1), rtol=1e-5, atol=1e-6)
