@@ -316,6 +316,9 @@ int scp_mutual_argmax(const float* scores, const float* rowmask, const float* co
  * (model/module/network/image_encoder.py:141-193), NHWC fp32, exact factor two only:
  *   grad_out [N,2H,2W,C] -> grad_in [N,H,W,C], C % 4 == 0.  Gather form, no atomics, deterministic. */
 int scp_upsample2x_bilinear_backward(const float* grad_out, float* grad_in, int N, int H, int W, int C, void* stream);
+/* the forward itself (same formula as ATen's align_corners=False for an exact factor of two): in [N,H,W,C] -> out [N,2H,2W,C] */
+int scp_upsample2x_bilinear_forward(const float* in, float* out, int N, int H, int W, int C, void* stream);
+int scp_upsample2x_bilinear_forward_bf16(const void* in, void* out, int N, int H, int W, int C, void* stream);
 /* same with bf16 storage (configs[4] precision; accumulation in fp32) */
 int scp_upsample2x_bilinear_backward_bf16(const void* grad_out, void* grad_in, int N, int H, int W, int C, void* stream);
 

@@ -79,6 +79,8 @@ SYMBOLS = {
     "scp_mutual_argmax_workspace": (ctypes.c_size_t, [_I, _I]),
     "scp_mutual_argmax": (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, ctypes.c_size_t, _P]),
     "scp_upsample2x_bilinear_backward": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "scp_upsample2x_bilinear_forward": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "scp_upsample2x_bilinear_forward_bf16": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "scp_upsample2x_bilinear_backward_bf16": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "scp_vit_attention_bf16_forward": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "scp_add_layernorm_forward": (ctypes.c_int, [_P, _P, _P, _P, _F, ctypes.c_long, _I, _P, _P, _P]),

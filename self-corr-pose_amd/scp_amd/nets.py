@@ -118,13 +118,20 @@ class _ConvUnit(nn.Module):
 
 
 class _Upsample2x(torch.autograd.Function):
-    """exact-2x bilinear upsampling, NHWC fp32 (or bf16 in configs[4] precision): ATen forward, HIP gather backward (csrc/upsample.hip) instead of ATen's
-    atomicAdd scatter -- deterministic and ~5x faster at the decoder's sizes"""
+    """exact-2x bilinear upsampling, NHWC fp32 (or bf16 in configs[4] precision), csrc/upsample.hip: forward (ATen's NHWC kernel
+    runs at 0.7 TB/s here) and a gather backward instead of ATen's atomicAdd scatter -- deterministic and ~5x faster"""
 
     @staticmethod
     def forward(ctx, x):
+        import ctypes
+        from . import capi
         ctx.shape = x.shape
-        return F.interpolate(x, (x.shape[2] * 2, x.shape[3] * 2), mode="bilinear", align_corners=False)
+        n, c, h, w = x.shape
+        out = torch.empty((n, c, 2 * h, 2 * w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        fn = capi.lib().scp_upsample2x_bilinear_forward if x.dtype == torch.float32 else capi.lib().scp_upsample2x_bilinear_forward_bf16
+        capi.check(fn(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), n, h, w, c, capi.current_stream()),
+                   "upsample2x_bilinear_forward")
+        return out
 
     @staticmethod
     def backward(ctx, g):
