@@ -263,6 +263,19 @@ int scp_batchnorm_act_backward_bf16(const void* dy, const void* x, const void* y
 int scp_conv3x3_nhwc_forward(const float* x, const float* w, const float* bias, const float* zeros64, float* y, int N, int H,
                              int W, int Cin, int Cout, void* stream);
 
+/* ---- decoder conv units: bias + LeakyReLU around a bias-free library convolution --------------------------------------
+ * Replaces, in `conv(x) -> + bias -> LeakyReLU(0.1)` of image_encoder.py:141-193 (nn.Conv2d(bias=True) + nn.LeakyReLU, inplace):
+ * the broadcast bias add and the activation (one in-place pass over y [R = N*H*W, C], NHWC), and in backward the activation
+ * backward and the bias-gradient reduction (one pass: g = dy * (y > 0 ? 1 : slope), dbias[c] = sum over rows of g).
+ * workspace >= scp_batchnorm_workspace(R, C) bytes, `ticket` as for scp_batchnorm_act_*; dbias may be NULL.  C a power of two
+ * in [16, 1024]. */
+int scp_bias_leaky_relu_forward(float* y, const float* bias, float slope, long R, int C, void* stream);
+int scp_bias_leaky_relu_forward_bf16(void* y, const float* bias, float slope, long R, int C, void* stream);
+int scp_bias_leaky_relu_backward(const float* dy, const float* y, float slope, long R, int C, float* g, float* dbias,
+                                 void* workspace, size_t workspace_bytes, unsigned* ticket, void* stream);
+int scp_bias_leaky_relu_backward_bf16(const void* dy, const void* y, float slope, long R, int C, void* g, float* dbias,
+                                      void* workspace, size_t workspace_bytes, unsigned* ticket, void* stream);
+
 /* ---- test-time pose fitting: batched RANSAC + Umeyama similarity fit -----------------------------------
  * Replaces model/util/umeyama.py (estimateSimilarityTransform :9-38, getRANSACInliers :97-121,
  * evaluateModel :123-131, estimateSimilarityUmeyama :161-201) as called per image by Tester.pose_fitting

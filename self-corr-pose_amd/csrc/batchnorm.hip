@@ -334,6 +334,57 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T* __restri
     st4(dx + 4 * i, o);
 }
 
+// ---- decoder conv units: y = LeakyReLU(conv(x) + bias) (image_encoder.py:141-193).  The library convolution is called
+// without its bias; bias add and activation are ONE in-place pass, and the backward is one pass that writes the gradient of the
+// pre-activation and the per-(block, channel) partial sums of the bias gradient, folded by the last-arriving workgroup
+// (through ATen: a broadcast add, an in-place activation, an activation backward and a separate reduction over N*H*W).
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bias_leaky_fwd_kernel(T* __restrict__ y, const float* __restrict__ bias, long quads,
+                                                                    int tc_n, float slope) {
+    const long i = (long)blockIdx.x * BN_THREADS + threadIdx.x;
+    if (i >= quads) return;
+    const float4 b = ld4(bias + 4 * (int)(i % tc_n));
+    float4 v = ld4(y + 4 * i);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    v.x = v.x > 0.f ? v.x : slope * v.x;
+    v.y = v.y > 0.f ? v.y : slope * v.y;
+    v.z = v.z > 0.f ? v.z : slope * v.z;
+    v.w = v.w > 0.f ? v.w : slope * v.w;
+    st4(y + 4 * i, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bias_leaky_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, long R, int C,
+                                                                    int tc_n, int rows_per_block, float slope, T* __restrict__ g_out,
+                                                                    float* __restrict__ pa, float* __restrict__ pb,
+                                                                    unsigned* __restrict__ ticket, float* __restrict__ dbias) {
+    __shared__ float4 lds[2 * BN_THREADS];
+    const int ri_n = BN_THREADS / tc_n;
+    const int tc = threadIdx.x % tc_n, ri = threadIdx.x / tc_n;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(r0 + rows_per_block, R);
+    float4 s = {0, 0, 0, 0};
+    const float4 zero = {0, 0, 0, 0};
+    for (long r = r0 + ri; r < r1; r += ri_n) {
+        const size_t o = r * C + 4 * tc;
+        float4 g = ld4(dy + o);
+        const float4 out = ld4(y + o);               // slope > 0: the output has the sign of the pre-activation
+        if (!(out.x > 0.f)) g.x *= slope;
+        if (!(out.y > 0.f)) g.y *= slope;
+        if (!(out.z > 0.f)) g.z *= slope;
+        if (!(out.w > 0.f)) g.w *= slope;
+        st4(g_out + o, g);
+        s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+    }
+    fold_rows(s, zero, tc_n, ri_n, pa, pb, C, lds);
+    if (!dbias || !last_block_arrived(ticket)) return;
+    double sa[4], sb[4];
+    if (!fold_partials(pa, pb, (int)gridDim.x, C, tc_n, sa, sb, lds)) return;
+#pragma unroll
+    for (int i = 0; i < 4; i++) dbias[4 * tc + i] = (float)sa[i];
+}
+
+
 bool bad_shape(long R, int C) { return R <= 0 || C < 16 || C > 1024 || (C & (C - 1)) != 0; }
 
 }  // namespace
@@ -460,4 +511,45 @@ extern "C" int scp_batchnorm_act_backward_bf16(const void* dy, const void* x, co
     return bn_backward_impl<__bf16>(static_cast<const __bf16*>(dy), static_cast<const __bf16*>(x), static_cast<const __bf16*>(y), save_mean,
                                     save_invstd, save_scale, save_shift, R, C, relu, has_skip, training, static_cast<__bf16*>(dx),
                                     static_cast<__bf16*>(dskip), dgamma, dbeta, workspace, workspace_bytes, ticket, stream);
+}
+
+namespace {
+template <typename T>
+int bias_leaky_fwd(T* y, const float* bias, float slope, long R, int C, void* stream) {
+    if (bad_shape(R, C)) return scp::fail(hipErrorInvalidValue, "bias_leaky: C must be a power of two in [16,1024], R > 0");
+    if (!y || !bias) return scp::fail(hipErrorInvalidValue, "bias_leaky: null argument");
+    const long quads = R * C / 4;
+    hipLaunchKernelGGL(bias_leaky_fwd_kernel<T>, dim3((unsigned)((quads + BN_THREADS - 1) / BN_THREADS)), dim3(BN_THREADS), 0,
+                       static_cast<hipStream_t>(stream), y, bias, quads, C / 4, slope);
+    return scp::check_launch("bias_leaky forward");
+}
+template <typename T>
+int bias_leaky_bwd(const T* dy, const T* y, float slope, long R, int C, T* g, float* dbias, void* workspace, size_t workspace_bytes,
+                   unsigned* ticket, void* stream) {
+    if (bad_shape(R, C)) return scp::fail(hipErrorInvalidValue, "bias_leaky: C must be a power of two in [16,1024], R > 0");
+    if (!dy || !y || !g || (dbias && !ticket)) return scp::fail(hipErrorInvalidValue, "bias_leaky backward: null argument");
+    if (workspace_bytes < scp_batchnorm_workspace(R, C)) return scp::fail(hipErrorInvalidValue, "bias_leaky: workspace too small");
+    const Geometry ge = geometry(R, C);
+    float* pa = static_cast<float*>(workspace);
+    float* pb = pa + (size_t)ge.blocks * C;
+    hipLaunchKernelGGL(bias_leaky_bwd_kernel<T>, dim3(ge.blocks), dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), dy, y, R, C, ge.tc,
+                       ge.rows_per_block, slope, g, pa, pb, ticket, dbias);
+    return scp::check_launch("bias_leaky backward");
+}
+}  // namespace
+
+extern "C" int scp_bias_leaky_relu_forward(float* y, const float* bias, float slope, long R, int C, void* stream) {
+    return bias_leaky_fwd<float>(y, bias, slope, R, C, stream);
+}
+extern "C" int scp_bias_leaky_relu_forward_bf16(void* y, const float* bias, float slope, long R, int C, void* stream) {
+    return bias_leaky_fwd<__bf16>(static_cast<__bf16*>(y), bias, slope, R, C, stream);
+}
+extern "C" int scp_bias_leaky_relu_backward(const float* dy, const float* y, float slope, long R, int C, float* g, float* dbias,
+                                            void* workspace, size_t workspace_bytes, unsigned* ticket, void* stream) {
+    return bias_leaky_bwd<float>(dy, y, slope, R, C, g, dbias, workspace, workspace_bytes, ticket, stream);
+}
+extern "C" int scp_bias_leaky_relu_backward_bf16(const void* dy, const void* y, float slope, long R, int C, void* g, float* dbias,
+                                                 void* workspace, size_t workspace_bytes, unsigned* ticket, void* stream) {
+    return bias_leaky_bwd<__bf16>(static_cast<const __bf16*>(dy), static_cast<const __bf16*>(y), slope, R, C, static_cast<__bf16*>(g), dbias,
+                                  workspace, workspace_bytes, ticket, stream);
 }

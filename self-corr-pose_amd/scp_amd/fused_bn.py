@@ -93,3 +93,55 @@ def bn_act(x, bn, skip=None, relu=False):
     if not _fused_ok(x, bn, skip):
         return _composition(x, bn, skip, relu)
     return _BatchNormAct.apply(x, skip, bn.weight, bn.bias, bn, relu)
+
+
+class _BiasLeakyReLU(Function):
+    """y = leaky_relu(y0 + bias, slope) in place on the (bias-free) convolution output y0, NHWC (csrc/batchnorm.hip
+    scp_bias_leaky_relu_*): one pass forward, one pass backward (gradient of the pre-activation + bias gradient)"""
+
+    @staticmethod
+    def forward(ctx, y0, bias, slope):
+        L = capi.lib()
+        n, c, h, w = y0.shape
+        rows = n * h * w
+        fwd = L.scp_bias_leaky_relu_forward if y0.dtype == torch.float32 else L.scp_bias_leaky_relu_forward_bf16
+        capi.check(fwd(_ptr(y0), _ptr(bias), float(slope), rows, c, capi.current_stream()), "bias_leaky_relu_forward")
+        ctx.mark_dirty(y0)
+        ctx.save_for_backward(y0)
+        ctx.cfg = (rows, c, float(slope))
+        return y0
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = capi.lib()
+        (y,) = ctx.saved_tensors
+        rows, c, slope = ctx.cfg
+        dy = _nhwc(dy.to(y.dtype))
+        g = torch.empty_like(y)
+        want_b = ctx.needs_input_grad[1]
+        dbias = torch.empty(c, dtype=torch.float32, device=y.device) if want_b else None
+        ws_bytes = L.scp_batchnorm_workspace(rows, c)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=y.device)
+        bwd = L.scp_bias_leaky_relu_backward if y.dtype == torch.float32 else L.scp_bias_leaky_relu_backward_bf16
+        capi.check(bwd(_ptr(dy), _ptr(y), slope, rows, c, _ptr(g), _ptr(dbias), _ptr(ws), ws_bytes, capi.ticket(y.device),
+                       capi.current_stream()), "bias_leaky_relu_backward")
+        return g, dbias, None
+
+
+def bias_leaky_ok(y0, bias):
+    c = y0.shape[1] if y0.dim() == 4 else 0
+    return (y0.is_cuda and y0.dtype in (torch.float32, torch.bfloat16) and y0.dim() == 4 and bias is not None
+            and bias.dtype == torch.float32 and 16 <= c <= 1024 and (c & (c - 1)) == 0
+            and y0.is_contiguous(memory_format=torch.channels_last))
+
+
+def conv_bias_leaky(x, conv, slope=0.1, stride=None):
+    """leaky_relu(conv(x), slope) for an nn.Conv2d with bias: on CUDA NHWC the convolution runs without its bias and bias +
+    activation are one fused pass; otherwise the stock composition"""
+    stride = conv.stride if stride is None else stride
+    if conv.bias is not None and x.is_cuda and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
+        y0 = F.conv2d(x, conv.weight, None, stride, conv.padding, conv.dilation, conv.groups)
+        if bias_leaky_ok(y0, conv.bias):
+            return _BiasLeakyReLU.apply(y0, conv.bias.float(), slope)
+        return F.leaky_relu(y0 + conv.bias.to(y0.dtype).view(1, -1, 1, 1), slope)
+    return F.leaky_relu(F.conv2d(x, conv.weight, conv.bias, stride, conv.padding, conv.dilation, conv.groups), slope)

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused_bn import bn_act
+from .fused_bn import bn_act, conv_bias_leaky
 
 
 # ------------------------------------------------------------------------------------------------
@@ -111,9 +111,12 @@ class _ConvUnit(nn.Module):
         self.cbr_unit = nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1, bias=True), nn.LeakyReLU(0.1, inplace=True))
 
     def forward(self, x, stride=1):
+        """stride 2: only every other output pixel is wanted -- the same weights as a strided convolution"""
+        conv = self.cbr_unit[0]
+        if x.is_cuda:
+            return conv_bias_leaky(x, conv, 0.1, stride)       # bias + LeakyReLU fused (csrc/batchnorm.hip)
         if stride == 1:
             return self.cbr_unit(x)
-        conv = self.cbr_unit[0]            # only every `stride`-th output pixel is wanted: the same weights as a strided convolution
         return F.leaky_relu(F.conv2d(x, conv.weight, conv.bias, stride, 1), 0.1)
 
 

@@ -197,3 +197,27 @@ def test_bn_act_on_concurrent_streams_is_deterministic():
         torch.cuda.synchronize()
         for (y, g), (y0, g0) in zip(outs, serial):
             assert torch.equal(y, y0) and torch.equal(g, g0), rep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,stride", [((4, 64, 16, 16), 1), ((2, 128, 9, 7), 1), ((3, 32, 8, 8), 2), ((32, 256, 16, 16), 1)])
+def test_conv_bias_leaky_matches_the_stock_composition(shape, stride):
+    """decoder conv unit: bias-free library convolution + fused bias/LeakyReLU (forward in place, one-pass backward with the
+    bias gradient) against conv(bias) -> LeakyReLU evaluated in float64"""
+    from scp_amd.fused_bn import conv_bias_leaky
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    conv = torch.nn.Conv2d(c, 64, 3, 1, 1).cuda().to(memory_format=torch.channels_last)
+    x = torch.randn(shape, generator=g).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = conv_bias_leaky(x, conv, 0.1, stride)
+    assert "BiasLeakyReLU" in type(y.grad_fn).__name__
+    dy = torch.randn(y.shape, generator=g).cuda()
+    gx, gw, gb = torch.autograd.grad(y, (x, conv.weight, conv.bias), dy)
+    x64 = x.detach().double().requires_grad_(True)
+    c64 = torch.nn.Conv2d(c, 64, 3, 1, 1).cuda().double()
+    c64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x64, c64.weight, c64.bias, stride, 1), 0.1)
+    rx, rw, rb = torch.autograd.grad(ref, (x64, c64.weight, c64.bias), dy.double())
+    for name, a, b in (("y", y, ref), ("dx", gx, rx), ("dw", gw, rw), ("db", gb, rb)):
+        err = (a.double() - b).abs().max().item()
+        assert err <= 2e-5 * max(b.abs().max().item(), 1.0), (name, err)
