@@ -141,6 +141,13 @@ int scp_fvm_backward(const float* img_feat, const float* mesh_feat, const float*
 enum { SCP_GEMM_BIAS = 0, SCP_GEMM_BIAS_RESIDUAL = 1, SCP_GEMM_LN = 2, SCP_GEMM_LN_GELU = 3 };
 int scp_vit_linear(const float* A, const float* W, const float* vec0, const float* vec1, const float* rowstat,
                    const float* resid, float* C, int M, int N, int K, int epilogue, void* stream);
+/* the same for a SELECTION of rows made on the device: rows_dev[0] (clamped to [0, max_rows]) rows are computed; GEMM row m
+ * reads A row a_rows[m] and uses rowstat / resid / C row c_rows[m] (int32 index lists of >= max_rows entries; NULL = identity).
+ * The rows are the foreground tokens of the last ViT block (scp_amd/dino.py); the host never waits for their number and nothing
+ * is gathered or scattered by a copy. */
+int scp_vit_linear_rows(const float* A, const float* W, const float* vec0, const float* vec1, const float* rowstat,
+                        const float* resid, float* C, const int* rows_dev, int max_rows, const int* a_rows, const int* c_rows,
+                        int N, int K, int epilogue, void* stream);
 /* stats[rows,2] = (mean, 1/sqrt(biased var + eps)) of every row of x[rows,C] (nn.LayerNorm's statistics), C <= 1536 */
 int scp_row_mean_rstd(const float* x, float* stats, int rows, int C, float eps, void* stream);
 

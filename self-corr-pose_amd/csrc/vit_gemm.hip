@@ -59,11 +59,14 @@ struct GemmArgs {
     float* C;              // [M, N]
     int M, N, K;
     int nblk_n, full_panels, rem_blocks, per_xcd;
+    const int* m_dev;      // optional: the row count lives on the device (<= M); the tile bookkeeping is then redone in the kernel
+    const int* a_rows;     // optional: GEMM row m reads A row a_rows[m] ...
+    const int* c_rows;     // ... and its rowstat / resid / C row is c_rows[m] (row gather / scatter without a copy)
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
-template <int EPI>
+template <int EPI, bool INDEXED>
 __global__ __launch_bounds__(THREADS, 3) void vit_gemm_kernel(const GemmArgs g) {
     // one LDS object per (operand, stage): the compiler's wait-count insertion tracks LDS-DMA writes per object, so a
     // ds_read of stage 0 does not have to wait for the DMA that is filling stage 1 (with a_lds[2][..] it inserted
@@ -87,7 +90,16 @@ __global__ __launch_bounds__(THREADS, 3) void vit_gemm_kernel(const GemmArgs g) 
     // workgroups (3 per CU) and every workgroup walks tiles t = blockIdx.x, + gridDim.x, ...; the LDS-DMA prologue of its
     // next tile is issued before the epilogue of the current one, so stores, GELU and LayerNorm arithmetic of tile i overlap
     // the first loads of tile i+1 instead of leaving the matrix pipe idle at both ends of every tile (K = 384: 24 chunks).
-    const int full_slots = g.per_xcd * 8, total = full_slots + g.rem_blocks;
+    // row count: host value, or read from the device (rows selected by an earlier kernel, no host round trip)
+    int M = g.M, full_panels = g.full_panels, rem_blocks = g.rem_blocks, per_xcd = g.per_xcd;
+    if (g.m_dev) {
+        M = min(max(__builtin_amdgcn_readfirstlane(*g.m_dev), 0), g.M);
+        const int tail_rows = M % BM;
+        full_panels = M / BM + (tail_rows > 32 ? 1 : 0);
+        rem_blocks = (tail_rows > 0 && tail_rows <= 32) ? g.nblk_n : 0;
+        per_xcd = (full_panels * g.nblk_n + 7) / 8;
+    }
+    const int full_slots = per_xcd * 8, total = full_slots + rem_blocks;
     struct Tile { int m0, n0; bool rem, ok; };
     auto tile_of = [&](int t) {
         Tile x;
@@ -95,11 +107,11 @@ __global__ __launch_bounds__(THREADS, 3) void vit_gemm_kernel(const GemmArgs g) 
         int bm, bn;
         if (x.rem) {
             bn = t - full_slots;
-            bm = g.full_panels;
+            bm = full_panels;
             x.ok = true;
         } else {
-            const int lid = (t & 7) * g.per_xcd + (t >> 3);
-            x.ok = lid < g.full_panels * g.nblk_n;
+            const int lid = (t & 7) * per_xcd + (t >> 3);
+            x.ok = lid < full_panels * g.nblk_n;
             bm = lid / g.nblk_n;
             bn = lid - bm * g.nblk_n;
         }
@@ -116,7 +128,9 @@ __global__ __launch_bounds__(THREADS, 3) void vit_gemm_kernel(const GemmArgs g) 
         for (int i = 0; i < 2; i++) {
             const int r = 16 * (2 * wave + i) + prow;                      // tile row 0..127
             const int chunk = pslot ^ ((r >> 2) & 3);
-            a_off[i] = (unsigned)min(x.m0 + r, g.M - 1) * (unsigned)g.K + 4u * chunk;
+            int arow = min(x.m0 + r, M - 1);
+            if (INDEXED && g.a_rows) arow = g.a_rows[arow];
+            a_off[i] = (unsigned)arow * (unsigned)g.K + 4u * chunk;
             w_off[i] = (unsigned)min(x.n0 + r, g.N - 1) * (unsigned)g.K + 4u * chunk;
         }
     };
@@ -246,11 +260,17 @@ __global__ __launch_bounds__(THREADS, 3) void vit_gemm_kernel(const GemmArgs g) 
         for (int i = 0; i < 2; i++) {
             if (!tile_live[i]) continue;
             const int mb = m0 + row_base + 32 * i;
+            // output-side row (rowstat / resid / C) of accumulator row r; looked up at each use (an L1 hit) rather than held
+            // in 16 registers through the epilogue
+            auto orow = [&](int r) {
+                const int m = min(mb + acc_row(r, half), M - 1);
+                return (INDEXED && g.c_rows) ? g.c_rows[m] : m;
+            };
             float mean[16], rstd[16];
             if (EPI == SCP_GEMM_LN || EPI == SCP_GEMM_LN_GELU) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const int m = min(mb + acc_row(r, half), g.M - 1);
+                    const int m = orow(r);
                     const float2 st = *reinterpret_cast<const float2*>(g.rowstat + 2 * (size_t)m);
                     mean[r] = st.x;
                     rstd[r] = st.y;
@@ -269,8 +289,7 @@ __global__ __launch_bounds__(THREADS, 3) void vit_gemm_kernel(const GemmArgs g) 
                 if (EPI == SCP_GEMM_BIAS_RESIDUAL) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        const int m = min(mb + acc_row(r, half), g.M - 1);
-                        res[r] = g.resid[(size_t)m * g.N + nc];
+                        res[r] = g.resid[(size_t)orow(r) * g.N + nc];
                     }
                 }
 #pragma unroll
@@ -287,7 +306,7 @@ __global__ __launch_bounds__(THREADS, 3) void vit_gemm_kernel(const GemmArgs g) 
 #if defined(SCP_GEMM_ABLATE) && (SCP_GEMM_ABLATE & 1)
                     if (x == 12345.678f)                       // timing ablation only (tools/probes): no output traffic
 #endif
-                    if (m < g.M && n_ok) g.C[(size_t)m * g.N + n] = x;
+                    if (m < M && n_ok) g.C[(size_t)orow(r) * g.N + n] = x;
                 }
             }
         }
@@ -401,13 +420,17 @@ int resident_slots() {
 template <int EPI>
 void launch(const GemmArgs& g, hipStream_t st) {
     const int total = g.per_xcd * 8 + g.rem_blocks;
-    hipLaunchKernelGGL(vit_gemm_kernel<EPI>, dim3(min(total, resident_slots())), dim3(THREADS), 0, st, g);
+    const dim3 grid(min(total, resident_slots()));
+    // the row-index variant is a separate instantiation: the plain one keeps its register allocation
+    if (g.a_rows || g.c_rows) hipLaunchKernelGGL((vit_gemm_kernel<EPI, true>), grid, dim3(THREADS), 0, st, g);
+    else hipLaunchKernelGGL((vit_gemm_kernel<EPI, false>), grid, dim3(THREADS), 0, st, g);
 }
 
 }  // namespace
 
-extern "C" int scp_vit_linear(const float* A, const float* W, const float* vec0, const float* vec1, const float* rowstat,
-                              const float* resid, float* C, int M, int N, int K, int epilogue, void* stream) {
+namespace {
+int vit_linear_impl(const float* A, const float* W, const float* vec0, const float* vec1, const float* rowstat, const float* resid,
+                    float* C, int M, const int* m_dev, const int* a_rows, const int* c_rows, int N, int K, int epilogue, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return scp::fail(hipErrorInvalidValue, "vit_linear: empty problem");
     if (K % (2 * BK) != 0) return scp::fail(hipErrorInvalidValue, "vit_linear: K must be a multiple of 32");
     if ((size_t)M * (size_t)K >= (1ull << 32) || (size_t)N * (size_t)K >= (1ull << 32))
@@ -417,7 +440,7 @@ extern "C" int scp_vit_linear(const float* A, const float* W, const float* vec0,
         return scp::fail(hipErrorInvalidValue, "vit_linear: missing epilogue operand");
     GemmArgs g{};
     g.A = A; g.W = W; g.vec0 = vec0; g.vec1 = vec1; g.rowstat = rowstat; g.resid = resid; g.C = C;
-    g.M = M; g.N = N; g.K = K;
+    g.M = M; g.N = N; g.K = K; g.m_dev = m_dev; g.a_rows = a_rows; g.c_rows = c_rows;
     g.nblk_n = (N + BN - 1) / BN;
     // a last panel of <= 32 rows (M = B * 1025 tokens at B = 32 k) runs in strip mode; a longer one is an ordinary panel with
     // clamped loads and masked stores
@@ -434,6 +457,19 @@ extern "C" int scp_vit_linear(const float* A, const float* W, const float* vec0,
         default: return scp::fail(hipErrorInvalidValue, "vit_linear: unknown epilogue");
     }
     return scp::check_launch("vit_linear");
+}
+}  // namespace
+
+extern "C" int scp_vit_linear(const float* A, const float* W, const float* vec0, const float* vec1, const float* rowstat,
+                              const float* resid, float* C, int M, int N, int K, int epilogue, void* stream) {
+    return vit_linear_impl(A, W, vec0, vec1, rowstat, resid, C, M, nullptr, nullptr, nullptr, N, K, epilogue, stream);
+}
+
+extern "C" int scp_vit_linear_rows(const float* A, const float* W, const float* vec0, const float* vec1, const float* rowstat,
+                                   const float* resid, float* C, const int* rows_dev, int max_rows, const int* a_rows,
+                                   const int* c_rows, int N, int K, int epilogue, void* stream) {
+    if (!rows_dev) return scp::fail(hipErrorInvalidValue, "vit_linear_rows: null row count");
+    return vit_linear_impl(A, W, vec0, vec1, rowstat, resid, C, max_rows, rows_dev, a_rows, c_rows, N, K, epilogue, stream);
 }
 
 extern "C" int scp_row_mean_rstd(const float* x, float* stats, int rows, int C, float eps, void* stream) {

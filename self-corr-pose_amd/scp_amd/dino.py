@@ -20,6 +20,7 @@ The module tree and parameter names equal the DINO checkpoint's, so
 `pretrain/dino_deitsmall8_pretrain.pth` loads with strict=True and MeshNet's state_dict keys are
 `pretrain_corr_net.net.model.*` as in the reference.
 """
+import ctypes
 import math
 import os
 
@@ -132,9 +133,13 @@ def add_layernorm(x, branch, norm):
 GEMM_BIAS, GEMM_BIAS_RESIDUAL, GEMM_LN, GEMM_LN_GELU = 0, 1, 2, 3      # include/scp_hip.h SCP_GEMM_*
 
 
-def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilogue=GEMM_BIAS):
+def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilogue=GEMM_BIAS, rows=None, a_rows=None, c_rows=None,
+               max_rows=None):
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T) on the fp32 matrix cores (csrc/vit_gemm.hip, include/scp_hip.h
-    scp_vit_linear); `resid` may be `out` itself (in-place residual stream).  Forward only, GPU tensors only."""
+    scp_vit_linear); `resid` may be `out` itself (in-place residual stream).  Forward only, GPU tensors only.
+    Row selection made on the device (scp_vit_linear_rows): `rows` = int32 device scalar, only the first rows[0] GEMM rows
+    are computed and the host never reads the count; GEMM row m reads a[a_rows[m]] and uses rowstat / resid / out row
+    c_rows[m] (int32 index lists, None = identity); untouched rows of `out` keep their contents."""
     from . import capi
     if torch.is_grad_enabled() and (a.requires_grad or w.requires_grad):
         raise RuntimeError("scp_amd.dino.vit_linear is forward-only (frozen ViT)")
@@ -142,10 +147,22 @@ def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilog
     n = w.shape[0]
     if out is None:
         out = torch.empty(m, n, dtype=torch.float32, device=a.device)
-    code = capi.lib().scp_vit_linear(capi.dev_ptr(a, "a"), capi.dev_ptr(w, "w"), capi.dev_ptr(vec0, "vec0"),
+    L = capi.lib()
+    if rows is None:
+        code = L.scp_vit_linear(capi.dev_ptr(a, "a"), capi.dev_ptr(w, "w"), capi.dev_ptr(vec0, "vec0"),
+                                capi.opt_ptr(vec1, "vec1"), capi.opt_ptr(rowstat, "rowstat"),
+                                capi.opt_ptr(resid, "resid"), capi.dev_ptr(out, "out"), m, n, k, epilogue,
+                                capi.current_stream())
+    else:
+        for t, name in ((rows, "rows"), (a_rows, "a_rows"), (c_rows, "c_rows")):
+            if t is not None and not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+                raise RuntimeError("vit_linear: %s must be a contiguous int32 device tensor" % name)
+        max_rows = min(m, out.shape[0]) if max_rows is None else max_rows
+        ip = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+        code = L.scp_vit_linear_rows(capi.dev_ptr(a, "a"), capi.dev_ptr(w, "w"), capi.dev_ptr(vec0, "vec0"),
                                      capi.opt_ptr(vec1, "vec1"), capi.opt_ptr(rowstat, "rowstat"),
-                                     capi.opt_ptr(resid, "resid"), capi.dev_ptr(out, "out"), m, n, k, epilogue,
-                                     capi.current_stream())
+                                     capi.opt_ptr(resid, "resid"), capi.dev_ptr(out, "out"), ip(rows), max_rows, ip(a_rows),
+                                     ip(c_rows), n, k, epilogue, capi.current_stream())
     capi.check(code, "scp_vit_linear")
     return out
 
@@ -210,6 +227,37 @@ class _Block(nn.Module):
         vit_linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL)
         return x2d
 
+    def tail_keys_fused(self, x2d, b, n, keep, key_block):
+        """The last block before the key layer, and the keys themselves, for the tokens in `keep` only (bool [b, n]):
+        after this block's attention nothing mixes tokens any more, so proj / MLP of this block and LN1 + K of `key_block`
+        are needed only for the tokens whose keys are consumed (pretrained_corr.py:85-89 masks every other token out of the
+        matching).  QKV and attention still run on all tokens (keys / values of every token feed the kept queries).  Kept
+        rows are compacted to the front (stable order), the GEMMs take their row count from the device, and the keys of all
+        other tokens are returned as zeros.  Same values for the kept tokens as the full path (row-wise identical GEMMs)."""
+        (wq, sq, tq), (w1, s1, t1) = self._folded()
+        a = self.attn
+        c = x2d.shape[1]
+        qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN)
+        y = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, c // a.num_heads, a.scale).view(b * n, c)
+        flat = keep.reshape(-1)
+        idx = torch.argsort(flat.to(torch.uint8), descending=True, stable=True).to(torch.int32)   # kept rows first, original order
+        rows = flat.sum(dtype=torch.int32).reshape(1)
+        m = b * n
+        sel = dict(rows=rows, max_rows=m)
+        # x[idx] += proj(y[idx]);  h = gelu(fc1(LN2 x[idx]));  x[idx] += fc2(h);  k[idx] = Wk LN1(x[idx]) -- rows addressed
+        # through the index list inside the GEMM (no gather / scatter copies); statistics are taken for all rows (11 us)
+        vit_linear(y, a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, a_rows=idx, c_rows=idx, **sel)
+        h = torch.empty(m, w1.shape[0], dtype=torch.float32, device=x2d.device)           # only the kept rows are written / read
+        vit_linear(x2d, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), out=h, epilogue=GEMM_LN_GELU, a_rows=idx, c_rows=idx, **sel)
+        vit_linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, a_rows=idx, c_rows=idx,
+                   **sel)
+        (kq, ks, kt), _ = key_block._folded()
+        k = torch.zeros(m, c, dtype=torch.float32, device=x2d.device)
+        vit_linear(x2d, kq[c:2 * c], ks[c:2 * c], kt[c:2 * c], row_mean_rstd(x2d, key_block.norm1.eps), out=k, epilogue=GEMM_LN,
+                   a_rows=idx, c_rows=idx, **sel)
+        heads = key_block.attn.num_heads
+        return k.view(b, n, heads, c // heads).permute(0, 2, 1, 3)
+
     def keys_fused(self, x2d, b, n):
         """K third of qkv(LN1(x)): [b, heads, n, d]  (the only part of block 9 the DINO features need)"""
         (wq, sq, tq), _ = self._folded()
@@ -268,12 +316,18 @@ class VisionTransformer(nn.Module):
         tok = torch.cat((self.cls_token.expand(b, -1, -1), tok), 1)
         return tok + self.interpolate_pos_encoding(tok.shape[1] - 1, w, h)
 
-    def key_features(self, x, layer=9):
-        """keys of block `layer`: [b, heads, tokens, d]"""
+    def key_features(self, x, layer=9, keep=None):
+        """keys of block `layer`: [b, heads, tokens, d].  `keep` (bool [b, tokens - 1], patch tokens): only these tokens' keys
+        are needed -- the others come back as zeros (fused GPU path; ignored elsewhere, where all keys are computed)"""
         if x.is_cuda and not MIXED_BF16:
             tok = self.prepare_tokens(x).contiguous()
             b, n, c = tok.shape
             x2d = tok.view(b * n, c)
+            if keep is not None and layer >= 1:
+                for blk in self.blocks[:layer - 1]:
+                    blk.forward_fused(x2d, b, n)
+                keep_tok = torch.cat((torch.zeros(b, 1, dtype=torch.bool, device=x.device), keep.reshape(b, n - 1).bool()), 1)
+                return self.blocks[layer - 1].tail_keys_fused(x2d, b, n, keep_tok, self.blocks[layer])
             for blk in self.blocks[:layer]:
                 blk.forward_fused(x2d, b, n)
             return self.blocks[layer].keys_fused(x2d, b, n)
@@ -313,8 +367,10 @@ class DINO(nn.Module):
         return super().train(False)  # frozen feature extractor, always eval (pretrained_corr.py:21)
 
     @torch.no_grad()
-    def forward(self, img):
-        k = self.model.key_features(img, self.feat_layer)[:, :, 1:, :]     # drop cls: b,h,t,d
+    def forward(self, img, keep=None):
+        """`keep` (bool [b, side*side] or [b, side, side]): the patch tokens whose features will be read; the others may come
+        back as zeros (VisionTransformer.key_features)"""
+        k = self.model.key_features(img, self.feat_layer, keep)[:, :, 1:, :]     # drop cls: b,h,t,d
         b, nh, t, d = k.shape
         side = int(math.sqrt(t))
         return k.permute(0, 1, 3, 2).reshape(b, nh * d, side, side)

@@ -51,7 +51,7 @@ class MeshNet(nn.Module):
         faces = self.mesh.faces[None].expand(bsz, -1, -1)
 
         if opts.train and getattr(self, "overlap_dino", True):
-            self.pretrain_corr_net.prefetch_features(img)
+            self.pretrain_corr_net.prefetch_features(img, mask)
         img_feat, mesh_feat, pred_v, rotation, translation, scale = self.encoder(img, mean_v, pp_crop, foc_crop)
         # The rotation-cycle branch (a second, independent encoder pass over the rotated images) only
         # needs img / mask / img_feat: it runs on a side HIP stream next to the correspondence + render +

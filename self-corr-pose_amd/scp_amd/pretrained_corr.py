@@ -83,7 +83,13 @@ class PretrainedCorrespondence(nn.Module):
         indices_match = torch.gather(bw, -1, indices)
         return match, grid_k, indices_match, indices, match_mask
 
-    def prefetch_features(self, img):
+    def _keep_tokens(self, mask):
+        """the patch tokens inside the object mask at the DINO resolution: match_features masks every other token out of the
+        mutual-nearest-neighbour search (pretrained_corr.py:85-89), so their features are never read"""
+        fs = self.feat_size
+        return F.interpolate(mask[:, None].float(), (fs, fs), mode="nearest").reshape(mask.shape[0], -1) > 0
+
+    def prefetch_features(self, img, mask=None):
         """Start the frozen DINO ViT on a side HIP stream (it depends on nothing but the input images);
         the encoder / correspondence / render work of the main stream overlaps with it and
         compute_cycle_loss joins the stream right before it needs the features."""
@@ -96,17 +102,19 @@ class PretrainedCorrespondence(nn.Module):
             self._side_stream = torch.cuda.Stream(device=img.device)
         self._side_stream.wait_stream(torch.cuda.current_stream(img.device))
         with torch.cuda.stream(self._side_stream):
-            feats = self.net(img)
+            feats = self.net(img, None if mask is None else self._keep_tokens(mask))
         img.record_stream(self._side_stream)
+        if mask is not None:
+            mask.record_stream(self._side_stream)
         self._prefetched = (img, feats)
 
-    def _features(self, img):
+    def _features(self, img, mask=None):
         pre = getattr(self, "_prefetched", None)
         self._prefetched = None
         if pre is not None and pre[0] is img:
             torch.cuda.current_stream(img.device).wait_stream(self._side_stream)
             return pre[1]
-        return self.net(img)
+        return self.net(img, None if mask is None else self._keep_tokens(mask))
 
     def compute_cycle_loss(self, img, mask, depth_weight, pointcorr):
         num_verts = pointcorr.shape[-1]
@@ -115,7 +123,7 @@ class PretrainedCorrespondence(nn.Module):
         hh, wh = self.hf // 2, self.wf // 2
         grid = self.half_grid(n)
 
-        feats = self._features(img)                                              # once per unique image
+        feats = self._features(img, mask)                                        # once per unique image
         pts_src, pts_tgt, indices_src, indices_tgt, mask_k = self.match_features(
             feats[src_idx], feats[tgt_idx], mask[src_idx], mask[tgt_idx], grid)
 

@@ -164,7 +164,7 @@ class Trainer:
         try:
             total_loss, aux_output = self.model(data)
             if next_data is not None:
-                self.model.pretrain_corr_net.prefetch_features(next_data[0])
+                self.model.pretrain_corr_net.prefetch_features(next_data[0], next_data[1])
             total_loss.mean().backward()
         finally:
             if serial:

@@ -194,3 +194,54 @@ def test_fused_block_matches_oracle(B, N):
         err, scale = (g_ - r_).abs().max().item(), r_.abs().max().item()
         print("%s: max abs err %.3e of scale %.3e" % (name, err, scale))
         assert err <= 2e-5 * scale
+
+
+@pytest.mark.gpu
+def test_vit_linear_with_device_row_count():
+    """scp_vit_linear_rows: only the first rows[0] rows are computed (bitwise equal to the full launch), the rest is untouched"""
+    from scp_amd import dino
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(700, 384, generator=g).cuda()
+    w = (torch.randn(384, 384, generator=g) * 0.05).cuda()
+    b = torch.randn(384, generator=g).cuda()
+    res = torch.randn(700, 384, generator=g).cuda()
+    full = dino.vit_linear(a, w, b, resid=res, epilogue=dino.GEMM_BIAS_RESIDUAL)
+    for count in (0, 1, 31, 32, 33, 128, 160, 161, 399, 700, 900):
+        out = torch.full((700, 384), -7.0, device="cuda")
+        dino.vit_linear(a, w, b, resid=res, out=out, epilogue=dino.GEMM_BIAS_RESIDUAL,
+                        rows=torch.tensor([count], dtype=torch.int32, device="cuda"))
+        k = min(count, 700)
+        assert torch.equal(out[:k], full[:k]), count
+        assert bool((out[k:] == -7.0).all()), count
+    # row selection through index lists: GEMM row m = A row idx[m], residual / output row idx[m] (in place on the selection)
+    keep = torch.rand(700, generator=g) < 0.37
+    idx = torch.argsort(keep.to(torch.uint8), descending=True, stable=True).to(torch.int32).cuda()
+    rows = keep.sum(dtype=torch.int32).reshape(1).cuda()
+    out = res.clone()
+    dino.vit_linear(a, w, b, resid=out, out=out, epilogue=dino.GEMM_BIAS_RESIDUAL, rows=rows, a_rows=idx, c_rows=idx, max_rows=700)
+    keep = keep.cuda()
+    assert torch.equal(out[keep], full[keep])
+    assert torch.equal(out[~keep], res[~keep])
+
+
+@pytest.mark.gpu
+def test_dino_features_of_kept_tokens_equal_the_full_pass():
+    """DINO.forward(img, keep): proj / MLP of the last block and the key projection run on the kept tokens only; their
+    features are bitwise those of the full pass, all others are zero"""
+    from scp_amd import dino
+    old, dino.ALLOW_RANDOM_INIT = dino.ALLOW_RANDOM_INIT, True
+    try:
+        net = dino.DINO("/nonexistent.pth").cuda()
+    finally:
+        dino.ALLOW_RANDOM_INIT = old
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(3, 3, 128, 128, generator=g).cuda()
+    keep = (torch.rand(3, 16 * 16, generator=g) < 0.4).cuda()
+    keep[1] = False                      # an image with nothing to keep
+    keep[2, :] = True                    # and one with everything
+    full = net(img)
+    part = net(img, keep)
+    b, c, s, _ = full.shape
+    km = keep.view(b, 1, s, s).expand(-1, c, -1, -1)
+    assert torch.equal(part[km], full[km])
+    assert bool((part[~km] == 0).all())
