@@ -194,6 +194,11 @@ int scp_dual_softmax_backward(const float* scores, const float* rowmask, const f
  * head_dim must be 64.  No score tensor is materialised. */
 int scp_vit_attention_forward(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale,
                               void* stream);
+/* the same for a selection of QUERIES per image: query slot j of image b is token q_rows[b*N + j] (int32), only the first
+ * q_count[b] slots exist; keys and values are all N tokens.  Outputs are written to the selected tokens' own rows, other rows
+ * of `out` are not touched.  (Last ViT block before the key layer: only the tokens inside the object mask are consumed.) */
+int scp_vit_attention_forward_rows(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale,
+                                   const int* q_rows, const int* q_count, void* stream);
 
 /* ---- brute-force 1-nearest-neighbour (symmetry loss) -----------------------------------------------
  * Replaces pytorch3d.ops.knn_points(x, y, K=1).idx as used by model/util/chamfer.py:135 for

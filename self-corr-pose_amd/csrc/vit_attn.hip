@@ -55,7 +55,8 @@ __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const float* __restrict__ qkv,
                                                                    float* __restrict__ out, int N, int H,
-                                                                   float scale_log2e) {
+                                                                   float scale_log2e, const int* __restrict__ q_rows,
+                                                                   const int* __restrict__ q_count) {
     __shared__ __attribute__((aligned(16))) float k_lds[2][KT * HD];
     __shared__ __attribute__((aligned(16))) float v_lds[2][KT * HD];
 
@@ -74,6 +75,11 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
     }
     const int b = bh / H, h = bh - b * H;
     const int q0 = (qg * WAVES + wave) * 32;
+    // optional query selection (scp_vit_attention_forward_rows): query slot j of image b is token q_rows[b*N + j], only the
+    // first q_count[b] slots exist.  Keys / values are always all N tokens.  A workgroup whose slots are all past the count
+    // leaves before it touches anything; its outputs are simply not produced.
+    const int n_query = q_count ? min(q_count[b], N) : N;
+    if (qg * WAVES * 32 >= n_query) return;          // workgroup-uniform
     const size_t row_stride = (size_t)3 * H * HD;                 // floats between consecutive tokens
     const float* base = qkv + (size_t)b * N * row_stride + (size_t)h * HD;
 
@@ -121,7 +127,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
     // Q fragment: qreg[s] = Q[q][s + 32*half] * scale*log2(e)
     float qreg[32];
     {
-        const int q = min(q0 + l31, N - 1);
+        int q = min(q0 + l31, n_query - 1);
+        if (q_rows) q = q_rows[(size_t)b * N + q];
         const float4* qp = reinterpret_cast<const float4*>(base + (size_t)q * row_stride + 32 * half);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -239,8 +246,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
     // ---- normalise and store: lane holds O[q = l31][d = acc_row(r, half) (+32)]
     const float l_tot = l_run + other_half(l_run);
     const float inv = 1.f / l_tot;
-    const int q = q0 + l31;
-    if (q < N) {
+    const int qslot = q0 + l31;
+    if (qslot < n_query) {
+        const int q = q_rows ? q_rows[(size_t)b * N + qslot] : qslot;
         float* op = out + ((size_t)b * N + q) * (H * HD) + (size_t)h * HD;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -253,8 +261,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void vit_attention_kernel(const floa
 
 }  // namespace
 
-extern "C" int scp_vit_attention_forward(const float* qkv, float* out, int B, int N, int H, int head_dim,
-                                         float scale, void* stream) {
+namespace {
+int attention_impl(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale, const int* q_rows, const int* q_count,
+                   void* stream) {
     if (B <= 0 || N <= 0 || H <= 0) return scp::fail(hipErrorInvalidValue, "vit_attention: empty problem");
     if (head_dim != HD) return scp::fail(hipErrorInvalidValue, "vit_attention: head_dim must be 64");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -262,9 +271,21 @@ extern "C" int scp_vit_attention_forward(const float* qkv, float* out, int B, in
     const int qtiles = (N + 31) / 32;
     // 3 wavefronts per workgroup when that leaves no idle wavefront (1025 tokens = 33 tiles = 11 x 3)
     if (qtiles % 3 == 0 && qtiles % 4 != 0) {
-        hipLaunchKernelGGL(vit_attention_kernel<3>, dim3(qtiles / 3, B * H), dim3(192), 0, st, qkv, out, N, H, sl);
+        hipLaunchKernelGGL(vit_attention_kernel<3>, dim3(qtiles / 3, B * H), dim3(192), 0, st, qkv, out, N, H, sl, q_rows, q_count);
     } else {
-        hipLaunchKernelGGL(vit_attention_kernel<4>, dim3((qtiles + 3) / 4, B * H), dim3(256), 0, st, qkv, out, N, H, sl);
+        hipLaunchKernelGGL(vit_attention_kernel<4>, dim3((qtiles + 3) / 4, B * H), dim3(256), 0, st, qkv, out, N, H, sl, q_rows, q_count);
     }
     return scp::check_launch("vit_attention");
+}
+}  // namespace
+
+extern "C" int scp_vit_attention_forward(const float* qkv, float* out, int B, int N, int H, int head_dim,
+                                         float scale, void* stream) {
+    return attention_impl(qkv, out, B, N, H, head_dim, scale, nullptr, nullptr, stream);
+}
+
+extern "C" int scp_vit_attention_forward_rows(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale,
+                                              const int* q_rows, const int* q_count, void* stream) {
+    if (!q_rows || !q_count) return scp::fail(hipErrorInvalidValue, "vit_attention_rows: null selection");
+    return attention_impl(qkv, out, B, N, H, head_dim, scale, q_rows, q_count, stream);
 }

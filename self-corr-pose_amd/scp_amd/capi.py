@@ -90,6 +90,7 @@ SYMBOLS = {
     "scp_vit_attention_bf16_forward": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "scp_add_layernorm_forward": (ctypes.c_int, [_P, _P, _P, _P, _F, ctypes.c_long, _I, _P, _P, _P]),
     "scp_vit_attention_forward": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _F, _P]),
+    "scp_vit_attention_forward_rows": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "scp_dual_softmax_backward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _F,
                                                 _I, _I, _I, _P]),
 }

@@ -82,17 +82,28 @@ class _Attention(nn.Module):
         return k.reshape(b, n, self.num_heads, c // self.num_heads).permute(0, 2, 1, 3)
 
 
-def fused_attention(qkv, b, n, heads, head_dim, scale):
+def fused_attention(qkv, b, n, heads, head_dim, scale, q_rows=None, q_count=None):
     """HIP flash-style attention on the fp32 matrix cores (csrc/vit_attn.hip): qkv [b,n,3*heads*head_dim]
     as produced by the qkv Linear -> [b, n, heads*head_dim].  Forward only (the DINO ViT is frozen and
-    always evaluated under no_grad); GPU tensors only, no CPU fallback."""
+    always evaluated under no_grad); GPU tensors only, no CPU fallback.
+    Query selection (scp_vit_attention_forward_rows): q_rows [b,n] int32 = token index of query slot j per image, q_count [b]
+    int32 = number of slots; only those tokens' outputs are produced (at their own rows; the other rows stay uninitialised),
+    keys and values are always all n tokens."""
     from . import capi
     if torch.is_grad_enabled() and qkv.requires_grad:
         raise RuntimeError("scp_amd.dino.fused_attention is forward-only (frozen ViT)")
     qkv = qkv.contiguous()
     out = torch.empty(b, n, heads * head_dim, dtype=torch.float32, device=qkv.device)
-    code = capi.lib().scp_vit_attention_forward(capi.dev_ptr(qkv, "qkv"), capi.dev_ptr(out, "out"), b, n, heads,
-                                                head_dim, float(scale), capi.current_stream())
+    if q_rows is None:
+        code = capi.lib().scp_vit_attention_forward(capi.dev_ptr(qkv, "qkv"), capi.dev_ptr(out, "out"), b, n, heads,
+                                                    head_dim, float(scale), capi.current_stream())
+    else:
+        for t, name, numel in ((q_rows, "q_rows", b * n), (q_count, "q_count", b)):
+            if not (t is not None and t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and t.numel() == numel):
+                raise RuntimeError("fused_attention: %s must be a contiguous int32 device tensor of %d entries" % (name, numel))
+        code = capi.lib().scp_vit_attention_forward_rows(capi.dev_ptr(qkv, "qkv"), capi.dev_ptr(out, "out"), b, n, heads, head_dim,
+                                                         float(scale), ctypes.c_void_p(q_rows.data_ptr()),
+                                                         ctypes.c_void_p(q_count.data_ptr()), capi.current_stream())
     capi.check(code, "scp_vit_attention_forward")
     return out
 
@@ -231,14 +242,19 @@ class _Block(nn.Module):
         """The last block before the key layer, and the keys themselves, for the tokens in `keep` only (bool [b, n]):
         after this block's attention nothing mixes tokens any more, so proj / MLP of this block and LN1 + K of `key_block`
         are needed only for the tokens whose keys are consumed (pretrained_corr.py:85-89 masks every other token out of the
-        matching).  QKV and attention still run on all tokens (keys / values of every token feed the kept queries).  Kept
-        rows are compacted to the front (stable order), the GEMMs take their row count from the device, and the keys of all
-        other tokens are returned as zeros.  Same values for the kept tokens as the full path (row-wise identical GEMMs)."""
+        matching).  The QKV projection still runs on all tokens (keys / values of every token feed the kept queries); the
+        attention runs for the kept queries only.  The GEMMs take their row count and row index list from the device, and the
+        keys of all other tokens are returned as zeros.  Same values for the kept tokens as the full path (row-wise identical GEMMs)."""
         (wq, sq, tq), (w1, s1, t1) = self._folded()
         a = self.attn
         c = x2d.shape[1]
         qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN)
-        y = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, c // a.num_heads, a.scale).view(b * n, c)
+        # attention: keys / values of all tokens, queries only for the kept ones (per image, compacted to the front of the
+        # query slots; their outputs land on their own rows)
+        k8 = keep.to(torch.uint8)
+        q_rows = torch.argsort(k8, dim=1, descending=True, stable=True).to(torch.int32)
+        q_count = keep.sum(1, dtype=torch.int32)
+        y = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, c // a.num_heads, a.scale, q_rows, q_count).view(b * n, c)
         flat = keep.reshape(-1)
         idx = torch.argsort(flat.to(torch.uint8), descending=True, stable=True).to(torch.int32)   # kept rows first, original order
         rows = flat.sum(dtype=torch.int32).reshape(1)

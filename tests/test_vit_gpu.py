@@ -226,8 +226,8 @@ def test_vit_linear_with_device_row_count():
 
 @pytest.mark.gpu
 def test_dino_features_of_kept_tokens_equal_the_full_pass():
-    """DINO.forward(img, keep): proj / MLP of the last block and the key projection run on the kept tokens only; their
-    features are bitwise those of the full pass, all others are zero"""
+    """DINO.forward(img, keep): the last block's attention queries, proj / MLP and the key projection run on the kept tokens
+    only; their features equal those of the full pass, all others are zero"""
     from scp_amd import dino
     old, dino.ALLOW_RANDOM_INIT = dino.ALLOW_RANDOM_INIT, True
     try:
@@ -243,5 +243,7 @@ def test_dino_features_of_kept_tokens_equal_the_full_pass():
     part = net(img, keep)
     b, c, s, _ = full.shape
     km = keep.view(b, 1, s, s).expand(-1, c, -1, -1)
-    assert torch.equal(part[km], full[km])
+    # the GEMM rows are bitwise those of the full pass; the attention's deferred-rescale decision is taken per wavefront, so a
+    # query that shares its wavefront with different neighbours may round differently in the last bits
+    torch.testing.assert_close(part[km], full[km], rtol=1e-5, atol=2e-6 * full.abs().max().item())
     assert bool((part[~km] == 0).all())
