@@ -333,6 +333,8 @@ def main():
     gemm_flops = []
 
     def count_gemm(a, w, *rest, **kw):
+        if kw.get("rows") is not None:      # row-selected launches (last block's tail on the masked tokens): their row count
+            return False                     # lives on the device -- not timed, so that flops and time refer to the same launches
         gemm_flops.append(2.0 * a.shape[0] * a.shape[1] * w.shape[0])
         return True
     with KernelTimer(native, "backward_soft_rasterize", is_softtex) as kt, \
