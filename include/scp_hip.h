@@ -275,6 +275,15 @@ int scp_batchnorm_act_backward_bf16(const void* dy, const void* x, const void* y
 int scp_conv3x3_nhwc_forward(const float* x, const float* w, const float* bias, const float* zeros64, float* y, int N, int H,
                              int W, int Cin, int Cout, void* stream);
 
+/* ---- stem max pooling ------------------------------------------------------------------------------------------
+ * nn.MaxPool2d(3, 2, 1) of torchvision's resnet18 stem (image_encoder.py:119-139), NHWC, even H and W, C % 4 == 0:
+ *   x [N,H,W,C] -> y [N,H/2,W/2,C]; where [N,H/2,W/2,C] bytes: position 0..8 of the maximum inside its window (ATen's tie
+ *   rule: first maximum in row-major window order).  backward: dy, where -> dx [N,H,W,C] (gather, deterministic). */
+int scp_maxpool3x3s2_forward(const float* x, float* y, unsigned char* where, int N, int H, int W, int C, void* stream);
+int scp_maxpool3x3s2_forward_bf16(const void* x, void* y, unsigned char* where, int N, int H, int W, int C, void* stream);
+int scp_maxpool3x3s2_backward(const float* dy, const unsigned char* where, float* dx, int N, int H, int W, int C, void* stream);
+int scp_maxpool3x3s2_backward_bf16(const void* dy, const unsigned char* where, void* dx, int N, int H, int W, int C, void* stream);
+
 /* ---- decoder conv units: bias + LeakyReLU around a bias-free library convolution --------------------------------------
  * Replaces, in `conv(x) -> + bias -> LeakyReLU(0.1)` of image_encoder.py:141-193 (nn.Conv2d(bias=True) + nn.LeakyReLU, inplace):
  * the broadcast bias add and the activation (one in-place pass over y [R = N*H*W, C], NHWC), and in backward the activation

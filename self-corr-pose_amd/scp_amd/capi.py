@@ -71,6 +71,10 @@ SYMBOLS = {
                                                      _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "scp_batchnorm_act_backward_bf16": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _I, _P, _P, _P, _P,
                                                       _P, ctypes.c_size_t, _P, _P]),
+    "scp_maxpool3x3s2_forward": (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "scp_maxpool3x3s2_forward_bf16": (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "scp_maxpool3x3s2_backward": (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "scp_maxpool3x3s2_backward_bf16": (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "scp_bias_leaky_relu_forward": (ctypes.c_int, [_P, _P, _F, ctypes.c_long, _I, _P]),
     "scp_bias_leaky_relu_forward_bf16": (ctypes.c_int, [_P, _P, _F, ctypes.c_long, _I, _P]),
     "scp_bias_leaky_relu_backward": (ctypes.c_int, [_P, _P, _F, ctypes.c_long, _I, _P, _P, _P, ctypes.c_size_t, _P, _P]),

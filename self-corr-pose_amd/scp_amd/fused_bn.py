@@ -145,3 +145,40 @@ def conv_bias_leaky(x, conv, slope=0.1, stride=None):
             return _BiasLeakyReLU.apply(y0, conv.bias.float(), slope)
         return F.leaky_relu(y0 + conv.bias.to(y0.dtype).view(1, -1, 1, 1), slope)
     return F.leaky_relu(F.conv2d(x, conv.weight, conv.bias, stride, conv.padding, conv.dilation, conv.groups), slope)
+
+
+class _MaxPool3x3s2(Function):
+    """nn.MaxPool2d(3, 2, 1) on NHWC activations (csrc/pool.hip): byte-sized argmax map instead of int64 indices, gather
+    backward; same values and the same gradient routing (ties included) as ATen"""
+
+    @staticmethod
+    def forward(ctx, x):
+        L = capi.lib()
+        n, c, h, w = x.shape
+        y = torch.empty((n, c, h // 2, w // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        where = torch.empty(n * (h // 2) * (w // 2) * c, dtype=torch.uint8, device=x.device)
+        fn = L.scp_maxpool3x3s2_forward if x.dtype == torch.float32 else L.scp_maxpool3x3s2_forward_bf16
+        capi.check(fn(_ptr(x), _ptr(y), _ptr(where), n, h, w, c, capi.current_stream()), "maxpool3x3s2_forward")
+        ctx.save_for_backward(where)
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = capi.lib()
+        (where,) = ctx.saved_tensors
+        n, c, h, w = ctx.shape
+        dy = _nhwc(dy)
+        dx = torch.empty((n, c, h, w), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        fn = L.scp_maxpool3x3s2_backward if dy.dtype == torch.float32 else L.scp_maxpool3x3s2_backward_bf16
+        capi.check(fn(_ptr(dy), _ptr(where), _ptr(dx), n, h, w, c, capi.current_stream()), "maxpool3x3s2_backward")
+        return dx
+
+
+def maxpool3x3s2(x, stock):
+    """`stock(x)` for stock = nn.MaxPool2d(3, 2, 1): HIP kernels on CUDA NHWC fp32 / bf16 with even H, W; the module otherwise"""
+    if (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+            and x.shape[1] % 4 == 0 and x.is_contiguous(memory_format=torch.channels_last)
+            and stock.kernel_size == 3 and stock.stride == 2 and stock.padding == 1 and stock.dilation == 1 and not stock.ceil_mode):
+        return _MaxPool3x3s2.apply(x)
+    return stock(x)

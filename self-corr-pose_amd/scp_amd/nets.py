@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused_bn import bn_act, conv_bias_leaky
+from .fused_bn import bn_act, conv_bias_leaky, maxpool3x3s2
 
 
 # ------------------------------------------------------------------------------------------------
@@ -95,7 +95,7 @@ class ResNet_Encoder(nn.Module):
 
     def forward(self, x):
         r = self.resnet
-        x = r.maxpool(bn_act(r.conv1(x), r.bn1, relu=True))
+        x = maxpool3x3s2(bn_act(r.conv1(x), r.bn1, relu=True), r.maxpool)
         c2 = r.layer1(x)
         c3 = r.layer2(c2)
         c4 = r.layer3(c3)

@@ -221,3 +221,24 @@ def test_conv_bias_leaky_matches_the_stock_composition(shape, stride):
     for name, a, b in (("y", y, ref), ("dx", gx, rx), ("dw", gw, rw), ("db", gb, rb)):
         err = (a.double() - b).abs().max().item()
         assert err <= 2e-5 * max(b.abs().max().item(), 1.0), (name, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 8, 4, 6), (3, 64, 16, 16), (32, 64, 128, 128)])
+def test_maxpool3x3s2_matches_aten_bitwise_including_ties(shape):
+    """stem max pooling (csrc/pool.hip) vs F.max_pool2d on a ReLU output (a third of the values are exact zeros, so windows
+    with several equal maxima are common): same values, and the gradient goes to the same element"""
+    from scp_amd.fused_bn import maxpool3x3s2
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.relu(torch.randn(shape, generator=g)).cuda().contiguous(memory_format=torch.channels_last)
+    stock = torch.nn.MaxPool2d(3, 2, 1)
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    ya = maxpool3x3s2(xa, stock)
+    assert "MaxPool3x3s2" in type(ya.grad_fn).__name__
+    yb = stock(xb)
+    assert torch.equal(ya, yb)
+    dy = torch.randn(ya.shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    (ga,) = torch.autograd.grad(ya, xa, dy)
+    (gb,) = torch.autograd.grad(yb, xb, dy)
+    assert torch.equal(ga, gb)
