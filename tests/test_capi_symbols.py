@@ -67,3 +67,23 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, os.path.join(dirpath, f)
+
+
+def test_bench_and_entry_points_use_the_oracle_only_where_allowed():
+    """bench.py may touch oracle/ only in its baseline leg (cpu_baseline / reference_kernels_same_gpu, both after the timed
+    region) and must not import the test tree; __graft_entry__ only in smoke() and when BUILDING the checker"""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    allowed = {"cpu_baseline", "reference_kernels_same_gpu", "bench_posefit"}
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        for node in ast.walk(fn):
+            if isinstance(node, (ast.Import, ast.ImportFrom)):
+                names = [a.name for a in node.names] + ([node.module] if isinstance(node, ast.ImportFrom) and node.module else [])
+                if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                    assert fn.name in allowed, "bench.py:%s imports the oracle" % fn.name
+    for node in tree.body:                      # module level: nothing from oracle/ or tests/
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            names = [a.name for a in node.names] + ([node.module] if isinstance(node, ast.ImportFrom) and node.module else [])
+            assert not any(n.split(".")[0] in ("oracle", "tests", "scenes", "synth", "step_case") for n in names), names
+    assert 'os.path.join(ROOT, "tests")' not in src and "'tests'" not in src
