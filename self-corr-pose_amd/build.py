@@ -47,9 +47,10 @@ def build(force=False, verbose=True):
         o = os.path.join(objdir, s[:-4] + ".o")
         src = os.path.join(CSRC, s)
         objs.append(o)
+        headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]      # every .hip may include any of them
         if not force and os.path.exists(o) and os.path.getmtime(o) > max(
-                os.path.getmtime(src), os.path.getmtime(os.path.join(CSRC, "scp_common.h")),
-                os.path.getmtime(os.path.join(ROOT, "include", "scp_hip.h")), os.path.getmtime(__file__)):
+                [os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "include", "scp_hip.h")), os.path.getmtime(__file__)]
+                + [os.path.getmtime(h) for h in headers]):
             continue
         cmd = [hipcc] + COMMON + EXTRA.get(s, []) + ["-c", src, "-o", o]
         if verbose:
