@@ -27,9 +27,6 @@
 //                 done with stage kc % NSTAGE], then MFMAs on F1 interleaved with D(kc+NSTAGE) into the freed stage and the
 //                 reads R0(kc+1) -> F0; lgkmcnt(0)
 #pragma once
-#ifndef SCP_GEMM_ABL
-#define SCP_GEMM_ABL 0
-#endif
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -175,9 +172,7 @@ struct GemmCore {
             mfma<N>(acc, F0);
             static_for<0, NREAD>([&](auto r) {
                 constexpr int R = decltype(r)::value;
-#if !(SCP_GEMM_ABL & 4)
                 if constexpr (imin(1 + 2 * R, NM - 1) == N) read<S, 1, R>(F1);
-#endif
             });
         });
         asm volatile("s_waitcnt lgkmcnt(0)");
@@ -187,23 +182,14 @@ struct GemmCore {
             mfma<N>(acc, F1);
             if constexpr (MODE != GEMM_STEP_LAST) {
                 if constexpr (N == 1) {
-#if SCP_GEMM_ABL & 2
-                    if constexpr (MODE == GEMM_STEP_ISSUE) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER * (CFG::NSTAGE - 2)) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#elif SCP_GEMM_ABL & 8
-                    asm volatile("s_barrier" ::: "memory");
-#else
                     if constexpr (MODE == GEMM_STEP_ISSUE) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(PER * (CFG::NSTAGE - 2)) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
                 }
                 static_for<0, NREAD>([&](auto r) {
                     constexpr int R = decltype(r)::value;
-#if !(SCP_GEMM_ABL & 4)
                     if constexpr (imin(2 + 2 * R, NM - 1) == N) read<SN, 0, R>(F0);
-#endif
                 });
-                if constexpr (MODE == GEMM_STEP_ISSUE && !(SCP_GEMM_ABL & 1)) {
+                if constexpr (MODE == GEMM_STEP_ISSUE) {
                     static_for<0, PER>([&](auto p) {
                         constexpr int P = decltype(p)::value;
                         if constexpr (imin(3 + 4 * P, NM - 1) == N) src.template issue<P>(kc + CFG::NSTAGE, lds0 + S * CFG::STAGE_BYTES, wave);

@@ -810,10 +810,6 @@ __device__ __forceinline__ void backward_group(const RasterArgs& a, const float*
         if (slow) backward_pair<RGB, SAMPLE, false>(a, g, rec, pr, bn);
         else backward_pair<RGB, SAMPLE, true>(a, g, rec, pr, bn);
     }
-#ifdef SCP_ABLATE_NO_REDUCE   // tools/softras_ablate.py builds: price the reduction + flush
-    if (g[0] + g[5] + g[11] == 12345.f) acc[0] = 1.f;
-    return;
-#endif
     // rows are merged by the LDS atomics themselves (several rows of a group may hold the same face)
     const bool row_live = (row_first >> (lane & 48)) & 1ull;
     float* slot_acc = acc + q * NACC;

@@ -55,13 +55,13 @@ class FlatGradients:
         self._pending = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
         self._armed = False
-        self._silent, self._fired = set(), set()
+        self._prepared = False
+        self._silent, self._fired, self._poisoned = set(), set(), set()
         self.launched_in_backward = 0          # buckets whose collective was enqueued from a hook (test / log)
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" and self.active else None
-        self._hooks = []
-        if self.active:
-            for p in self.params:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        # hooks at every world size: with one rank they only record which parameters received a gradient (finish() needs that
+        # to leave the unused ones at grad = None)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def _view_like(self, p, off):
         """a view of flat[off : off + p.numel()] with p's sizes AND strides: the fused optimizer requires gradients in the
@@ -86,15 +86,20 @@ class FlatGradients:
         for t in tensors:
             dist.broadcast(t, src, group=self.group)
 
-    def average_buffers(self, module):
-        """BatchNorm statistics are per rank (each rank normalises with its own 32 images, like the reference without
-        SyncBatchNorm); before a checkpoint is written they are averaged so the saved ones do not depend on which rank saves"""
+    def averaged_running_stats(self, module):
+        """{buffer name: mean over ranks} for the BatchNorm running_mean / running_var buffers of `module` (each rank normalises
+        with its own 32 images, like the reference without SyncBatchNorm; a checkpoint should not depend on which rank
+        writes it).  COLLECTIVE: every rank must call it.  The live buffers are not touched and nothing else is reduced
+        (constant buffers and integer counters are identical on every rank by construction)."""
+        out = {}
         if self.world == 1:
-            return
-        for b in module.buffers():
-            if b.is_floating_point():
-                dist.all_reduce(b.data, op=dist.ReduceOp.SUM, group=self.group)
-                b.data.div_(self.world)
+            return out
+        for name, b in module.named_buffers():
+            if b.is_floating_point() and (name.endswith("running_mean") or name.endswith("running_var")):
+                avg = b.detach().clone()
+                dist.all_reduce(avg, op=dist.ReduceOp.SUM, group=self.group)
+                out[name] = avg.div_(self.world)
+        return out
 
     # ------------------------------------------------------------------------------------------------
     def prepare(self):
@@ -111,8 +116,10 @@ class FlatGradients:
         self._pending = [len(c) for c in self._counted]
         self._work = [None] * len(self.buckets)
         self._fired = set()
+        self._poisoned = set()
         self.launched_in_backward = 0
         self._armed = True
+        self._prepared = True
 
     def _launch(self, i):
         lo, hi, _ = self.buckets[i]
@@ -134,29 +141,60 @@ class FlatGradients:
         i = self.bucket_of[id(p)]
         first = id(p) not in self._fired
         self._fired.add(id(p))
-        if id(p) in self._silent or not first or self._work[i] is not None:
+        if not first or not self.active:
+            return
+        if id(p) in self._silent:
+            # a parameter that had no gradient in the previous step produces one now (an iteration- or flag-dependent
+            # branch): it was left out of its bucket's count-down.
+            if self._work[i] is not None:
+                # its bucket is already being reduced: the accumulation that just ran raced with the in-place all-reduce
+                # on the communication stream and the other ranks summed a stale value -- not recoverable
+                raise RuntimeError(
+                    "FlatGradients: a parameter of shape %s received its first gradient after its bucket had been "
+                    "all-reduced (it had none in the previous step); call reset_static_graph() before a step that changes "
+                    "the set of used parameters" % (tuple(p.shape),))
+            # not launched yet: only finish() may launch this bucket now (and, buckets going out in index order, every
+            # later one), after all of backward
+            self._poisoned.add(i)
+            return
+        if self._work[i] is not None:
             return
         self._pending[i] -= 1
         # buckets are launched strictly in index order (here or in finish()), so every rank issues the same
         # collective sequence whatever the timing of its hooks
         while True:
             nxt = next((j for j in range(len(self.buckets)) if self._work[j] is None), None)
-            if nxt is None or self._pending[nxt] != 0:
+            if nxt is None or self._pending[nxt] != 0 or nxt in self._poisoned:
                 break
             self._launch(nxt)
             self.launched_in_backward += 1
 
-    def finish(self):
+    def reset_static_graph(self):
+        """forget which parameters were unused in the previous step: every bucket waits for all of its parameters again
+        (call before a step whose set of used parameters differs from the last one's)"""
+        self._silent = set()
+
+    def finish(self, keep_unused_none=False):
         """after backward: adopt gradients that were assigned around the views, launch the buckets that have not fired,
-        wait for the collectives.  Returns the flat buffer holding the SUM over ranks (divide by .world)."""
+        wait for the collectives.  Returns the flat buffer holding the SUM over ranks (divide by .world).
+        keep_unused_none: parameters that received no gradient this step end with `p.grad = None` (what
+        zero_grad(set_to_none=True) leaves in the reference, so AdamW skips them: no weight decay, no moment update) instead
+        of a zero view; prepare() points them at their views again."""
         self._armed = False
+        unused = []
         for p in self.params:
             v = self.views[id(p)]
             if p.grad is None:
-                p.grad = v                               # no gradient this step: zeros (buffer was cleared)
+                if not self._prepared:
+                    v.zero_()                            # prepare() was skipped: the span still holds the previous step
+                p.grad = v                               # no gradient this step: zeros
+                unused.append(p)
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
                 p.grad = v
+            elif id(p) not in self._fired:
+                unused.append(p)                         # still the zero view prepare() installed
+        self._prepared = False
         if self.active:
             for i in range(len(self.buckets)):
                 if self._work[i] is None:
@@ -166,6 +204,9 @@ class FlatGradients:
                 w.wait()                                  # NCCL: the current stream waits; gloo: blocks
             if self.comm_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if keep_unused_none:
+            for p in unused:
+                p.grad = None
         return self.flat
 
 

@@ -39,6 +39,7 @@ class PretrainedCorrespondence(nn.Module):
         self.topk_override = None   # indices [N,k]
         self.nn_override = None     # (bw [N,P], fw [N,P]) mutual-NN argmax indices
         self.last_nn = None
+        self.last_topk = None       # the top-k selection of the last match_features call (parity runs inject it on the other side)
 
     def half_grid(self, bsz):
         """the pixel grid at half the correspondence resolution (pretrained_corr.py:112-114 interpolates the constant
@@ -77,6 +78,7 @@ class PretrainedCorrespondence(nn.Module):
         else:
             indices = torch.topk(-distance, k=self.k, dim=1).indices
         self.last_distance = distance.detach()
+        self.last_topk = indices
         match = torch.gather(match, -1, indices[:, None].expand(-1, 2, -1))
         grid_k = torch.gather(grid, -1, indices[:, None].expand(-1, 2, -1))
         match_mask = torch.gather(tgt_mask_down, -1, indices)

@@ -115,7 +115,9 @@ class Trainer:
         the reference's zero_grad()) directly on the flat gradient buffer the parameters' .grad are views of:
         ~10 launches, no host round trip, no gather / scatter copies (the reference does one isnan().sum() > 0
         host sync per parameter).  With N > 1 most of the all-reduce has already run underneath backward."""
-        flat = self.grads.finish()                      # SUM over ranks; waits for the in-flight buckets
+        # SUM over ranks; waits for the in-flight buckets.  Parameters without a gradient this step (shapenerf under no_deform,
+        # decoder units a flag switches off) keep grad = None like after the reference's zero_grad(): AdamW skips them
+        flat = self.grads.finish(keep_unused_none=True)
         if self.grads.world > 1:
             flat.div_(self.grads.world)
         finite = torch.isfinite(flat).all()
@@ -216,13 +218,16 @@ class Trainer:
         return history
 
     def save(self, path):
-        """rank 0 writes (trainer.py:152-158 guards with local_rank <= 0); every rank must call it: the per-rank BatchNorm
-        statistics are averaged first so the checkpoint does not depend on which rank saves"""
-        if self.reducer is not None:
-            self.reducer.average_buffers(self.model)
+        """rank 0 writes (trainer.py:152-158 guards with local_rank <= 0).  COLLECTIVE when world > 1: every rank must call it
+        (Trainer.train does) -- the per-rank BatchNorm running statistics are averaged INTO THE SAVED COPY so the checkpoint
+        does not depend on which rank writes it; the live buffers keep their per-rank values and nothing else is reduced."""
+        averaged = self.reducer.averaged_running_stats(self.model) if self.reducer is not None else {}
         if self.rank != 0:
             return
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        state = self.model.state_dict()
+        state = dict(self.model.state_dict())
+        for name, avg in averaged.items():
+            if name in state:
+                state[name] = avg
         state["mesh.faces"] = self.model.mesh.faces.cpu()
         torch.save(state, path)

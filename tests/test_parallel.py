@@ -77,8 +77,65 @@ def _reducer_worker(rank, world, port, out):
     dist.all_gather_object(sync, [w.numpy() for w in w0])
     for a, b in zip(sync[0], sync[1]):
         assert (a == b).all()
-    red.average_buffers(model)
+    # checkpoint statistics: averaged into a COPY; the live buffers keep their per-rank values, non-statistics are not touched
+    model.register_buffer("running_mean", torch.full((3,), float(rank)))
+    avg = red.averaged_running_stats(model)
+    assert set(avg) == {"running_mean"} and torch.equal(avg["running_mean"], torch.full((3,), 0.5))
+    assert torch.equal(model.running_mean, torch.full((3,), float(rank))) and torch.equal(model.running, torch.full((3,), 0.0))
     out.put((rank, launched_during))
+    dist.destroy_process_group()
+
+
+def _late_parameter_worker(rank, world, port, out):
+    """a parameter that had no gradient in the previous step starts producing one.
+    (a) its gradient arrives BEFORE its bucket is complete: the bucket must not go out from a hook any more (finish()
+        launches it after backward) and the averaged gradients must be exact;
+    (b) it arrives AFTER the bucket was all-reduced: unrecoverable, must raise instead of training on diverged replicas."""
+    _init(rank, world, port)
+    from scp_amd.parallel import FlatGradients
+    torch.manual_seed(0)
+    a, b, c = torch.nn.Linear(6, 6), torch.nn.Linear(6, 6), torch.nn.Linear(6, 6)
+    params = list(a.parameters()) + list(b.parameters()) + list(c.parameters())
+    red = FlatGradients(params, bucket_bytes=1 << 20)          # one bucket
+    assert len(red.buckets) == 1
+    x = torch.randn(5, 6, generator=torch.Generator().manual_seed(7 + rank))
+    red.prepare()
+    b(x).square().sum().backward()                             # step 1: only b is used -> a, c are learned as silent
+    red.finish(keep_unused_none=True)
+    assert all(p.grad is None for p in list(a.parameters()) + list(c.parameters()))       # unused: AdamW would skip them
+    assert all(p.grad is not None for p in b.parameters())
+    # (a) c(b(x)): c's gradients come first, while b's are still pending
+    red.prepare()
+    assert all(p.grad is not None and p.grad.data_ptr() == red.views[id(p)].data_ptr() for p in params)
+    c(b(x)).square().sum().backward()
+    assert red.launched_in_backward == 0                       # the poisoned bucket waits for finish()
+    flat = red.finish().clone().div_(world)
+    local = torch.autograd.grad(c(b(x)).square().sum(), list(b.parameters()) + list(c.parameters()))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [g.numpy() for g in local])
+    for i, p in enumerate(list(b.parameters()) + list(c.parameters())):
+        o, n = red.span[id(p)]
+        want = sum(torch.tensor(g[i]) for g in gathered) / world
+        torch.testing.assert_close(flat[o:o + n].view_as(p), want, rtol=1e-6, atol=1e-7)
+    # (b) a step that uses b only (a and c silent again), then b(a(x)): b completes the bucket, a's gradient arrives after
+    # the all-reduce was enqueued
+    red.prepare(); b(x).square().sum().backward(); red.finish()
+    red.prepare()
+    raised = False
+    try:
+        b(a(x)).square().sum().backward()
+    except RuntimeError as e:
+        raised = "after its bucket" in str(e)
+    # every rank raises at the same point, so no collective is left half-issued; reset_static_graph() is the documented way
+    red._armed = False
+    for w in red._work:
+        if w is not None:
+            w.wait()
+    red.reset_static_graph()
+    red.prepare()
+    b(a(x)).square().sum().backward()
+    red.finish()
+    out.put((rank, raised))
     dist.destroy_process_group()
 
 
@@ -165,6 +222,48 @@ def test_bucket_all_reduce_overlaps_backward_gloo_world2():
 
 def test_trainer_step_data_parallel_gloo_world2():
     _run(_trainer_worker)
+
+
+def test_parameter_that_becomes_used_gloo_world2():
+    got = _run(_late_parameter_worker)
+    assert all(got.values()), "a gradient that arrived after its bucket's all-reduce must raise"
+
+
+def _rccl_two_rank_worker(rank, world, port, out):
+    """2 real RCCL ranks on 2 GPUs: 1 x (2B) equals 2 x B (mean of the per-rank gradients == gradient of the mean loss over the
+    joint batch), and >= 2 buckets are enqueued from inside backward"""
+    for p in (ROOT, os.path.join(ROOT, "self-corr-pose_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from scp_amd.parallel import FlatGradients
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(*[torch.nn.Linear(256, 256) for _ in range(6)]).cuda()
+    red = FlatGradients(net.parameters(), bucket_bytes=2 * (256 * 256 + 256) * 4)
+    red.broadcast_parameters(net, 0)
+    xs = torch.randn(2 * 8, 256, generator=torch.Generator().manual_seed(5)).cuda()
+    ref = torch.autograd.grad(net(xs).square().sum(1).mean(), list(net.parameters()))          # one process, 2B samples
+    red.prepare()
+    net(xs[rank * 8:(rank + 1) * 8]).square().sum(1).mean().backward()                        # this rank's B samples
+    launched = red.launched_in_backward
+    flat = red.finish()
+    flat.div_(world)
+    torch.cuda.synchronize()
+    for p, g in zip(net.parameters(), ref):
+        torch.testing.assert_close(p.grad, g, rtol=2e-5, atol=1e-6)
+    out.put((rank, launched))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_rccl_gradient_equals_joint_batch():
+    """needs >= 2 visible GPUs (the round-end 1-GPU box skips it; an 8-GPU node runs it)"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible GPU: RCCL refuses two ranks on one device")
+    got = _run(_rccl_two_rank_worker)
+    assert all(v >= 2 for v in got.values()), got
 
 
 @pytest.mark.gpu

@@ -49,7 +49,13 @@ def test_full_step_free_running_on_gpu():
         cap["enc"] = out
         return out
     model.encoder.forward = spy
-    report = step_case.run_and_compare(model, data, d, rtol_loss=band, grad_rel_l2=0.1, grad_cos=0.995)
+    # what is ASSERTED is tighter than the reference's own conditioning band: per term max(1e-4, 3 x the deviation observed
+    # on the MI355X in round 2, profiles/r02_ref_tests.txt), never wider than the band -- a 10x regression of any term fails
+    observed_r02 = {"total_loss": 6.15e-6, "mask_loss": 1.08e-5, "triangle_loss": 4.62e-7, "deform_loss": 1.09e-6, "pullfar_loss": 0.0,
+                    "symmetry_loss": 5.92e-7, "match_loss": 5.81e-6, "texture_loss": 4.91e-5, "imatch_loss": 5.51e-7,
+                    "cycle_loss_pretrain": 8.55e-8, "cycle_loss": 9.89e-8, "depth_loss": 5.19e-5}
+    asserted = {k: min(b, max(1e-4, 3.0 * observed_r02.get(k, 0.0))) for k, b in band.items()}
+    report = step_case.run_and_compare(model, data, d, rtol_loss=asserted, grad_rel_l2=0.1, grad_cos=0.995)
     # the premise of the band: the encoder's geometric outputs deviate from the reference's by no more than the
     # perturbation levels the fixture covers
     for j, key in ((2, "pred_v"), (3, "rotation"), (4, "translation")):
@@ -58,8 +64,79 @@ def test_full_step_free_running_on_gpu():
         assert np.sqrt((dev ** 2).mean()) <= float(sigmas.max())
     for k, (got, ref) in report.items():
         if k in band:
-            print("%-22s rel dev %.2e | allowed %.2e (reference's own spread under perturbation %.2e)"
-                  % (k, abs(got - ref) / max(abs(ref), 1e-12), band[k], spread[k]))
+            print("%-22s rel dev %.2e | asserted %.2e | reference's own spread under perturbation %.2e"
+                  % (k, abs(got - ref) / max(abs(ref), 1e-12), asserted[k], spread[k]))
+
+
+def test_full_step_b8_laptop_vs_oracle_backend(monkeypatch):
+    """BASELINE configs[1] as a WHOLE step (B = 8 = batch_size 2 x repeat 4, laptop mesh 995 v / 1986 f): forward + backward on
+    the GPU (HIP kernels) against the same step on the CPU oracle backend (oracle/backend.py: C rasteriser + torch
+    restatements, themselves pinned to the reference's recordings in tests/golden).  Identical recipe weights, batch and
+    pinned RNG consumers; the CPU side's mutual-NN / top-k selections are injected on the GPU side.
+    Every loss term within max(1e-4, the reference's own conditioning band), poses within 1e-4 / 1e-5, probe gradients
+    cos >= 0.9995 / rel-L2 <= 5e-2."""
+    import numpy as np
+    import golden_io
+    import oracle_backend
+    import recipe
+    import synth
+    import scp_amd.dino as dino
+    from scp_amd.flags import Options
+    from scp_amd.model import MeshNet
+    d = golden_io.load("step_laptopflags_laptop_b2x2")
+    assert d["prior_verts"].shape[0] == 995 and d["prior_faces"].shape[0] == 1986
+    dino.ALLOW_RANDOM_INIT = True
+    bs, rep = 2, 4
+
+    def build(device):
+        opts = Options("laptop_wild6d", batch_size=bs, repeat=rep, train=True, vis_freq=10 ** 9)
+        torch.manual_seed(0)
+        model = MeshNet(opts, prior=(d["prior_verts"], d["prior_faces"]))
+        recipe.load_recipe(model)
+        model.encoder.random_jitter = torch.nn.Identity()
+        model.rotation_angle = 90.0
+        k = model.mesh.symm_rots.shape[0]
+        fi, bary = recipe.symmetry_sample(k * bs * rep, 10000, model.mesh.num_faces)
+        model = model.to(device).train()
+        model.mesh.sample_override = (fi.to(device), bary.to(device))
+        model.iters = 0
+        return model
+
+    probes = {"mean_v": "mesh.mean_v", "resnet_conv1": "encoder.backbone.resnet.conv1.weight", "featnet_proj": "encoder.featnet.proj.weight",
+              "pose_trans": "encoder.pose_predictor.trans_pred_layer.weight", "mesh_stn_fc": "encoder.featnet_mesh.stn.fc.weight"}
+
+    def run(model, data):
+        total, aux = model(data)
+        total.mean().backward()
+        params = dict(model.named_parameters())
+        return ({k: float(v) for k, v in aux.items()}, [t.detach().cpu().double().numpy() for t in model.last_pose],
+                {k: params[n].grad.detach().cpu().double().numpy().ravel() for k, n in probes.items()})
+
+    with monkeypatch.context() as mp:
+        oracle_backend.install(mp)                     # CPU stand-ins for every HIP kernel (checker side only)
+        cpu = build("cpu")
+        ref_aux, ref_pose, ref_grad = run(cpu, synth.make_batch(bs, rep, 256, seed=3, device="cpu"))
+        pc = cpu.pretrain_corr_net
+        sel_nn, sel_topk = tuple(t.clone() for t in pc.last_nn), pc.last_topk.clone()
+    gpu = build("cuda")
+    from scp_amd.soft_renderer.cuda import soft_rasterize as native
+    assert native.forward_soft_rasterize.__module__.startswith("scp_amd"), "HIP path must be the one that runs"
+    gpu.pretrain_corr_net.nn_override = tuple(t.cuda() for t in sel_nn)
+    gpu.pretrain_corr_net.topk_override = sel_topk.cuda()
+    got_aux, got_pose, got_grad = run(gpu, synth.make_batch(bs, rep, 256, seed=3, device="cuda"))
+    band, _, _ = step_case.conditioning_band()
+    for k, ref in ref_aux.items():
+        rel = abs(got_aux[k] - ref) / max(abs(ref), 1e-6)
+        print("%-22s cpu-oracle %.9g gpu %.9g rel %.2e" % (k, ref, got_aux[k], rel))
+        assert rel <= band.get(k, 1e-4), "%s: %.9g vs %.9g (rel %.2e)" % (k, got_aux[k], ref, rel)
+    np.testing.assert_allclose(got_pose[0], ref_pose[0], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(got_pose[1], ref_pose[1], rtol=1e-4, atol=1e-5)
+    for k in probes:
+        g, r = got_grad[k], ref_grad[k]
+        rel = np.linalg.norm(g - r) / np.linalg.norm(r)
+        cos = g @ r / (np.linalg.norm(g) * np.linalg.norm(r))
+        print("grad %-14s rel L2 %.3e cos %.7f" % (k, rel, cos))
+        assert rel <= 5e-2 and cos >= 0.9995, "%s: rel L2 %.3e cos %.7f" % (k, rel, cos)
 
 
 def test_trainer_step_runs_and_updates():

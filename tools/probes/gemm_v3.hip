@@ -17,6 +17,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINBLK) void gemm_plain_kernel(c
                                                                                float* __restrict__ C, int M, int N, int K, int nblk_n,
                                                                                int per_xcd, int panels, long long* stamps) {
     const long long t0 = __builtin_amdgcn_s_memtime();
+    const long long r0 = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using Core = scp::GemmCore<CFG>;
     const int t = blockIdx.x;
@@ -48,7 +49,10 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINBLK) void gemm_plain_kernel(c
         const long long t3 = __builtin_amdgcn_s_memtime();
         if ((threadIdx.x & 63) == 0) {
             long long* o = stamps + ((size_t)blockIdx.x * CFG::NW + (threadIdx.x >> 6)) * 4;
+            long long* clk = stamps + (size_t)gridDim.x * CFG::NW * 4 + ((size_t)blockIdx.x * CFG::NW + (threadIdx.x >> 6)) * 2;
             o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+            const long long r3 = __builtin_amdgcn_s_memrealtime();
+            clk[0] = t3 - t0; clk[1] = r3 - r0;
         }
     }
 }
@@ -92,27 +96,37 @@ void run(const char* name, const float* A, const float* W, float* C, const float
     {
         long long* st;
         const size_t ns = (size_t)grid * CFG::NW * 4;
-        hipMalloc(&st, ns * 8); hipMemset(st, 0, ns * 8);
+        hipMalloc(&st, ns * 8 * 2); hipMemset(st, 0, ns * 8 * 2);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG::THREADS), lds_bytes, 0, A, W, C, M, N, K, nblk_n, per_xcd, panels, st);
         hipDeviceSynchronize();
-        std::vector<long long> hs(ns);
-        hipMemcpy(hs.data(), st, ns * 8, hipMemcpyDeviceToHost);
+        std::vector<long long> hs(ns * 2);
+        hipMemcpy(hs.data(), st, ns * 8 * 2, hipMemcpyDeviceToHost);
+        double ct = 0, cr = 0;
+        for (size_t w = 0; w < ns / 4; w++) { ct += hs[ns + 2 * w]; cr += hs[ns + 2 * w + 1]; }
+        printf("    shader clock during the launch: %.3f GHz (s_memtime / s_memrealtime at 100 MHz)\n", ct / cr * 0.1);
         hipFree(st);
         double pro = 0, loop = 0, epi = 0; long long tmin = -1, tmax = 0; int cnt = 0;
         for (size_t w = 0; w < ns / 4; w++) {
             if (hs[4 * w + 3] == 0) continue;
             pro += hs[4 * w + 1] - hs[4 * w]; loop += hs[4 * w + 2] - hs[4 * w + 1]; epi += hs[4 * w + 3] - hs[4 * w + 2];
-            if (tmin < 0 || hs[4 * w] < tmin) tmin = hs[4 * w];
-            if (hs[4 * w + 3] > tmax) tmax = hs[4 * w + 3];
+            if ((w / CFG::NW) % 8 == 0) {                       // one XCD's workgroups share a counter
+                if (tmin < 0 || hs[4 * w] < tmin) tmin = hs[4 * w];
+                if (hs[4 * w + 3] > tmax) tmax = hs[4 * w + 3];
+            }
             cnt++;
         }
-        printf("    per wavefront (memtime ticks): setup %.0f  main loop %.0f (ideal %d)  epilogue %.0f ; kernel span %lld ticks\n", pro / cnt, loop / cnt,
-               (K / 16) * CFG::NM * 2 * 64, epi / cnt, tmax - tmin);
+        hipEvent_t g0, g1; hipEventCreate(&g0); hipEventCreate(&g1);
+        hipEventRecord(g0);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG::THREADS), lds_bytes, 0, A, W, C, M, N, K, nblk_n, per_xcd, panels, (long long*)nullptr);
+        hipEventRecord(g1); hipEventSynchronize(g1);
+        float gms; hipEventElapsedTime(&gms, g0, g1);
+        printf("    per wavefront (memtime ticks): setup %.0f  main loop %.0f (ideal %d)  epilogue %.0f ; XCD0 span %lld ticks for a %.1f us launch = %.2f ticks/ns\n", pro / cnt, loop / cnt,
+               (K / 16) * CFG::NM * 2 * 64, epi / cnt, tmax - tmin, gms * 1e3, (tmax - tmin) / (gms * 1e6));
     }
     {
         long long* st;
         const size_t ns = (size_t)grid * CFG::NW * 4;
-        hipMalloc(&st, ns * 8);
+        hipMalloc(&st, ns * 8 * 2);
         hipEvent_t f0, f1; hipEventCreate(&f0); hipEventCreate(&f1);
         hipEventRecord(f0);
         for (int i = 0; i < reps; i++) hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG::THREADS), lds_bytes, 0, A, W, C, M, N, K, nblk_n, per_xcd, panels, st);
@@ -153,7 +167,7 @@ int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 32800;
     const bool race_mode = argc > 2;
     struct Shape { int N, K; const char* name; };
-    const Shape shapes[] = {{1152, 384, "qkv"}, {384, 384, "proj"}, {1536, 384, "fc1"}, {384, 1536, "fc2"}, {128, 1152, "conv128"}, {64, 576, "conv64"}};
+    const Shape shapes[] = {{1152, 384, "qkv"}, {384, 384, "proj"}, {1536, 384, "fc1"}, {384, 1536, "fc2"}, {128, 1152, "conv128"}, {64, 576, "conv64"}, {1024, 384, "n1024"}};
     const size_t maxA = (size_t)M * 1536, maxW = (size_t)1536 * 1536, maxC = (size_t)M * 1536;
     float *A, *W, *C, *Cref;
     hipMalloc(&A, maxA * 4); hipMalloc(&W, maxW * 4); hipMalloc(&C, maxC * 4); hipMalloc(&Cref, maxC * 4);
