@@ -265,15 +265,28 @@ int scp_batchnorm_act_backward_bf16(const void* dy, const void* x, const void* y
                                     int C, int relu, int has_skip, int training, void* dx, void* dskip, float* dgamma,
                                     float* dbeta, void* workspace, size_t workspace_bytes, unsigned* ticket, void* stream);
 
-/* ---- encoder: 3x3 / stride 1 / pad 1 convolution, NHWC fp32, implicit GEMM on the fp32 matrix cores ---------------------
- * Replaces the nn.Conv2d(k=3, s=1, p=1) calls of torchvision's BasicBlock and of the U-decoder's conv units as instantiated by
- * model/module/network/image_encoder.py:119-193 (F.conv2d on MIOpen in the reference / round 1).
- *   x [N,H,W,Cin], w [Cout,3,3,Cin] (= the channels_last storage of a [Cout,Cin,3,3] tensor), bias [Cout] or NULL,
- *   y [N,H,W,Cout];  zeros64: >= 64 bytes of zeros on the device (source of the padding taps).
- * The input gradient is the same call with dy as x, Cin <-> Cout and w transposed + flipped ([Cin,3,3,Cout], tap (2-ky, 2-kx)).
- * Requires Cin % 16 == 0 and N*H*W % 128 == 0 (else hipErrorInvalidValue: the caller keeps its library convolution). */
-int scp_conv3x3_nhwc_forward(const float* x, const float* w, const float* bias, const float* zeros64, float* y, int N, int H,
-                             int W, int Cin, int Cout, void* stream);
+/* ---- encoder: 3x3 / 1x1 convolutions, stride 1 or 2, NHWC fp32, implicit GEMM on the fp32 matrix cores -------------------
+ * Replaces the nn.Conv2d calls of torchvision's BasicBlock (3x3 s1/s2 p1, 1x1 s2 downsample) and of the U-decoder's conv units
+ * as instantiated by model/module/network/image_encoder.py:119-193, net_blocks.py:336-359 (F.conv2d on MIOpen in the
+ * reference / rounds 1-2).  csrc/conv_igemm.hip (forward, input gradient), csrc/conv_wgrad.hip (weight gradient).
+ *   x [N,H,W,Cin], w [Cout,k,k,Cin] (= the channels_last storage of a [Cout,Cin,k,k] tensor), padding k/2,
+ *   y [N,Ho,Wo,Cout] with Ho = (H + 2 (k/2) - k) / stride + 1.
+ *   leaky != 0: y = leaky_relu(conv + bias[Cout], slope) (the decoder's conv unit); else the raw convolution (bias ignored).
+ *   partials (or NULL): [tiles_m][2][Cout] per-tile column sums of the RAW output and of its squares over the tile's
+ *   rows_per_tile output pixels (scp_conv_nhwc_partial_rows gives both numbers) -- the BatchNorm that follows folds them into
+ *   its batch statistics instead of re-reading y (scp_batchnorm_act_forward_partials).
+ * The input gradient of a stride-1 convolution is the same call with dy as x, Cin <-> Cout and w transposed + flipped
+ * ([Cin,k,k,Cout], tap (k-1-ky, k-1-kx)).  Requires Cin a power of two >= 32, k in {1, 3}, stride in {1, 2}
+ * (else hipErrorInvalidValue: the caller keeps its library convolution -- the 7x7 stem does).
+ * scp_conv_nhwc_weight_grad: dw [Cout,k,k,Cin] = sum over output pixels of dy[p][co] x[p + tap][ci]; x [N,H,W,Cin],
+ *   dy [N,Ho,Wo,Cout]; workspace >= scp_conv_nhwc_weight_grad_workspace(...) bytes (partial sums of the pixel split, folded in a
+ *   fixed order: deterministic); dbias (or NULL): [Cout] = sum over pixels of dy. */
+int scp_conv_nhwc_forward(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int H, int W,
+                          int Cin, int Cout, int ksize, int stride, int leaky, float slope, void* stream);
+int scp_conv_nhwc_partial_rows(int N, int H, int W, int Cout, int ksize, int stride, int* tiles_m, int* rows_per_tile);
+size_t scp_conv_nhwc_weight_grad_workspace(int N, int H, int W, int Cin, int Cout, int ksize, int stride);
+int scp_conv_nhwc_weight_grad(const float* x, const float* dy, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                              int N, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
 
 /* ---- stem max pooling ------------------------------------------------------------------------------------------
  * nn.MaxPool2d(3, 2, 1) of torchvision's resnet18 stem (image_encoder.py:119-139), NHWC, even H and W, C % 4 == 0:

@@ -1,0 +1,265 @@
+// self-corr-pose_amd/csrc/conv_igemm.hip -- the image encoder's 3x3 / 1x1 convolutions on NHWC fp32 activations as implicit
+// GEMMs on the gfx950 fp32 matrix cores: forward, input gradient (the same kernel on transformed weights) -- the weight
+// gradient is csrc/conv_wgrad.hip.
+//
+// Replaces MIOpen for model/module/network/image_encoder.py:119-193 (ResNet18 BasicBlocks of the trunk, the U-decoder's
+// conv units of net_blocks.py:336-359), called twice per step (encoder.py:29-37, correspondence.py:91).
+//
+// GEMM view: y[M = N Ho Wo pixels][Cout] = A[M][K = taps x Cin] W[Cout][K]^T with K ordered (tap, channel).  In NHWC the 16
+// consecutive channels of one tap of one pixel are 64 contiguous bytes -- one LDS-DMA row of csrc/gemm_core.h -- and the
+// channels_last storage of a [Cout, Cin, kh, kw] weight tensor IS [Cout][ky][kx][Cin], the K-contiguous W operand.  So this is
+// the GEMM core with an A source that gathers: the source of a row is its pixel's address plus a wavefront-uniform tap offset.
+// Taps that fall outside the image are not branched on: the A tile is loaded through a BUFFER descriptor
+// (buffer_load_dwordx4 ... lds) and their lanes get an offset beyond the descriptor's size, for which the hardware returns
+// zeros -- no zero page, no im2col, nothing unfolded; the nine taps of a pixel re-read the same input rows through L2.
+// Stride 2 (the first block of layer2..4) only changes the pixel -> address map.
+//
+// Epilogues: raw output (BatchNorm follows); + bias + LeakyReLU (decoder units, net_blocks.py:336-359 with_bn=False);
+// optionally the per-channel sum and sum of squares of the tile's rows, so that the BatchNorm that follows does not have to
+// read the activation again for its statistics (csrc/batchnorm.hip folds the per-tile partials in a fixed order).
+// Tile shapes (all 4 wavefronts, 2 workgroups per CU): 256 x 64 for the 64-channel layers (131072 pixels -> 512 tiles),
+// 64 x 128 and 64 x 64 for the deeper, narrower-in-pixels layers so that every layer launches >= 256 tiles.
+// Roofline: bound = fp32 MFMA (157.3 TFLOP/s nominal; the clock the part sustains under this load is ~1.95 GHz = 128 TFLOP/s,
+// tools/probes/gemm_v3.hip); algorithmic flops 2 M Cout taps Cin; algorithmic bytes 4 (M_in Cin + taps Cin Cout + M Cout).
+#include <hip/hip_runtime.h>
+
+#include "gemm_core.h"
+#include "scp_common.h"
+#include "scp_hip.h"
+
+namespace {
+
+using scp::f32x16;
+
+struct ConvArgs {
+    const float* x;        // [N, H, W, Cin]
+    const float* w;        // [Cout, taps, Cin]
+    const float* bias;     // [Cout] or nullptr
+    float* y;              // [N, Ho, Wo, Cout]
+    float* partials;       // [tiles_m][2][Cout] or nullptr
+    int H, W, Ho, Wo, Cin, Cout, M, K;
+    int stride, lg_cpt;    // chunks per tap = Cin / 16 = 1 << lg_cpt
+    int nblk_n, tiles_m;
+    unsigned x_bytes;
+    float slope;
+};
+
+// one LDS-DMA piece through a buffer descriptor: lanes whose offset is beyond the descriptor read zeros
+__device__ __forceinline__ void bufload16(unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <class CFG, int TAPS>
+struct ConvSource {
+    __amdgpu_buffer_rsrc_t rsrc;
+    const char* w_base;
+    unsigned a_pix[CFG::A_PER], tap_ok[CFG::A_PER], w_off[CFG::W_PER];
+    int Win, Cin, lg_cpt;
+
+    __device__ __forceinline__ void set(const ConvArgs& g, int m0, int n0, int wave, int lane) {
+        const int prow = lane >> 2, pslot = lane & 3;
+        const int chunk = pslot ^ ((prow >> 2) & 3);
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, (int)g.x_bytes, 0x00020000);
+        w_base = reinterpret_cast<const char*>(g.w);
+        Win = g.W; Cin = g.Cin; lg_cpt = g.lg_cpt;
+        const int hw = g.Ho * g.Wo;
+#pragma unroll
+        for (int i = 0; i < CFG::A_PER; i++) {
+            const int r = 16 * (wave * CFG::A_PER + i) + prow;
+            const int p = min(m0 + r, g.M - 1);
+            const int img = p / hw, rem = p - img * hw;
+            const int yo = rem / g.Wo, xo = rem - yo * g.Wo;
+            const int yi = yo * g.stride, xi = xo * g.stride;          // centre tap
+            a_pix[i] = ((unsigned)((img * g.H + yi) * g.W + xi) * (unsigned)g.Cin + 4u * chunk) * 4u;
+            unsigned ok = 0;
+            if (TAPS == 9) {
+#pragma unroll
+                for (int tap = 0; tap < 9; tap++) {
+                    const int y2 = yi + tap / 3 - 1, x2 = xi + tap % 3 - 1;
+                    if (y2 >= 0 && y2 < g.H && x2 >= 0 && x2 < g.W) ok |= 1u << tap;
+                }
+            } else {
+                ok = 1u;
+            }
+            tap_ok[i] = ok;
+        }
+#pragma unroll
+        for (int i = 0; i < CFG::W_PER; i++) {
+            const int r = 16 * (wave * CFG::W_PER + i) + prow;
+            w_off[i] = ((unsigned)min(n0 + r, g.Cout - 1) * (unsigned)g.K + 4u * chunk) * 4u;
+        }
+    }
+    template <int I>
+    __device__ __forceinline__ void issue(int kc, unsigned stage_lds, int wave) const {
+        if constexpr (I < CFG::A_PER) {
+            const int tap = kc >> lg_cpt, c = kc - (tap << lg_cpt);
+            int delta = 64 * c;
+            if (TAPS == 9) {
+                const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;                   // tap / 3, tap % 3 for tap < 9
+                delta += ((ky - 1) * Win + (kx - 1)) * Cin * 4;
+            }
+            const bool ok = (tap_ok[I] >> tap) & 1u;
+            const unsigned voff = ok ? a_pix[I] + (unsigned)delta : 0x80000000u;      // beyond the descriptor: zeros
+            bufload16(voff, rsrc, stage_lds + (unsigned)(wave * CFG::A_PER + I) * 1024u);
+        } else {
+            scp::glds16(w_off[I - CFG::A_PER], w_base + (size_t)kc * (CFG::BK * 4),
+                        stage_lds + CFG::W_BASE_BYTES + (unsigned)(wave * CFG::W_PER + (I - CFG::A_PER)) * 1024u);
+        }
+    }
+};
+
+enum { EPI_RAW = 0, EPI_BIAS_LEAKY = 1 };
+
+template <class CFG, int TAPS, int EPI, bool STATS>
+__global__ __launch_bounds__(CFG::THREADS, 2) void conv_igemm_kernel(const ConvArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[CFG::LDS_BYTES / 4];
+    using Core = scp::GemmCore<CFG, ConvSource<CFG, TAPS>>;
+    // tile order: workgroup t runs on XCD t % 8; consecutive tiles of one XCD walk the column blocks of one pixel panel
+    const int total = g.tiles_m * g.nblk_n;
+    const int per_xcd = (total + 7) >> 3;
+    const int lid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lid >= total) return;
+    const int bm = lid / g.nblk_n, bn = lid - bm * g.nblk_n;
+    const int m0 = bm * CFG::BM, n0 = bn * CFG::BN;
+    Core core(lds);
+    core.src.set(g, m0, n0, core.wave, core.lane);
+    typename Core::Acc acc;
+    core.run(acc, g.K / CFG::BK);
+
+    const int half = core.lane >> 5, l31 = core.lane & 31;
+    float csum[CFG::WN], csq[CFG::WN];
+#pragma unroll
+    for (int j = 0; j < CFG::WN; j++) csum[j] = csq[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < CFG::WM; i++) {
+        const int mb = m0 + core.row_base() + 32 * i;
+#pragma unroll
+        for (int j = 0; j < CFG::WN; j++) {
+            const int n = n0 + core.col_base() + 32 * j + l31;
+            const bool n_ok = n < g.Cout;
+            float b = 0.f;
+            if (EPI == EPI_BIAS_LEAKY) b = g.bias[min(n, g.Cout - 1)];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mb + scp::acc_row(r, half);
+                float v = acc.t[i * CFG::WN + j][r];
+                const bool live = m < g.M && n_ok;
+                if (STATS && live) {
+                    csum[j] += v;
+                    csq[j] += v * v;
+                }
+                if (EPI == EPI_BIAS_LEAKY) {
+                    v += b;
+                    v = v > 0.f ? v : v * g.slope;
+                }
+                if (live) g.y[(size_t)m * g.Cout + n] = v;
+            }
+        }
+    }
+    if (STATS) {
+        // column sums of this tile's rows: the two half-waves hold different rows of the same columns; the NWM wavefronts
+        // stacked along M are folded through LDS (the ring is idle now) in a fixed order
+        __syncthreads();
+        float* red = lds;                                   // [NW][WN][2][32]
+#pragma unroll
+        for (int j = 0; j < CFG::WN; j++) {
+            const float s = csum[j] + __shfl_xor(csum[j], 32), q = csq[j] + __shfl_xor(csq[j], 32);
+            if (half == 0) {
+                red[((core.wave * CFG::WN + j) * 2 + 0) * 32 + l31] = s;
+                red[((core.wave * CFG::WN + j) * 2 + 1) * 32 + l31] = q;
+            }
+        }
+        __syncthreads();
+        // thread t < BN * 2: (which, column)
+        const int t = threadIdx.x;
+        if (t < 2 * CFG::BN) {
+            const int which = t / CFG::BN, col = t - which * CFG::BN;
+            const int wn = col / (32 * CFG::WN), j = (col >> 5) % CFG::WN, l = col & 31;
+            float s = 0.f;
+#pragma unroll
+            for (int wm = 0; wm < CFG::NWM; wm++) s += red[(((wm * CFG::NWN + wn) * CFG::WN + j) * 2 + which) * 32 + l];
+            const int n = n0 + col;
+            if (n < g.Cout) g.partials[((size_t)bm * 2 + which) * g.Cout + n] = s;
+        }
+    }
+}
+
+using Cfg256x64 = scp::GemmCfg<2, 2, 4, 1, 2, 2>;     // 64-channel layers at 64 x 64 resolution
+using Cfg64x128 = scp::GemmCfg<1, 2, 2, 2, 2, 2>;
+using Cfg64x64 = scp::GemmCfg<1, 1, 2, 2, 2, 2>;
+
+template <class CFG, int TAPS>
+void launch_cfg(ConvArgs& g, bool leaky, bool stats, hipStream_t st) {
+    g.nblk_n = (g.Cout + CFG::BN - 1) / CFG::BN;
+    g.tiles_m = (g.M + CFG::BM - 1) / CFG::BM;
+    const int total = g.tiles_m * g.nblk_n;
+    const dim3 grid(((total + 7) >> 3) << 3), block(CFG::THREADS);
+    if (leaky) {
+        if (stats) hipLaunchKernelGGL((conv_igemm_kernel<CFG, TAPS, EPI_BIAS_LEAKY, true>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((conv_igemm_kernel<CFG, TAPS, EPI_BIAS_LEAKY, false>), grid, block, 0, st, g);
+    } else {
+        if (stats) hipLaunchKernelGGL((conv_igemm_kernel<CFG, TAPS, EPI_RAW, true>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((conv_igemm_kernel<CFG, TAPS, EPI_RAW, false>), grid, block, 0, st, g);
+    }
+}
+
+// tile shape of a layer: the widest tile that still gives the machine >= 256 workgroups
+int pick_cfg(long M, int Cout) {
+    if (Cout <= 64) return 0;                                                      // 256 x 64
+    const long t128 = ((M + 63) / 64) * ((Cout + 127) / 128);
+    return t128 >= 384 ? 1 : 2;                                                    // 64 x 128, else 64 x 64
+}
+int tile_rows(int cfg) { return cfg == 0 ? Cfg256x64::BM : 64; }
+
+}  // namespace
+
+extern "C" int scp_conv_nhwc_partial_rows(int N, int H, int W, int Cout, int ksize, int stride, int* tiles_m, int* rows_per_tile) {
+    const int pad = ksize / 2;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const long M = (long)N * Ho * Wo;
+    const int rows = tile_rows(pick_cfg(M, Cout));
+    if (tiles_m) *tiles_m = (int)((M + rows - 1) / rows);
+    if (rows_per_tile) *rows_per_tile = rows;
+    return 0;
+}
+
+extern "C" int scp_conv_nhwc_forward(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int H, int W,
+                                     int Cin, int Cout, int ksize, int stride, int leaky, float slope, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return scp::fail(hipErrorInvalidValue, "conv_nhwc: empty problem");
+    if (!x || !w || !y || (leaky && !bias)) return scp::fail(hipErrorInvalidValue, "conv_nhwc: null argument");
+    if (ksize != 1 && ksize != 3) return scp::fail(hipErrorInvalidValue, "conv_nhwc: kernel size must be 1 or 3");
+    if (stride != 1 && stride != 2) return scp::fail(hipErrorInvalidValue, "conv_nhwc: stride must be 1 or 2");
+    const int cpt = Cin / 16;
+    if (Cin % 32 != 0 || (cpt & (cpt - 1))) return scp::fail(hipErrorInvalidValue, "conv_nhwc: Cin must be a power of two >= 32");
+    const int pad = ksize / 2;
+    ConvArgs g{};
+    g.x = x; g.w = w; g.bias = bias; g.y = y; g.partials = partials;
+    g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.stride = stride; g.slope = slope;
+    g.Ho = (H + 2 * pad - ksize) / stride + 1;
+    g.Wo = (W + 2 * pad - ksize) / stride + 1;
+    const long M = (long)N * g.Ho * g.Wo, in_bytes = (long)N * H * W * Cin * 4;
+    if (in_bytes >= (1l << 31) || M * Cout >= (1l << 31) || (long)Cout * ksize * ksize * Cin >= (1l << 30))
+        return scp::fail(hipErrorInvalidValue, "conv_nhwc: tensor larger than 2^31 bytes");
+    g.M = (int)M;
+    g.K = ksize * ksize * Cin;
+    g.x_bytes = (unsigned)in_bytes;
+    g.lg_cpt = 0;
+    while ((1 << g.lg_cpt) < cpt) g.lg_cpt++;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int cfg = pick_cfg(M, Cout);
+    const bool stats = partials != nullptr;
+    if (ksize == 3) {
+        if (cfg == 0) launch_cfg<Cfg256x64, 9>(g, leaky, stats, st);
+        else if (cfg == 1) launch_cfg<Cfg64x128, 9>(g, leaky, stats, st);
+        else launch_cfg<Cfg64x64, 9>(g, leaky, stats, st);
+    } else {
+        if (cfg == 0) launch_cfg<Cfg256x64, 1>(g, leaky, stats, st);
+        else if (cfg == 1) launch_cfg<Cfg64x128, 1>(g, leaky, stats, st);
+        else launch_cfg<Cfg64x64, 1>(g, leaky, stats, st);
+    }
+    return scp::check_launch("conv_nhwc_forward");
+}

@@ -1,0 +1,292 @@
+// self-corr-pose_amd/csrc/conv_wgrad.hip -- weight gradient of the encoder's 3x3 / stride 1 / pad 1 convolutions, NHWC fp32, on the
+// gfx950 fp32 matrix cores:   dw[co][ky][kx][ci] = sum over output pixels p of dy[p][co] * x[p + (ky-1, kx-1)][ci].
+//
+// Replaces MIOpen's weight-gradient kernels for model/module/network/image_encoder.py:119-193 (BasicBlock 3x3 convolutions and
+// the U-decoder's conv units), backward of both encoder passes of a step (encoder.py:29-37, correspondence.py:91).
+//
+// GEMM view: the contraction runs over PIXELS, so both operands are "K-major" (a pixel's channels are contiguous, consecutive
+// pixels are the contraction index).  One workgroup owns a 64 (co) x 64 (ci) block of ALL NINE taps over a range of pixels:
+//   * a chunk = 16 consecutive output pixels of one image row (two rows of 8 for the 8 x 8 maps);
+//   * LDS holds dy[16 pixels][64 co] and the HALO block of x: (rows + 2) x (pixels + 2) input positions x 64 ci -- every tap is
+//     the same block read at a shifted row, so x is fetched once for nine taps.  Positions outside the image are zero-filled by
+//     the loader (buffer descriptor, out-of-range offsets return zeros): padding costs no branch and no second code path;
+//   * v_mfma_f32_32x32x2_f32 takes one k (= pixel) pair per instruction: a lane's operand element is LDS[pixel row][channel]
+//     -- 32 consecutive floats per half-wave, conflict-free ds_read_b32 with immediate offsets (pixel row and tap shift are
+//     compile-time), no transposition anywhere;
+//   * a wavefront accumulates 32 co x 32 ci x 9 taps = 144 accumulator VGPRs; per pixel pair 1 + 9 fragment reads feed 9 MFMAs.
+// The instruction stream is the software-pipelined in-order stream of csrc/gemm_core.h (asm statements: the reads of the next
+// pixel pair and the LDS-DMA of the chunk after next are issued in the shadow of the running MFMAs; one barrier per chunk).
+// The pixel range is split over workgroups so that a layer launches ~512 of them; each writes its partial [64][9][64] block and
+// a second kernel folds the partials in split order (deterministic, no atomics).
+// Roofline: bound = fp32 MFMA; algorithmic flops 2 M Cout 9 Cin; algorithmic bytes 4 (M Cin + M Cout + 9 Cin Cout).
+#include <hip/hip_runtime.h>
+
+#include "gemm_core.h"
+#include "scp_common.h"
+#include "scp_hip.h"
+
+namespace {
+
+using scp::f32x16;
+using scp::static_for;
+
+constexpr int THREADS = 256, BC = 64;            // block of output / input channels per workgroup
+constexpr int CHUNK = 16;                        // pixels per chunk
+constexpr int DY_BYTES = CHUNK * BC * 4;         // 4 KiB
+constexpr int X_ROWS = 64;                       // LDS rows reserved for the halo block (54 or 40 used)
+constexpr int STAGE_BYTES = DY_BYTES + X_ROWS * BC * 4;      // 20 KiB
+constexpr int NSTAGE = 2;
+constexpr int PER = 1 + 4;                       // LDS-DMA pieces per wavefront per chunk: 1 of dy, 4 of x
+
+struct WgradArgs {
+    const float* x;        // [N, H, W, Cin]
+    const float* dy;       // [N, H, W, Cout]
+    float* partial;        // [splits][Cout][9][Cin]
+    int lgW, lgH, Cin, Cout;
+    int ncob, ncib, splits, chunks_per_split, total_chunks;
+    unsigned x_bytes;
+};
+
+__device__ __forceinline__ void bufload16(unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+enum { MODE_ISSUE = 0, MODE_TAIL = 1, MODE_LAST = 2 };
+
+// CW = pixels of one image row inside a chunk (16, or 8 for 8-pixel-wide maps: a chunk is then two rows)
+template <int CW>
+struct WgradCore {
+    static constexpr int CR = CHUNK / CW, HC = CW + 2, HR = CR + 2;
+    static_assert(HR * HC <= X_ROWS, "halo block fits the reserved rows");
+    struct Acc { f32x16 t[9]; };
+    struct Frag { float a; float b[9]; };
+
+    const WgradArgs& g;
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned lds0, a_rd, b_rd;
+    unsigned dy_off;                 // lane's byte offset inside a dy chunk
+    int x_hr[4], x_hc[4];            // lane's halo position (row, column) per x piece; row < 0: beyond the block
+    unsigned x_lane;                 // lane's byte offset inside a pixel's channels
+    int wave, lane;
+    int chunk0;
+    const char* dy_base;
+    Frag F[2];
+
+    __device__ __forceinline__ WgradCore(const WgradArgs& args, float* lds, int cob, int cib, int first_chunk) : g(args) {
+        lds0 = SCP_LDS_ADDR(lds);
+        lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int half = lane >> 5, l31 = lane & 31;
+        const int wm = wave >> 1, wn = wave & 1;
+        a_rd = lds0 + half * (BC * 4) + (wm * 32 + l31) * 4;
+        b_rd = lds0 + DY_BYTES + half * (BC * 4) + (wn * 32 + l31) * 4;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, (int)g.x_bytes, 0x00020000);
+        chunk0 = first_chunk;
+        const int prow = lane >> 4, grp = lane & 15;          // a 1-KiB piece = 4 rows x 256 B
+        dy_off = ((unsigned)(4 * wave + prow) * (unsigned)g.Cout + (unsigned)(cob * BC)) * 4u + 16u * grp;
+        dy_base = reinterpret_cast<const char*>(g.dy);
+        x_lane = (unsigned)(cib * BC) * 4u + 16u * grp;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = 4 * (4 * wave + i) + prow;        // LDS row of the halo block
+            x_hr[i] = row < HR * HC ? row / HC : -1000;
+            x_hc[i] = row % HC;
+        }
+    }
+
+    // chunk c of this workgroup -> stage s
+    __device__ __forceinline__ void issue(int c, int s) {
+        const int gc = chunk0 + c;                             // global chunk index
+        const int p0 = gc * CHUNK;
+        const int W = 1 << g.lgW, H = 1 << g.lgH;
+        const int x0 = p0 & (W - 1), y0 = (p0 >> g.lgW) & (H - 1), img = p0 >> (g.lgW + g.lgH);
+        const unsigned stage = lds0 + (unsigned)s * STAGE_BYTES;
+        scp::glds16(dy_off, dy_base + (size_t)p0 * g.Cout * 4, stage + (unsigned)wave * 1024u);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int yy = y0 + x_hr[i] - 1, xx = x0 + x_hc[i] - 1;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const unsigned off = (unsigned)(((img << g.lgH) + yy) << g.lgW) + (unsigned)xx;
+            const unsigned voff = ok ? off * (unsigned)g.Cin * 4u + x_lane : 0x80000000u;
+            bufload16(voff, rsrc, stage + DY_BYTES + (unsigned)(4 * wave + i) * 1024u);
+        }
+    }
+
+    // fragments of pixel pair (2 st, 2 st + 1) of the chunk in stage S: A from dy, B per tap from the shifted halo rows
+    template <int S, int ST, int R>
+    __device__ __forceinline__ void read(Frag& f) {
+        if constexpr (R == 0) {
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.a) : "v"(a_rd), "i"(S * STAGE_BYTES + (2 * ST) * BC * 4));
+        } else {
+            constexpr int tap = R - 1, ky = tap / 3, kx = tap % 3;
+            // pixel k = 2 ST + half: row (k / CW + ky) * HC + k % CW + kx; 2 ST and 2 ST + 1 share the image row (CW is even)
+            constexpr int row = ((2 * ST) / CW + ky) * HC + (2 * ST) % CW + kx;
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.b[tap]) : "v"(b_rd), "i"(S * STAGE_BYTES + row * BC * 4));
+        }
+    }
+    template <int TAP>
+    __device__ __forceinline__ void mfma(Acc& acc, const Frag& f) {
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc.t[TAP]) : "v"(f.a), "v"(f.b[TAP]));
+    }
+
+    template <int S, int MODE>
+    __device__ __forceinline__ void chunk(Acc& acc, int c) {
+        static_for<0, 8>([&](auto st) {
+            constexpr int ST = decltype(st)::value;
+            Frag& cur = F[ST & 1];
+            Frag& nxt = F[(ST + 1) & 1];
+            static_for<0, 9>([&](auto tap) {
+                constexpr int T = decltype(tap)::value;
+                mfma<T>(acc, cur);
+                if constexpr (ST < 7) {
+                    read<S, ST + 1, T + 1>(nxt);
+                    if constexpr (T == 0) read<S, ST + 1, 0>(nxt);
+                } else if constexpr (MODE != MODE_LAST) {
+                    // last pixel pair of the chunk: every read of this chunk has completed (lgkmcnt(0) below); hand the
+                    // stage over, then start on the next chunk's first pair
+                    if constexpr (T == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                    if constexpr (T >= 1) {
+                        read<(S + 1) % NSTAGE, 0, T>(nxt);
+                        if constexpr (T == 1) read<(S + 1) % NSTAGE, 0, 0>(nxt);
+                    }
+                }
+            });
+            if constexpr (ST == 7 && MODE != MODE_LAST) {
+                read<(S + 1) % NSTAGE, 0, 9>(nxt);
+                if constexpr (MODE == MODE_ISSUE) issue(c + NSTAGE, S);
+            }
+            if constexpr (!(ST == 7 && MODE == MODE_LAST)) asm volatile("s_waitcnt lgkmcnt(0)");
+        });
+    }
+
+    // nk chunks (even, >= 2)
+    __device__ __forceinline__ void run(Acc& acc, int nk) {
+        static_for<0, 9>([&](auto t) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc.t[decltype(t)::value][r] = 0.f;
+            asm volatile("" : "+v"(acc.t[decltype(t)::value]));
+        });
+        issue(0, 0);
+        issue(1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(PER) : "memory");
+        static_for<0, 10>([&](auto r) { read<0, 0, decltype(r)::value>(F[0]); });
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        int c = 0;
+        for (; c + NSTAGE < nk; c += NSTAGE) {
+            chunk<0, MODE_ISSUE>(acc, c);
+            chunk<1, MODE_ISSUE>(acc, c + 1);
+        }
+        chunk<0, MODE_TAIL>(acc, c);
+        chunk<1, MODE_LAST>(acc, c + 1);
+        asm volatile("s_nop 15\n\ts_nop 3");
+    }
+};
+
+template <int CW>
+__global__ __launch_bounds__(THREADS, 2) void conv_wgrad_kernel(const WgradArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE_BYTES / 4];
+    // workgroup b runs on XCD b % 8 and takes a contiguous share of the (split, co block, ci block) list, split slowest: the
+    // workgroups that read the same pixels sit on one XCD's L2
+    const int total = g.splits * g.ncob * g.ncib;
+    const int per_xcd = (total + 7) >> 3;
+    const int lid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lid >= total) return;
+    const int blocks = g.ncob * g.ncib;
+    const int split = lid / blocks, blk = lid - split * blocks;
+    const int cob = blk / g.ncib, cib = blk - cob * g.ncib;
+    const int first = split * g.chunks_per_split;
+    const int nk = min(g.chunks_per_split, g.total_chunks - first);
+    using Core = WgradCore<CW>;
+    Core core(g, lds, cob, cib, first);
+    typename Core::Acc acc;
+    core.run(acc, nk);
+    const int half = core.lane >> 5, l31 = core.lane & 31;
+    const int wm = core.wave >> 1, wn = core.wave & 1;
+    float* out = g.partial + (size_t)split * g.Cout * 9 * g.Cin;
+    const int ci = cib * BC + wn * 32 + l31;
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = cob * BC + wm * 32 + scp::acc_row(r, half);
+            out[((size_t)co * 9 + tap) * g.Cin + ci] = acc.t[tap][r];
+        }
+}
+
+// dw = sum over splits (in split order) of the partial blocks; dbias (optional) is not produced here
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* __restrict__ partial, float* __restrict__ dw, int n4, int splits) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4* p = reinterpret_cast<const float4*>(partial) + i;
+    float4 s = p[0];
+    for (int k = 1; k < splits; k++) {
+        const float4 v = p[(size_t)k * n4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4*>(dw)[i] = s;
+}
+
+struct Plan { int splits, chunks_per_split, total_chunks, ncob, ncib, lgW, lgH; bool ok; };
+Plan make_plan(int N, int H, int W, int Cin, int Cout) {
+    Plan p{};
+    p.ok = false;
+    if (N <= 0 || H < 8 || W < 8 || (H & (H - 1)) || (W & (W - 1)) || Cin % BC || Cout % BC) return p;
+    while ((1 << p.lgW) < W) p.lgW++;
+    while ((1 << p.lgH) < H) p.lgH++;
+    const long M = (long)N * H * W;
+    p.total_chunks = (int)(M / CHUNK);
+    p.ncob = Cout / BC;
+    p.ncib = Cin / BC;
+    const int blocks = p.ncob * p.ncib;
+    // ~512 workgroups, every split an even number of chunks >= 4
+    int splits = (512 + blocks - 1) / blocks;
+    int cps = (p.total_chunks + splits - 1) / splits;
+    cps = (cps + 1) & ~1;
+    if (cps < 4) cps = 4;
+    if (p.total_chunks < 2 || (p.total_chunks & 1)) return p;
+    cps = cps < p.total_chunks ? cps : p.total_chunks;
+    p.chunks_per_split = cps;
+    p.splits = (p.total_chunks + cps - 1) / cps;
+    p.ok = true;
+    return p;
+}
+
+}  // namespace
+
+extern "C" size_t scp_conv_nhwc_weight_grad_workspace(int N, int H, int W, int Cin, int Cout, int ksize, int stride) {
+    if (ksize != 3 || stride != 1) return 0;
+    const Plan p = make_plan(N, H, W, Cin, Cout);
+    if (!p.ok) return 0;
+    return (size_t)p.splits * Cout * 9 * Cin * sizeof(float);
+}
+
+extern "C" int scp_conv_nhwc_weight_grad(const float* x, const float* dy, float* dw, float* dbias, void* workspace,
+                                         size_t workspace_bytes, int N, int H, int W, int Cin, int Cout, int ksize, int stride,
+                                         void* stream) {
+    if (!x || !dy || !dw || !workspace) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: null argument");
+    if (ksize != 3 || stride != 1) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: 3x3 / stride 1 only");
+    if (dbias) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: the bias gradient comes from scp_bias_leaky_relu_backward");
+    const Plan p = make_plan(N, H, W, Cin, Cout);
+    if (!p.ok) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: needs power-of-two H, W >= 8 and channel counts that are multiples of 64");
+    const size_t need = (size_t)p.splits * Cout * 9 * Cin * sizeof(float);
+    if (workspace_bytes < need) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: workspace too small");
+    const long in_bytes = (long)N * H * W * Cin * 4;
+    if (in_bytes >= (1l << 31) || (long)N * H * W * Cout * 4 >= (1l << 32)) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: tensor too large");
+    WgradArgs g{};
+    g.x = x; g.dy = dy; g.partial = static_cast<float*>(workspace);
+    g.lgW = p.lgW; g.lgH = p.lgH; g.Cin = Cin; g.Cout = Cout;
+    g.ncob = p.ncob; g.ncib = p.ncib; g.splits = p.splits; g.chunks_per_split = p.chunks_per_split; g.total_chunks = p.total_chunks;
+    g.x_bytes = (unsigned)in_bytes;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int total = p.splits * p.ncob * p.ncib;
+    const dim3 grid(((total + 7) >> 3) << 3);
+    if (W >= 16) hipLaunchKernelGGL(conv_wgrad_kernel<16>, grid, dim3(THREADS), 0, st, g);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<8>, grid, dim3(THREADS), 0, st, g);
+    const int n4 = Cout * 9 * Cin / 4;
+    hipLaunchKernelGGL(wgrad_fold_kernel, dim3((n4 + 255) / 256), dim3(256), 0, st, static_cast<const float*>(workspace), dw, n4, p.splits);
+    return scp::check_launch("conv_weight_grad");
+}

