@@ -272,7 +272,7 @@ int scp_batchnorm_act_backward_bf16(const void* dy, const void* x, const void* y
  *   x [N,H,W,Cin], w [Cout,k,k,Cin] (= the channels_last storage of a [Cout,Cin,k,k] tensor), padding k/2,
  *   y [N,Ho,Wo,Cout] with Ho = (H + 2 (k/2) - k) / stride + 1.
  *   leaky != 0: y = leaky_relu(conv + bias[Cout], slope) (the decoder's conv unit); else the raw convolution (bias ignored).
- *   partials (or NULL): [tiles_m][2][Cout] per-tile column sums of the RAW output and of its squares over the tile's
+ *   partials (or NULL): [2][tiles_m][Cout] per-tile column sums of the RAW output, then of its squares, over the tile's
  *   rows_per_tile output pixels (scp_conv_nhwc_partial_rows gives both numbers) -- the BatchNorm that follows folds them into
  *   its batch statistics instead of re-reading y (scp_batchnorm_act_forward_partials).
  * The input gradient of a stride-1 convolution is the same call with dy as x, Cin <-> Cout and w transposed + flipped
@@ -284,6 +284,18 @@ int scp_batchnorm_act_backward_bf16(const void* dy, const void* x, const void* y
 int scp_conv_nhwc_forward(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int H, int W,
                           int Cin, int Cout, int ksize, int stride, int leaky, float slope, void* stream);
 int scp_conv_nhwc_partial_rows(int N, int H, int W, int Cout, int ksize, int stride, int* tiles_m, int* rows_per_tile);
+/* convolution (no bias) + the batch statistics of the nn.BatchNorm2d that follows it (training mode), one launch: the per-tile
+ * partial sums go to `workspace` (>= 2 * tiles_m * Cout floats), the last workgroup of the launch (ticket: a zeroed device word,
+ * re-armed by the kernel) folds them in fp64 in tile order and writes save_mean / save_invstd / save_scale (= gamma invstd) /
+ * save_shift (= beta - mean scale) [Cout] and the running-statistics update exactly as scp_batchnorm_act_forward does.
+ * scp_batchnorm_apply then produces relu(y scale + shift [+ skip]); scp_batchnorm_act_backward takes the saved statistics. */
+int scp_conv_nhwc_forward_bn(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride,
+                             const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             long long* batches_tracked, float momentum, float eps, float* save_mean, float* save_invstd,
+                             float* save_scale, float* save_shift, void* workspace, size_t workspace_bytes, unsigned* ticket,
+                             void* stream);
+int scp_batchnorm_apply(const float* x, const float* skip, const float* scale, const float* shift, long R, int C, int relu, float* y,
+                        void* stream);
 size_t scp_conv_nhwc_weight_grad_workspace(int N, int H, int W, int Cin, int Cout, int ksize, int stride);
 int scp_conv_nhwc_weight_grad(const float* x, const float* dy, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
                               int N, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);

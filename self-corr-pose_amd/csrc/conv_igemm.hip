@@ -23,6 +23,7 @@
 // tools/probes/gemm_v3.hip); algorithmic flops 2 M Cout taps Cin; algorithmic bytes 4 (M_in Cin + taps Cin Cout + M Cout).
 #include <hip/hip_runtime.h>
 
+#include "bn_common.h"
 #include "gemm_core.h"
 #include "scp_common.h"
 #include "scp_hip.h"
@@ -36,7 +37,9 @@ struct ConvArgs {
     const float* w;        // [Cout, taps, Cin]
     const float* bias;     // [Cout] or nullptr
     float* y;              // [N, Ho, Wo, Cout]
-    float* partials;       // [tiles_m][2][Cout] or nullptr
+    float* partials;       // [2][tiles_m][Cout] (sums, then sums of squares) or nullptr
+    unsigned* ticket;      // with partials: the last workgroup folds them and finalises the BatchNorm statistics (fin)
+    scp_bn::FwdFinalize fin;
     int H, W, Ho, Wo, Cin, Cout, M, K;
     int stride, lg_cpt;    // chunks per tap = Cin / 16 = 1 << lg_cpt
     int nblk_n, tiles_m;
@@ -114,6 +117,20 @@ struct ConvSource {
 
 enum { EPI_RAW = 0, EPI_BIAS_LEAKY = 1 };
 
+// last workgroup of a launch: per-tile column sums -> batch statistics of the BatchNorm that follows (fp64 fold in tile order)
+__device__ __forceinline__ void finalize_statistics(const ConvArgs& g, float* lds) {
+    if (threadIdx.x == 0 && g.fin.batches_tracked) *g.fin.batches_tracked += 1;
+    const int tc_n = g.Cout / 4;
+    double sa[4], sb[4];
+    __syncthreads();
+    if (!scp_bn::fold_partials(g.partials, g.partials + (size_t)g.tiles_m * g.Cout, g.tiles_m, g.Cout, tc_n, sa, sb,
+                               reinterpret_cast<float4*>(lds)))
+        return;
+    const int tc = threadIdx.x % tc_n;
+#pragma unroll
+    for (int i = 0; i < 4; i++) scp_bn::finalize_channel(g.fin, 4 * tc + i, true, sa[i], sb[i]);
+}
+
 template <class CFG, int TAPS, int EPI, bool STATS>
 __global__ __launch_bounds__(CFG::THREADS, 2) void conv_igemm_kernel(const ConvArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[CFG::LDS_BYTES / 4];
@@ -122,7 +139,11 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void conv_igemm_kernel(const ConvA
     const int total = g.tiles_m * g.nblk_n;
     const int per_xcd = (total + 7) >> 3;
     const int lid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (lid >= total) return;
+    if (lid >= total) {
+        // a padding workgroup still takes its ticket (the last arrival is counted over the whole grid); it can be the last
+        if (STATS && g.ticket && scp_bn::last_block_arrived(g.ticket)) finalize_statistics(g, lds);
+        return;
+    }
     const int bm = lid / g.nblk_n, bn = lid - bm * g.nblk_n;
     const int m0 = bm * CFG::BM, n0 = bn * CFG::BN;
     Core core(lds);
@@ -183,8 +204,11 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void conv_igemm_kernel(const ConvA
 #pragma unroll
             for (int wm = 0; wm < CFG::NWM; wm++) s += red[(((wm * CFG::NWN + wn) * CFG::WN + j) * 2 + which) * 32 + l];
             const int n = n0 + col;
-            if (n < g.Cout) g.partials[((size_t)bm * 2 + which) * g.Cout + n] = s;
+            // write-through (visible to the folding workgroup on another XCD once complete; csrc/bn_common.h)
+            if (n < g.Cout)
+                __hip_atomic_store(g.partials + ((size_t)which * g.tiles_m + bm) * g.Cout + n, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (g.ticket && scp_bn::last_block_arrived(g.ticket)) finalize_statistics(g, lds);
     }
 }
 
@@ -227,17 +251,20 @@ extern "C" int scp_conv_nhwc_partial_rows(int N, int H, int W, int Cout, int ksi
     return 0;
 }
 
-extern "C" int scp_conv_nhwc_forward(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int H, int W,
-                                     int Cin, int Cout, int ksize, int stride, int leaky, float slope, void* stream) {
+namespace {
+int conv_forward_impl(const float* x, const float* w, const float* bias, float* y, float* partials, unsigned* ticket,
+                      const scp_bn::FwdFinalize* fin, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int leaky,
+                      float slope, void* stream) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return scp::fail(hipErrorInvalidValue, "conv_nhwc: empty problem");
     if (!x || !w || !y || (leaky && !bias)) return scp::fail(hipErrorInvalidValue, "conv_nhwc: null argument");
     if (ksize != 1 && ksize != 3) return scp::fail(hipErrorInvalidValue, "conv_nhwc: kernel size must be 1 or 3");
     if (stride != 1 && stride != 2) return scp::fail(hipErrorInvalidValue, "conv_nhwc: stride must be 1 or 2");
     const int cpt = Cin / 16;
     if (Cin % 32 != 0 || (cpt & (cpt - 1))) return scp::fail(hipErrorInvalidValue, "conv_nhwc: Cin must be a power of two >= 32");
+    if (fin && (Cout < 16 || Cout > 1024 || (Cout & (Cout - 1)))) return scp::fail(hipErrorInvalidValue, "conv_nhwc: BatchNorm statistics need a power-of-two Cout in [16,1024]");
     const int pad = ksize / 2;
     ConvArgs g{};
-    g.x = x; g.w = w; g.bias = bias; g.y = y; g.partials = partials;
+    g.x = x; g.w = w; g.bias = bias; g.y = y; g.partials = partials; g.ticket = ticket;
     g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.stride = stride; g.slope = slope;
     g.Ho = (H + 2 * pad - ksize) / stride + 1;
     g.Wo = (W + 2 * pad - ksize) / stride + 1;
@@ -249,6 +276,10 @@ extern "C" int scp_conv_nhwc_forward(const float* x, const float* w, const float
     g.x_bytes = (unsigned)in_bytes;
     g.lg_cpt = 0;
     while ((1 << g.lg_cpt) < cpt) g.lg_cpt++;
+    if (fin) {
+        g.fin = *fin;
+        g.fin.R = M;
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int cfg = pick_cfg(M, Cout);
     const bool stats = partials != nullptr;
@@ -262,4 +293,25 @@ extern "C" int scp_conv_nhwc_forward(const float* x, const float* w, const float
         else launch_cfg<Cfg64x64, 1>(g, leaky, stats, st);
     }
     return scp::check_launch("conv_nhwc_forward");
+}
+}  // namespace
+
+extern "C" int scp_conv_nhwc_forward(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int H, int W,
+                                     int Cin, int Cout, int ksize, int stride, int leaky, float slope, void* stream) {
+    return conv_forward_impl(x, w, bias, y, partials, nullptr, nullptr, N, H, W, Cin, Cout, ksize, stride, leaky, slope, stream);
+}
+
+extern "C" int scp_conv_nhwc_forward_bn(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int ksize,
+                                        int stride, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                        long long* batches_tracked, float momentum, float eps, float* save_mean, float* save_invstd,
+                                        float* save_scale, float* save_shift, void* workspace, size_t workspace_bytes, unsigned* ticket,
+                                        void* stream) {
+    if (!save_mean || !save_invstd || !save_scale || !save_shift || !workspace || !ticket)
+        return scp::fail(hipErrorInvalidValue, "conv_nhwc_forward_bn: null argument");
+    int tiles_m = 0;
+    scp_conv_nhwc_partial_rows(N, H, W, Cout, ksize, stride, &tiles_m, nullptr);
+    if (workspace_bytes < (size_t)2 * tiles_m * Cout * sizeof(float)) return scp::fail(hipErrorInvalidValue, "conv_nhwc_forward_bn: workspace too small");
+    const scp_bn::FwdFinalize fin{0, gamma, beta, running_mean, running_var, batches_tracked, momentum, eps, save_mean, save_invstd,
+                                  save_scale, save_shift};
+    return conv_forward_impl(x, w, nullptr, y, static_cast<float*>(workspace), ticket, &fin, N, H, W, Cin, Cout, ksize, stride, 0, 0.f, stream);
 }

@@ -217,17 +217,32 @@ __global__ __launch_bounds__(THREADS, 2) void conv_wgrad_kernel(const WgradArgs 
         }
 }
 
-// dw = sum over splits (in split order) of the partial blocks; dbias (optional) is not produced here
+// dw = sum over splits of the partial blocks, in a FIXED order (deterministic): a workgroup = 16 output float4s x 16 split lanes;
+// lane j adds splits j, j + 16, ... in increasing order, the 16 lane sums are then added in lane order.  (One thread per output
+// walking all splits was latency-bound for the 64-channel layers: 9216 threads x 512 dependent-address loads, ~100 us.)
 __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* __restrict__ partial, float* __restrict__ dw, int n4, int splits) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    const float4* p = reinterpret_cast<const float4*>(partial) + i;
-    float4 s = p[0];
-    for (int k = 1; k < splits; k++) {
-        const float4 v = p[(size_t)k * n4];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    __shared__ float4 red[16][17];
+    const int o = threadIdx.x & 15, j = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + o;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+        const float4* p = reinterpret_cast<const float4*>(partial) + i;
+        for (int k = j; k < splits; k += 16) {
+            const float4 v = p[(size_t)k * n4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
-    reinterpret_cast<float4*>(dw)[i] = s;
+    red[j][o] = s;
+    __syncthreads();
+    if (j == 0 && i < n4) {
+        float4 t = red[0][o];
+#pragma unroll
+        for (int k = 1; k < 16; k++) {
+            const float4 v = red[k][o];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        reinterpret_cast<float4*>(dw)[i] = t;
+    }
 }
 
 struct Plan { int splits, chunks_per_split, total_chunks, ncob, ncib, lgW, lgH; bool ok; };
@@ -287,6 +302,6 @@ extern "C" int scp_conv_nhwc_weight_grad(const float* x, const float* dy, float*
     if (W >= 16) hipLaunchKernelGGL(conv_wgrad_kernel<16>, grid, dim3(THREADS), 0, st, g);
     else hipLaunchKernelGGL(conv_wgrad_kernel<8>, grid, dim3(THREADS), 0, st, g);
     const int n4 = Cout * 9 * Cin / 4;
-    hipLaunchKernelGGL(wgrad_fold_kernel, dim3((n4 + 255) / 256), dim3(256), 0, st, static_cast<const float*>(workspace), dw, n4, p.splits);
+    hipLaunchKernelGGL(wgrad_fold_kernel, dim3((n4 + 15) / 16), dim3(256), 0, st, static_cast<const float*>(workspace), dw, n4, p.splits);
     return scp::check_launch("conv_weight_grad");
 }

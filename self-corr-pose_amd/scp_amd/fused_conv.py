@@ -1,0 +1,211 @@
+"""scp_amd/fused_conv.py -- the image encoder's convolutions on the build's own implicit-GEMM kernels (csrc/conv_igemm.hip,
+csrc/conv_wgrad.hip), fused with what follows them.
+
+`conv_bn_act(x, conv, bn, skip=None, relu=False)` == `relu(bn(conv(x)) + skip)`: torchvision's BasicBlock as used by
+model/module/network/image_encoder.py:119-139.  ONE autograd op:
+  forward : convolution whose epilogue leaves the per-tile column sums and whose last workgroup finalises the batch statistics
+            (no statistics pass over the activation), then one apply pass (scale, shift [, + skip] [, ReLU]);
+  backward: the BatchNorm(+ReLU) backward of csrc/batchnorm.hip, then the input gradient (the forward kernel on flipped /
+            transposed weights) and the weight gradient (halo-block kernel, deterministic).
+`conv_bias_leaky(x, conv, slope, stride)` == `leaky_relu(conv(x) + bias)`: the decoder's conv unit
+(net_blocks.py:336-359 with_bn=False); bias and activation live in the convolution's epilogue.
+
+What the own kernels do not cover goes to MIOpen through ATen, layer by layer and direction by direction, never silently for a
+whole network: the 7x7 stem (Cin = 3), the backward of the three stride-2 3x3 layers and of the 1x1 stride-2 projections
+(`aten.convolution_backward`).  CPU tensors, eval-mode BatchNorm, SyncBatchNorm and non-fp32 activations (configs[4] bf16
+autocast) take the stock composition, which is also what the tests compare with."""
+import ctypes
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import capi
+
+
+def _nhwc(t):
+    return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _pow2(v):
+    return v > 0 and (v & (v - 1)) == 0
+
+
+def own_forward_ok(x, weight, stride):
+    """shapes scp_conv_nhwc_forward covers: 3x3 / 1x1, stride 1 / 2, Cin a power of two >= 32"""
+    k = weight.shape[2]
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and k == weight.shape[3]
+            and k in (1, 3) and stride in (1, 2) and weight.shape[1] >= 32 and _pow2(weight.shape[1]))
+
+
+def _own_dgrad_ok(weight, stride):
+    cout, k = weight.shape[0], weight.shape[2]
+    return stride == 1 and cout >= 32 and _pow2(cout)
+
+
+def _own_wgrad_ok(x_shape, weight, stride):
+    n, cin, h, w = x_shape
+    return (stride == 1 and weight.shape[2] == 3 and h >= 8 and w >= 8 and _pow2(h) and _pow2(w) and cin % 64 == 0
+            and weight.shape[0] % 64 == 0 and (n * h * w) % 32 == 0)
+
+
+def _conv_out_shape(x, weight, stride):
+    n, _, h, w = x.shape
+    k = weight.shape[2]
+    return n, weight.shape[0], (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
+
+
+def _conv_forward(x, weight, bias, stride, leaky, slope):
+    """raw own forward: x, weight channels_last; returns a channels_last tensor"""
+    L = capi.lib()
+    n, cin, h, w = x.shape
+    cout, k = weight.shape[0], weight.shape[2]
+    y = torch.empty(_conv_out_shape(x, weight, stride), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    capi.check(L.scp_conv_nhwc_forward(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), _ptr(None), n, h, w, cin, cout, k, stride,
+                                       int(leaky), float(slope), capi.current_stream()), "conv_nhwc_forward")
+    return y
+
+
+def _conv_backward(x, weight, g, stride, need_dx, need_dw):
+    """(dx, dw) of y = conv(x, weight) for the output gradient g; all channels_last.  Own kernels where they apply."""
+    L = capi.lib()
+    n, cin, h, w = x.shape
+    cout, k = weight.shape[0], weight.shape[2]
+    dx = dw = None
+    own_dx = need_dx and _own_dgrad_ok(weight, stride)
+    own_dw = need_dw and _own_wgrad_ok(x.shape, weight, stride)
+    if own_dx:
+        # the forward kernel on dy with the weights as [Cin, k, k, Cout], taps flipped
+        wt = weight.flip(2, 3).permute(1, 2, 3, 0).contiguous()
+        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        capi.check(L.scp_conv_nhwc_forward(_ptr(g), _ptr(wt), _ptr(None), _ptr(dx), _ptr(None), n, h, w, cout, cin, k, 1, 0, 0.0,
+                                           capi.current_stream()), "conv_nhwc_forward (input gradient)")
+    if own_dw:
+        ws_bytes = L.scp_conv_nhwc_weight_grad_workspace(n, h, w, cin, cout, 3, 1)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+        dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        capi.check(L.scp_conv_nhwc_weight_grad(_ptr(x), _ptr(g), _ptr(dw), _ptr(None), _ptr(ws), ws_bytes, n, h, w, cin, cout, 3, 1,
+                                               capi.current_stream()), "conv_nhwc_weight_grad")
+    miss_dx, miss_dw = need_dx and not own_dx, need_dw and not own_dw
+    if miss_dx or miss_dw:
+        p = weight.shape[2] // 2
+        rdx, rdw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, [stride, stride], [p, p], [1, 1], False, [0, 0], 1,
+                                                          [miss_dx, miss_dw, False])
+        if miss_dx:
+            dx = rdx
+        if miss_dw:
+            dw = rdw
+    return dx, dw
+
+
+class _ConvBNAct(Function):
+    @staticmethod
+    def forward(ctx, x, weight, skip, gamma, beta, bn, relu, stride):
+        L = capi.lib()
+        x, weight = _nhwc(x), _nhwc(weight)
+        n, cin, h, w = x.shape
+        cout, k = weight.shape[0], weight.shape[2]
+        conv = torch.empty(_conv_out_shape(x, weight, stride), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        rows = conv.shape[0] * conv.shape[2] * conv.shape[3]
+        stats = torch.empty(4, cout, dtype=torch.float32, device=x.device)
+        tiles = ctypes.c_int()
+        L.scp_conv_nhwc_partial_rows(n, h, w, cout, k, stride, ctypes.byref(tiles), None)
+        ws = torch.empty(2 * tiles.value * cout, dtype=torch.float32, device=x.device)
+        momentum = 0.1 if bn.momentum is None else bn.momentum
+        capi.check(L.scp_conv_nhwc_forward_bn(
+            _ptr(x), _ptr(weight), _ptr(conv), n, h, w, cin, cout, k, stride, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean),
+            _ptr(bn.running_var), _ptr(bn.num_batches_tracked if bn.track_running_stats else None), float(momentum), float(bn.eps),
+            _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(ws), ws.numel() * 4, capi.ticket(x.device),
+            capi.current_stream()), "conv_nhwc_forward_bn")
+        if skip is not None:
+            skip = _nhwc(skip)
+        y = torch.empty_like(conv)
+        capi.check(L.scp_batchnorm_apply(_ptr(conv), _ptr(skip), _ptr(stats[2]), _ptr(stats[3]), rows, cout, int(relu), _ptr(y),
+                                         capi.current_stream()), "batchnorm_apply")
+        residual_relu = relu and skip is not None
+        ctx.save_for_backward(x, weight, conv, y if residual_relu else None, stats)
+        ctx.cfg = (rows, cout, bool(relu), skip is not None, gamma is not None, beta is not None, stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = capi.lib()
+        x, weight, conv, y, stats = ctx.saved_tensors
+        rows, c, relu, has_skip, has_w, has_b, stride = ctx.cfg
+        dy = _nhwc(dy)
+        dconv = torch.empty_like(conv)
+        dskip = torch.empty_like(conv) if (relu and has_skip) else None
+        want_g = has_w and ctx.needs_input_grad[3]
+        want_b = has_b and ctx.needs_input_grad[4]
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device) if want_g else None
+        dbeta = torch.empty(c, dtype=torch.float32, device=x.device) if want_b else None
+        ws_bytes = L.scp_batchnorm_workspace(rows, c)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+        capi.check(L.scp_batchnorm_act_backward(
+            _ptr(dy), _ptr(conv), _ptr(y), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), rows, c, int(relu),
+            int(has_skip), 1, _ptr(dconv), _ptr(dskip), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws_bytes, capi.ticket(x.device),
+            capi.current_stream()), "batchnorm_act_backward")
+        if has_skip and dskip is None:
+            dskip = dy
+        dx, dw = _conv_backward(x, weight, dconv, stride, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, dw, (dskip if has_skip else None), dgamma, dbeta, None, None, None
+
+
+class _ConvBiasLeaky(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, slope, stride):
+        x, weight = _nhwc(x), _nhwc(weight)
+        y = _conv_forward(x, weight, bias, stride, True, slope)
+        ctx.save_for_backward(x, weight, y)
+        ctx.cfg = (float(slope), stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = capi.lib()
+        x, weight, y = ctx.saved_tensors
+        slope, stride = ctx.cfg
+        dy = _nhwc(dy)
+        n, c, h, w = y.shape
+        rows = n * h * w
+        g = torch.empty_like(y)
+        dbias = torch.empty(c, dtype=torch.float32, device=y.device) if ctx.needs_input_grad[2] else None
+        ws_bytes = L.scp_batchnorm_workspace(rows, c)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=y.device)
+        # gradient of the pre-activation (mask from the sign of the output: slope > 0 keeps it) + bias gradient, one pass
+        capi.check(L.scp_bias_leaky_relu_backward(_ptr(dy), _ptr(y), slope, rows, c, _ptr(g), _ptr(dbias), _ptr(ws), ws_bytes,
+                                                  capi.ticket(y.device), capi.current_stream()), "bias_leaky_relu_backward")
+        dx, dw = _conv_backward(x, weight, g, stride, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, dw, dbias, None, None
+
+
+def _fused_ok(x, conv, stride):
+    return (own_forward_ok(x, conv.weight, stride) and conv.groups == 1 and conv.dilation == (1, 1)
+            and conv.padding == (conv.kernel_size[0] // 2, conv.kernel_size[0] // 2) and x.shape[1] == conv.weight.shape[1])
+
+
+def conv_bn_act(x, conv, bn, skip=None, relu=False):
+    """relu(bn(conv(x)) + skip) with nn.Conv2d (no bias) / nn.BatchNorm2d semantics"""
+    from .fused_bn import bn_act
+    stride = conv.stride[0]
+    c = conv.weight.shape[0]
+    if (conv.bias is None and _fused_ok(x, conv, stride) and type(bn) is nn.BatchNorm2d and (bn.training or bn.running_mean is None)
+            and 16 <= c <= 1024 and _pow2(c) and (skip is None or skip.dtype == torch.float32) and not torch.is_autocast_enabled()):
+        return _ConvBNAct.apply(x, conv.weight, skip, bn.weight, bn.bias, bn, relu, stride)
+    return bn_act(conv(x), bn, skip=skip, relu=relu)
+
+
+def conv_bias_leaky(x, conv, slope=0.1, stride=None):
+    """leaky_relu(conv(x), slope) for an nn.Conv2d with bias (stride override: the same weights as a strided convolution)"""
+    from . import fused_bn
+    stride = conv.stride[0] if stride is None else stride
+    c = conv.weight.shape[0]
+    if (conv.bias is not None and _fused_ok(x, conv, stride) and 16 <= c <= 1024 and _pow2(c) and slope > 0
+            and not torch.is_autocast_enabled()):
+        return _ConvBiasLeaky.apply(x, conv.weight, conv.bias, slope, stride)
+    return fused_bn.conv_bias_leaky(x, conv, slope, stride)

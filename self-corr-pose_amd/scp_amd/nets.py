@@ -1,5 +1,6 @@
-"""scp_amd/nets.py -- the small stock-PyTorch networks around the hot path (north_star leaves them on
-PyTorch-ROCm / MIOpen).  Module and parameter NAMES follow the reference so that its checkpoints
+"""scp_amd/nets.py -- the networks around the hot path.  The image encoder's 3x3 / 1x1 convolutions, BatchNorms and
+activations run on the build's own kernels (scp_amd/fused_conv.py, scp_amd/fused_bn.py); the small heads stay
+stock PyTorch.  Module and parameter NAMES follow the reference so that its checkpoints
 load and its optimiser's name-based parameter groups (optimizers.py:16-35) keep working.
 
 Restated from (reference file:line):
@@ -16,7 +17,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused_bn import bn_act, conv_bias_leaky, maxpool3x3s2
+from .fused_bn import bn_act, maxpool3x3s2
+from .fused_conv import conv_bias_leaky, conv_bn_act
 
 
 # ------------------------------------------------------------------------------------------------
@@ -35,9 +37,11 @@ class _BasicBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
     def forward(self, x):
-        skip = x if self.downsample is None else bn_act(self.downsample[0](x), self.downsample[1])
-        y = bn_act(self.conv1(x), self.bn1, relu=True)
-        return bn_act(self.conv2(y), self.bn2, skip=skip, relu=True)
+        # convolution + BatchNorm (+ skip) (+ ReLU) as one op on the own kernels (scp_amd/fused_conv.py); CPU / eval / bf16 take
+        # the stock composition inside
+        skip = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1])
+        y = conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        return conv_bn_act(y, self.conv2, self.bn2, skip=skip, relu=True)
 
 
 class ResNet18Trunk(nn.Module):
@@ -114,7 +118,7 @@ class _ConvUnit(nn.Module):
         """stride 2: only every other output pixel is wanted -- the same weights as a strided convolution"""
         conv = self.cbr_unit[0]
         if x.is_cuda:
-            return conv_bias_leaky(x, conv, 0.1, stride)       # bias + LeakyReLU fused (csrc/batchnorm.hip)
+            return conv_bias_leaky(x, conv, 0.1, stride)       # own convolution, bias + LeakyReLU in its epilogue (scp_amd/fused_conv.py)
         if stride == 1:
             return self.cbr_unit(x)
         return F.leaky_relu(F.conv2d(x, conv.weight, conv.bias, stride, 1), 0.1)

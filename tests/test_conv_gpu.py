@@ -29,7 +29,7 @@ def _conv(x_nhwc, w_khwc, bias=None, stride=1, leaky=False, slope=0.1, partials=
     if partials:
         tm, rows = ctypes.c_int(), ctypes.c_int()
         L.scp_conv_nhwc_partial_rows(n, h, w, cout, k, stride, ctypes.byref(tm), ctypes.byref(rows))
-        part = torch.full((tm.value, 2, cout), float("nan"), device="cuda")
+        part = torch.full((2, tm.value, cout), float("nan"), device="cuda")
     capi.check(L.scp_conv_nhwc_forward(P(x_nhwc), P(w_khwc), P(bias), P(y), P(part), n, h, w, cin, cout, k, stride, int(leaky), slope,
                                        capi.current_stream()), "conv_nhwc_forward")
     return (y, part, rows.value) if partials else y
@@ -75,9 +75,9 @@ def test_conv_epilogues(n, cin, cout, h, w):
     flat = raw64.reshape(-1, cout)
     pad = (-flat.shape[0]) % rows
     tiles = torch.cat((flat, flat.new_zeros(pad, cout))).reshape(-1, rows, cout)
-    assert part.shape[0] == tiles.shape[0] and torch.isfinite(part).all()
-    torch.testing.assert_close(part[:, 0].double(), tiles.sum(1), rtol=1e-4, atol=1e-4 * float(flat.abs().max()) * rows ** 0.5)
-    torch.testing.assert_close(part[:, 1].double(), (tiles * tiles).sum(1), rtol=1e-4, atol=1e-4 * float(flat.abs().max()) ** 2 * rows ** 0.5)
+    assert part.shape[1] == tiles.shape[0] and torch.isfinite(part).all()
+    torch.testing.assert_close(part[0].double(), tiles.sum(1), rtol=1e-4, atol=1e-4 * float(flat.abs().max()) * rows ** 0.5)
+    torch.testing.assert_close(part[1].double(), (tiles * tiles).sum(1), rtol=1e-4, atol=1e-4 * float(flat.abs().max()) ** 2 * rows ** 0.5)
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 16, 16), (2, 128, 64, 32, 16), (4, 64, 128, 8, 8), (3, 128, 128, 8, 8),

@@ -216,7 +216,11 @@ def test_conv_bias_leaky_matches_the_stock_composition(shape, stride):
     x64 = x.detach().double().requires_grad_(True)
     c64 = torch.nn.Conv2d(c, 64, 3, 1, 1).cuda().double()
     c64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
-    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x64, c64.weight, c64.bias, stride, 1), 0.1)
+    pre = torch.nn.functional.conv2d(x64, c64.weight, c64.bias, stride, 1)
+    assert (y.double() - torch.nn.functional.leaky_relu(pre, 0.1)).abs().max().item() <= 2e-5 * max(pre.abs().max().item(), 1.0)
+    # gradients: the reference takes the fp32 run's branch of the activation (an output within rounding of zero flips between
+    # the precisions and moves single gradient elements by O(1))
+    ref = torch.where(y.detach() > 0, pre, 0.1 * pre)
     rx, rw, rb = torch.autograd.grad(ref, (x64, c64.weight, c64.bias), dy.double())
     for name, a, b in (("y", y, ref), ("dx", gx, rx), ("dw", gw, rw), ("db", gb, rb)):
         err = (a.double() - b).abs().max().item()

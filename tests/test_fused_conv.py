@@ -1,0 +1,146 @@
+"""scp_amd/fused_conv.py on the GPU: convolution + BatchNorm (+ skip) (+ ReLU) and convolution + bias + LeakyReLU as single
+autograd ops on the own implicit-GEMM kernels, against the stock torch composition in float64 (values, input / weight / affine
+gradients, running statistics), and the whole image encoder against itself with the fused path switched off."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "self-corr-pose_amd"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, tol, what):
+    err = (got.double() - ref).abs().max().item()
+    scale = max(ref.abs().max().item(), 1e-6)
+    assert err <= tol * scale, "%s: max err %.3e of scale %.3e" % (what, err, scale)
+
+
+def _close_grad(got, ref, tol, what):
+    """gradients behind a ReLU: an output within rounding of zero takes the other branch in float64 and moves a handful of
+    elements by O(1) -- judged in relative L2 and by the fraction of elements beyond the max-abs tolerance"""
+    d = (got.double() - ref).abs()
+    scale = max(ref.abs().max().item(), 1e-6)
+    rel = (d.square().sum().sqrt() / ref.square().sum().sqrt().clamp_min(1e-30)).item()
+    frac = (d > tol * scale).double().mean().item()
+    assert rel <= 4 * tol and frac <= 1e-4, "%s: rel L2 %.3e, %.2e of the elements beyond %.1e of scale" % (what, rel, frac, tol)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,k,stride,skip,relu", [
+    (4, 64, 64, 16, 3, 1, False, True), (4, 64, 64, 16, 3, 1, True, True), (2, 64, 128, 16, 3, 2, False, True),
+    (2, 64, 128, 16, 1, 2, False, False), (2, 128, 128, 8, 3, 1, True, True), (2, 256, 512, 8, 3, 2, False, True),
+    (32, 64, 64, 64, 3, 1, True, True)])
+def test_conv_bn_act_vs_float64(n, cin, cout, h, k, stride, skip, relu):
+    from scp_amd import fused_conv
+    g = torch.Generator().manual_seed(n + cin + cout + k)
+    conv = nn.Conv2d(cin, cout, k, stride, k // 2, bias=False).cuda().to(memory_format=torch.channels_last)
+    bn = nn.BatchNorm2d(cout).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * torch.randn(cout, generator=g))
+        bn.bias.copy_(0.3 * torch.randn(cout, generator=g))
+    x = torch.randn(n, cin, h, h, generator=g).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ho = (h + 2 * (k // 2) - k) // stride + 1
+    sk = torch.randn(n, cout, ho, ho, generator=g).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True) if skip else None
+    dy = torch.randn(n, cout, ho, ho, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    # float64 reference
+    conv64, bn64 = nn.Conv2d(cin, cout, k, stride, k // 2, bias=False).cuda().double(), nn.BatchNorm2d(cout).cuda().double()
+    conv64.weight.data.copy_(conv.weight.double())
+    bn64.weight.data.copy_(bn.weight.double()); bn64.bias.data.copy_(bn.bias.double())
+    x64 = x.detach().double().requires_grad_(True)
+    sk64 = sk.detach().double().requires_grad_(True) if skip else None
+    y = fused_conv.conv_bn_act(x, conv, bn, skip=sk, relu=relu)
+    assert y.grad_fn is not None and "ConvBNAct" in type(y.grad_fn).__name__, "the fused op must be the one that runs"
+    y.backward(dy)
+    r = bn64(conv64(x64))
+    if skip:
+        r = r + sk64
+    if relu:
+        _close(y, F.relu(r), 2e-5, "output")
+        # the reference's ReLU takes the fp32 run's branch: an output within rounding of zero would otherwise flip between the
+        # two precisions and move a handful of gradient elements by O(1), which says nothing about the kernels
+        r = r * (y.detach() > 0).double()
+    r.backward(dy.double())
+    _close(y, r, 2e-5, "output")
+    _close_grad(x.grad, x64.grad, 5e-5, "dx")
+    _close_grad(conv.weight.grad, conv64.weight.grad, 5e-5, "dw")
+    _close_grad(bn.weight.grad, bn64.weight.grad, 5e-5, "dgamma")
+    _close_grad(bn.bias.grad, bn64.bias.grad, 5e-5, "dbeta")
+    if skip:
+        _close_grad(sk.grad, sk64.grad, 5e-5, "dskip")
+    _close(bn.running_mean, bn64.running_mean, 1e-5, "running_mean")
+    _close(bn.running_var, bn64.running_var, 1e-5, "running_var")
+    assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("n,cin,cout,h,stride", [(2, 128, 64, 16, 1), (2, 512, 256, 8, 1), (2, 128, 64, 16, 2), (32, 128, 64, 64, 1)])
+def test_conv_bias_leaky_vs_float64(n, cin, cout, h, stride):
+    from scp_amd import fused_conv
+    g = torch.Generator().manual_seed(n + cin + cout + stride)
+    conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=True).cuda().to(memory_format=torch.channels_last)
+    x = torch.randn(n, cin, h, h, generator=g).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x64 = x.detach().double().requires_grad_(True)
+    w64, b64 = conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+    y = fused_conv.conv_bias_leaky(x, conv, 0.1, stride)
+    assert "ConvBiasLeaky" in type(y.grad_fn).__name__
+    pre = F.conv2d(x64, w64, b64, stride, 1)
+    _close(y, F.leaky_relu(pre, 0.1), 2e-5, "output")
+    r = torch.where(y.detach() > 0, pre, 0.1 * pre)          # the fp32 run's branch (see test_conv_bn_act_vs_float64)
+    dy = torch.randn(r.shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    r.backward(dy.double())
+    y.backward(dy)
+    _close_grad(x.grad, x64.grad, 5e-5, "dx")
+    _close_grad(conv.weight.grad, w64.grad, 5e-5, "dw")
+    _close_grad(conv.bias.grad, b64.grad, 5e-5, "dbias")
+
+
+def test_encoder_with_own_convolutions_is_as_accurate_as_the_stock_path(monkeypatch):
+    """the whole image encoder (ResNet18 trunk + U-decoder, B = 4, 256 x 256), forward features and the gradient of every
+    parameter, three ways on the same weights: (a) own convolutions with fused BatchNorm statistics, (b) the MIOpen +
+    separate-BatchNorm composition in fp32, (c) the stock composition in float64.  Two fp32 evaluations of a 20-layer ReLU
+    network differ by the rounding of their summation orders (and by ReLU outputs within rounding of zero taking different
+    branches), so (a) is not asserted against (b) but against (c): its deviation may not exceed 1.5 x that of (b) plus a floor."""
+    import scp_amd.dino as dino
+    from scp_amd import fused_conv
+    from scp_amd.flags import Options
+    from scp_amd.encoder import Encoder
+    dino.ALLOW_RANDOM_INIT = True
+    torch.manual_seed(0)
+    opts = Options("laptop_wild6d", batch_size=2, repeat=2, train=True)
+    enc = Encoder(opts).cuda().train()
+    enc.backbone.to(memory_format=torch.channels_last)
+    enc.featnet.to(memory_format=torch.channels_last)
+    enc.random_jitter = torch.nn.Identity()
+    img = torch.rand(4, 3, 256, 256, device="cuda")
+    state = {k: v.clone() for k, v in enc.state_dict().items()}
+
+    def run(net, x):
+        net.zero_grad(set_to_none=True)
+        code, feat = net.encode_img(x)
+        loss = (feat * torch.linspace(-1, 1, feat.numel(), device="cuda", dtype=feat.dtype).view_as(feat)).sum() + code.square().sum()
+        loss.backward()
+        return (feat.detach().double(), code.detach().double(),
+                {k: p.grad.detach().double() for k, p in net.named_parameters() if p.grad is not None})
+    enc.load_state_dict(state)
+    feat_a, code_a, grads_a = run(enc, img)
+    monkeypatch.setattr(fused_conv, "own_forward_ok", lambda *a, **k: False)          # (b): the fused ops switched off
+    enc.load_state_dict(state)
+    feat_b, code_b, grads_b = run(enc, img)
+    enc.load_state_dict(state)
+    enc64 = enc.double()                                                               # (c)
+    feat_c, code_c, grads_c = run(enc64, img.double())
+    rel = lambda u, v: ((u - v).norm() / v.norm().clamp_min(1e-30)).item()
+    print("features: own %.2e stock %.2e (relative L2 vs float64)" % (rel(feat_a, feat_c), rel(feat_b, feat_c)))
+    assert rel(feat_a, feat_c) <= 1.5 * rel(feat_b, feat_c) + 2e-6 and rel(code_a, code_c) <= 1.5 * rel(code_b, code_c) + 2e-6
+    assert set(grads_a) == set(grads_b) == set(grads_c)
+    worst = (0.0, 0.0, "")
+    for k in grads_c:
+        ea, eb = rel(grads_a[k], grads_c[k]), rel(grads_b[k], grads_c[k])
+        if ea > worst[0]:
+            worst = (ea, eb, k)
+        assert ea <= 1.5 * eb + 2e-4, "%s: own %.3e vs stock %.3e (relative L2 vs float64)" % (k, ea, eb)
+    print("encoder gradients, worst parameter %s: own %.2e, stock %.2e (relative L2 vs float64)" % (worst[2], worst[0], worst[1]))

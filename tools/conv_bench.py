@@ -1,12 +1,13 @@
-"""tools/conv_bench.py -- csrc/conv3x3.hip (implicit GEMM on the fp32 matrix cores, NHWC) vs MIOpen through F.conv2d on the
-encoder's stride-1 3x3 layers at B=32: device time of the forward launch (profiler), agreement with a float64 convolution."""
+"""tools/conv_bench.py -- the encoder's convolution layers at B=32, 256x256 (model/module/network/image_encoder.py:119-193): own
+NHWC implicit-GEMM kernels (csrc/conv_igemm.hip forward / input gradient, csrc/conv_wgrad.hip weight gradient) against MIOpen
+through F.conv2d / autograd (cudnn.benchmark, channels_last), device time per launch and TFLOP/s, per layer and summed per
+encoder pass.  Layers the own kernels do not cover (7x7 stem, stride-2 backward) are listed with MIOpen only."""
 import ctypes
 import os
 import sys
 
 import torch
 import torch.nn.functional as F
-from torch.profiler import ProfilerActivity, profile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "self-corr-pose_amd"))
@@ -15,43 +16,71 @@ from scp_amd import capi  # noqa: E402
 torch.backends.cudnn.benchmark = True
 L = capi.lib()
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
-ZEROS = torch.zeros(64, device="cuda")
-B = int(os.environ.get("B", "32"))
-LAYERS = [("layer1", 64, 64, 64), ("layer2", 128, 128, 32), ("layer3", 256, 256, 16), ("layer4", 512, 512, 8),
-          ("upconv5", 512, 256, 16), ("upconv4", 256, 128, 32), ("upconv3", 128, 64, 64)]
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+# (name, Cin, Cout, k, stride, H_in, count per encoder pass)
+LAYERS = [("stem 7x7/2", 3, 64, 7, 2, 256, 1), ("layer1 3x3", 64, 64, 3, 1, 64, 4), ("layer2.0 3x3/2", 64, 128, 3, 2, 64, 1),
+          ("layer2 3x3", 128, 128, 3, 1, 32, 3), ("layer2 down 1x1/2", 64, 128, 1, 2, 64, 1), ("layer3.0 3x3/2", 128, 256, 3, 2, 32, 1),
+          ("layer3 3x3", 256, 256, 3, 1, 16, 3), ("layer3 down 1x1/2", 128, 256, 1, 2, 32, 1), ("layer4.0 3x3/2", 256, 512, 3, 2, 16, 1),
+          ("layer4 3x3", 512, 512, 3, 1, 8, 3), ("layer4 down 1x1/2", 256, 512, 1, 2, 16, 1),
+          ("upconv5 3x3", 512, 256, 3, 1, 16, 1), ("iconv4 3x3", 512, 256, 3, 1, 16, 1), ("upconv4 3x3", 256, 128, 3, 1, 32, 1),
+          ("iconv3 3x3", 256, 128, 3, 1, 32, 1), ("upconv3 3x3", 128, 64, 3, 1, 64, 1), ("iconv2 3x3", 128, 64, 3, 1, 64, 1),
+          ("proj 1x1", 64, 64, 1, 1, 64, 1)]
 
 
-def own(x_nhwc, w_khwc, bias, y_nhwc):
-    n, h, w, cin = x_nhwc.shape
-    capi.check(L.scp_conv3x3_nhwc_forward(P(x_nhwc), P(w_khwc), P(bias), P(ZEROS), P(y_nhwc), n, h, w, cin, w_khwc.shape[0],
-                                          capi.current_stream()), "conv3x3")
-
-
-def device_us(fn, n=10):
-    for _ in range(3):
+def t(fn, n=20):
+    for _ in range(4):
         fn()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CUDA]) as prof:
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize()
-    return sum(e.self_device_time_total for e in prof.key_averages()) / n
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
 
 
-for name, cin, cout, h in LAYERS:
-    x = torch.randn(B, cin, h, h, device="cuda").contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(cout, cin, 3, 3, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
-    b = torch.randn(cout, device="cuda")
-    x_nhwc, w_khwc = x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1)          # views of the same storage
-    assert x_nhwc.is_contiguous() and w_khwc.is_contiguous()
-    y = torch.empty(B, h, h, cout, device="cuda")
-    own(x_nhwc, w_khwc, b, y)
-    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1).permute(0, 2, 3, 1)
-    lib = F.conv2d(x, w, b, 1, 1).permute(0, 2, 3, 1)
-    scale = ref.abs().max().item()
-    e_own, e_lib = (y.double() - ref).abs().max().item() / scale, (lib.double() - ref).abs().max().item() / scale
-    t_own = device_us(lambda: own(x_nhwc, w_khwc, b, y))
-    t_lib = device_us(lambda: F.conv2d(x, w, b, 1, 1))
-    gf = 2.0 * B * h * h * cout * cin * 9 / 1e12       # TFLOP; / (us * 1e-6) -> TFLOP/s
-    print("%-8s Cin %3d Cout %3d %3dx%-3d | own %7.1f us = %5.1f TF/s | MIOpen %7.1f us = %5.1f TF/s | err own %.1e MIOpen %.1e" % (
-        name, cin, cout, h, h, t_own, gf / (t_own * 1e-6), t_lib, gf / (t_lib * 1e-6), e_own, e_lib))
+tot = {k: 0.0 for k in ("mf", "md", "mw", "of", "od", "ow")}
+print("%-20s %3s %7s | MIOpen us fwd dgrad wgrad | own us fwd dgrad wgrad | own TFLOP/s fwd dgrad wgrad | MIOpen TFLOP/s" % ("layer", "cnt", "GFLOP"))
+for name, cin, cout, k, s, h, cnt in LAYERS:
+    x = torch.randn(B, cin, h, h, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(cout, cin, k, k, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, k // 2)
+    g = torch.randn_like(y)
+    ho = y.shape[2]
+    gf = 2.0 * B * ho * ho * cout * cin * k * k / 1e9
+    mf = t(lambda: F.conv2d(x, w, None, s, k // 2))
+    md = t(lambda: torch.autograd.grad(y, x, g, retain_graph=True)) if cin > 3 else float("nan")
+    mw = t(lambda: torch.autograd.grad(y, w, g, retain_graph=True))
+    of = od = ow = float("nan")
+    xn, wn, gn = x.detach().permute(0, 2, 3, 1), w.detach().permute(0, 2, 3, 1), g.permute(0, 2, 3, 1)      # NHWC views of the same storage
+    assert xn.is_contiguous() and wn.is_contiguous() and gn.is_contiguous()
+    if k in (1, 3) and cin >= 32:
+        yo = torch.empty(B, ho, ho, cout, device="cuda")
+        of = t(lambda: capi.check(L.scp_conv_nhwc_forward(P(xn), P(wn), P(None), P(yo), P(None), B, h, h, cin, cout, k, s, 0, 0.0,
+                                                          capi.current_stream()), "fwd"))
+        assert (yo - y.detach().permute(0, 2, 3, 1)).abs().max() <= 2e-4 * y.abs().max()
+        if s == 1:
+            wt = w.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous()
+            dxo = torch.empty(B, h, h, cin, device="cuda")
+            od = t(lambda: capi.check(L.scp_conv_nhwc_forward(P(gn), P(wt), P(None), P(dxo), P(None), B, h, h, cout, cin, k, 1, 0, 0.0,
+                                                              capi.current_stream()), "dgrad"))
+            if k == 3:
+                ws_bytes = L.scp_conv_nhwc_weight_grad_workspace(B, h, h, cin, cout, 3, 1)
+                if ws_bytes:
+                    ws = torch.empty(ws_bytes // 4, device="cuda")
+                    dw = torch.empty(cout, 3, 3, cin, device="cuda")
+                    ow = t(lambda: capi.check(L.scp_conv_nhwc_weight_grad(P(xn), P(gn), P(dw), P(None), P(ws), ws_bytes, B, h, h, cin, cout,
+                                                                          3, 1, capi.current_stream()), "wgrad"))
+    for key, v in (("mf", mf), ("md", md), ("mw", mw), ("of", of), ("od", od), ("ow", ow)):
+        # a layer the own kernels do not cover counts with MIOpen's time on both sides (that is what the encoder runs)
+        alt = {"of": mf, "od": md, "ow": mw}.get(key)
+        v = alt if (v != v and alt is not None) else v
+        if v == v:
+            tot[key] += cnt * v
+    tf = lambda us: gf / us * 1e3 if us == us else float("nan")
+    print("%-20s %3d %7.2f | %7.1f %7.1f %7.1f | %7.1f %7.1f %7.1f | %5.0f %5.0f %5.0f | %5.0f %5.0f %5.0f" % (
+        name, cnt, gf, mf, md, mw, of, od, ow, tf(of), tf(od), tf(ow), tf(mf), tf(md), tf(mw)))
+print("per encoder pass (ms): MIOpen fwd %.2f dgrad %.2f wgrad %.2f = %.2f | own (+MIOpen where not covered) fwd %.2f dgrad %.2f wgrad %.2f = %.2f" % (
+    tot["mf"] / 1e3, tot["md"] / 1e3, tot["mw"] / 1e3, (tot["mf"] + tot["md"] + tot["mw"]) / 1e3,
+    tot["of"] / 1e3, tot["od"] / 1e3, tot["ow"] / 1e3, (tot["of"] + tot["od"] + tot["ow"]) / 1e3))
