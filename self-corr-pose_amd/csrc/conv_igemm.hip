@@ -235,7 +235,9 @@ void launch_cfg(ConvArgs& g, bool leaky, bool stats, hipStream_t st) {
 int pick_cfg(long M, int Cout) {
     if (Cout <= 64) return 0;                                                      // 256 x 64
     const long t128 = ((M + 63) / 64) * ((Cout + 127) / 128);
-    return t128 >= 384 ? 1 : 2;                                                    // 64 x 128, else 64 x 64
+    // 64 x 128 while that still gives >= 384 workgroups, else 64 x 64 (measured inside the step: filling the machine with the
+    // smaller tile beats the larger tile on half the CUs, 39.8 vs 40.4 ms)
+    return t128 >= 384 ? 1 : 2;
 }
 int tile_rows(int cfg) { return cfg == 0 ? Cfg256x64::BM : 64; }
 

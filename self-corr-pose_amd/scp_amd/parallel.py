@@ -132,12 +132,12 @@ class FlatGradients:
             self._work[i] = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
-        if not self._armed:
-            return
         v = self.views[id(p)]
-        if p.grad is not None and p.grad.data_ptr() != v.data_ptr():     # autograd replaced the view (first-touch steal)
+        if self._prepared and p.grad is not None and p.grad.data_ptr() != v.data_ptr():     # autograd replaced the view (first-touch steal)
             v.copy_(p.grad)
             p.grad = v
+        if not self._armed:
+            return
         i = self.bucket_of[id(p)]
         first = id(p) not in self._fired
         self._fired.add(id(p))

@@ -98,8 +98,52 @@ def gaps(path, marker, skip, top=25):
         print("%8.1f us idle at %8.2f ms   after %-60s before %s" % (g / 1e3, at, before, after))
 
 
+def family(name):
+    n = name
+    for key, fam in (("vit_gemm", "vit_gemm"), ("vit_attention", "attention"), ("conv_igemm", "conv"), ("conv_wgrad", "wgrad"), ("wgrad_fold", "wgrad"),
+                     ("igemm_", "miopen"), ("grouped_conv", "miopen"), ("raster_", "raster"), ("fvm_", "corr"), ("cols_partial", "corr"),
+                     ("dual_backward", "corr"), ("Cijk_", "blas"), ("bn_", "bn"), ("bias_leaky", "bn"), ("multi_tensor", "optim"),
+                     ("row_stats", "vit_small"), ("mutual_nn", "corr"), ("nearest", "sym"), ("upsample", "up"), ("maxpool", "pool")):
+        if key in n:
+            return fam
+    return "other"
+
+
+def timeline(path, marker, skip, bin_us=500.0):
+    """one training step (between the skip-th and the (skip+1)-th launch of `marker`) in bins: for every bin, per kernel family, the
+    time-averaged number of resident kernels (1.0 = one kernel of that family resident during the whole bin), per queue"""
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    marks = [int(r["Start_Timestamp"]) for r in rows if marker in r["Kernel_Name"]]
+    # the optimizer launches several multi_tensor kernels per step: a step boundary = a gap of > 5 ms between marker launches
+    bounds = [marks[0]] + [b for a, b in zip(marks, marks[1:]) if b - a > 5e6]
+    t0, t1 = bounds[skip], bounds[skip + 1]
+    nb = int((t1 - t0) / (bin_us * 1e3)) + 1
+    fams, queues = {}, {}
+    for r in rows:
+        a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if b <= t0 or a >= t1:
+            continue
+        f = family(r["Kernel_Name"])
+        q = r.get("Queue_Id", "?")
+        for tab, key in ((fams, f), (queues, q)):
+            arr = tab.setdefault(key, [0.0] * nb)
+            i0, i1 = max(int((a - t0) / (bin_us * 1e3)), 0), min(int((b - t0) / (bin_us * 1e3)), nb - 1)
+            for i in range(i0, i1 + 1):
+                lo, hi = t0 + i * bin_us * 1e3, t0 + (i + 1) * bin_us * 1e3
+                arr[i] += max(0.0, min(b, hi) - max(a, lo)) / (bin_us * 1e3)
+    order = sorted(fams, key=lambda k: -sum(fams[k]))
+    print("# step of %.2f ms, %.0f us bins; residency per kernel family (then per queue)" % ((t1 - t0) / 1e6, bin_us))
+    print("t_ms  " + " ".join("%9s" % k[:9] for k in order) + " | " + " ".join("q%-4s" % str(k)[-4:] for k in sorted(queues)))
+    for i in range(nb):
+        print("%5.1f " % (i * bin_us / 1e3) + " ".join("%9.2f" % fams[k][i] if fams[k][i] >= 0.005 else "        ." for k in order) + " | "
+              + " ".join("%5.2f" % queues[k][i] for k in sorted(queues)))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "--gaps":
+    if sys.argv[1] == "--timeline":
+        timeline(sys.argv[2], sys.argv[3], int(sys.argv[4]), float(sys.argv[5]) if len(sys.argv) > 5 else 500.0)
+    elif sys.argv[1] == "--gaps":
         gaps(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 25)
     elif sys.argv[1] == "--trace":
         from_trace(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 45)
