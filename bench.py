@@ -84,6 +84,61 @@ class KernelTimer:
         return float(np.sum([a.elapsed_time(b) for a, b in self.events])) if self.events else None
 
 
+class KernelClock:
+    """kernel-duration clock of the vit_linear launches (include/scp_hip.h scp_kernel_clock_*): each launch stamps its earliest
+    workgroup start and latest workgroup end (100 MHz device ticks) into its own slot -- the span rocprofv3's kernel trace calls
+    the launch's duration -- without events on the stream and without a sync.  `flops[i]` is the i-th launch's algorithmic work
+    (None for row-selected launches, whose row count lives on the device)."""
+
+    def __init__(self, module, name, nslots, device):
+        import ctypes
+        from scp_amd import capi
+        self.module, self.name, self.capi, self.ctypes = module, name, capi, ctypes
+        self.orig = getattr(module, name)
+        self.slots = torch.empty(2 * nslots, dtype=torch.int64, device=device)
+        self.slots.view(-1, 2)[:, 0] = torch.iinfo(torch.int64).max
+        self.slots.view(-1, 2)[:, 1] = 0
+        self.flops, self.shapes, self.enabled, self.used = [], [], False, 0
+
+    def __enter__(self):
+        def wrapped(a, w, *args, **kwargs):
+            if self.enabled:
+                self.flops.append(None if kwargs.get("rows") is not None else 2.0 * a.shape[0] * a.shape[1] * w.shape[0])
+                self.shapes.append((a.shape[0], w.shape[0], a.shape[1]))
+            return self.orig(a, w, *args, **kwargs)
+        setattr(self.module, self.name, wrapped)
+        return self
+
+    def start(self):
+        torch.cuda.synchronize()
+        self.capi.check(self.capi.lib().scp_kernel_clock_begin(self.ctypes.c_void_p(self.slots.data_ptr()), self.slots.numel() // 2), "kernel_clock_begin")
+        self.enabled = True
+
+    def stop(self):
+        self.enabled = False
+        self.used = self.capi.lib().scp_kernel_clock_end()
+
+    def __exit__(self, *exc):
+        setattr(self.module, self.name, self.orig)
+
+    def result(self):
+        """(sum of flops, sum of durations in ms, launches) over the full (host-counted) launches"""
+        n = min(self.used, len(self.flops))
+        t = self.slots.view(-1, 2)[:n].cpu().numpy()
+        dur_ms = (t[:, 1] - t[:, 0]) * 1e-5                       # 100 MHz ticks -> ms
+        keep = [i for i in range(n) if self.flops[i] is not None and dur_ms[i] > 0]
+        if not keep:
+            return None
+        by_shape = {}
+        for i in keep:
+            e = by_shape.setdefault("M%d_N%d_K%d" % self.shapes[i], [0, 0.0, self.flops[i]])
+            e[0] += 1
+            e[1] += dur_ms[i]
+        self.by_shape = {k: {"launches": c, "avg_launch_ms": round(t / c, 4), "TFLOPs": round(f / (t / c * 1e-3) / 1e12, 1)}
+                         for k, (c, t, f) in by_shape.items()}
+        return float(sum(self.flops[i] for i in keep)), float(dur_ms[keep].sum()), len(keep)
+
+
 INIT_STEPS = 3
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")   # written by tools/traffic_report.py from rocprofv3 PMC passes
 
@@ -398,7 +453,8 @@ def main():
     # strides 5 and 3 are coprime to the 33 / 8 selected launches per step: over the timed steps every layer shape is sampled evenly
     with KernelTimer(native, "backward_soft_rasterize", is_softtex) as kt, \
             KernelTimer(dino_mod, "fused_attention", lambda *a, **k: len(a) <= 6 and k.get("q_rows") is None, stride=3) as at, \
-            KernelTimer(dino_mod, "vit_linear", full_gemm, stride=5, on_timed=count_gemm) as gt:
+            KernelTimer(dino_mod, "vit_linear", full_gemm, stride=5, on_timed=count_gemm) as gt, \
+            KernelClock(dino_mod, "vit_linear", 64 * args.steps + 64, device) as kc:
         # initialisation, not measurement: the first iterations run MIOpen's solver search (cudnn.benchmark, once per
         # convolution shape and process) and fill the caching allocator -- the counterpart of a compile step.  Done
         # before the W warm-up steps so that a small --warmup still times steady-state iterations.
@@ -409,12 +465,15 @@ def main():
             tr.step(data)
         sync()
         kt.enabled = at.enabled = gt.enabled = True
+        kc.start()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             tr.step(data)
         sync()
         elapsed = time.perf_counter() - t0
         kt.enabled = at.enabled = gt.enabled = False
+        kc.stop()
+        gemm_clock = kc.result()
         kernel_ms = kt.mean_ms()
         attn_ms = at.mean_ms()
         gemm_total_ms, gemm_launches, gemm_calls = gt.total_ms(), len(gt.events), gt.calls
@@ -470,15 +529,37 @@ def main():
         roofline = None
         if gemm_total_ms:
             fl = float(np.sum(gemm_flops[-gemm_launches:]))
-            tf = fl / (gemm_total_ms * 1e-3) / 1e12
+            tf_events = fl / (gemm_total_ms * 1e-3) / 1e12
+            # the contract number is taken on the KERNEL-DURATION clock (first workgroup start to last workgroup end, stamped
+            # inside every launch of the timed region): it is the clock of the committed rocprofv3 kernel trace, so the figure can
+            # be recomputed from profiles/.  HIP events around a launch (kept as `events`) also contain the time the launch waits
+            # for CUs held by the other streams' kernels.
+            if gemm_clock:
+                cfl, cms, cn = gemm_clock
+                tf = cfl / (cms * 1e-3) / 1e12
+            else:
+                cfl, cms, cn = fl, gemm_total_ms, gemm_launches
+                tf = tf_events
             per_step = gemm_calls / args.steps
             roofline = {"kernel": "vit_gemm_kernel family (fp32 MFMA GEMM + fused LayerNorm / GELU / bias+residual epilogues; "
                                   "%d launches per step, M = %d tokens)" % (per_step, B * ((S // 8) ** 2 + 1)),
                         "bound": "mfma", "achieved": tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TF,
                         "traffic": measured_traffic("vit_gemm", size_tag), "traffic_source": "profiles/r02_traffic.json (per step)",
-                        "avg_launch_ms": gemm_total_ms / gemm_launches, "algorithmic_flops_per_launch": fl / gemm_launches,
-                        "launches_per_step": per_step, "timed_launches": gemm_launches,
-                        "ms_per_step": gemm_total_ms / gemm_launches * per_step,
+                        "clock": "in-kernel s_memrealtime stamps: first workgroup start to last workgroup end of every full launch "
+                                 "of the timed region (= rocprofv3 kernel-trace duration; profiles/r03_kernel_stats_timed_window.csv)",
+                        "avg_launch_ms": cms / cn, "algorithmic_flops_per_launch": cfl / cn,
+                        "by_shape": getattr(kc, "by_shape", None),
+                        "profile_note": "a rocprofv3 trace of this command stretches the step (the traced run is host-bound, ~51 ms "
+                                        "instead of ~40), so its kernels share the device less and read 10-15 % shorter than in the "
+                                        "un-traced run that this clock measures",
+                        "launches_per_step": per_step, "timed_launches": cn,
+                        "ms_per_step": cms / cn * per_step,
+                        "events": {"what": "HIP events on the ViT stream around every 5th launch (includes waiting for CUs)",
+                                   "achieved": tf_events, "frac": tf_events / FP32_VALU_PEAK_TF,
+                                   "avg_launch_ms": gemm_total_ms / gemm_launches, "timed_launches": gemm_launches},
+                        "sustained_clock_note": "fp32 MFMA on random data runs the part at ~1.95 GHz (tools/probes/gemm_v3.hip: "
+                                                "s_memtime / s_memrealtime), i.e. 128 TFLOP/s is what 100 % matrix-pipe occupancy "
+                                                "delivers; peak above is the nominal 2.4 GHz figure",
                         # per block: qkv (r 384, w 1152), proj (r 384 + 384 residual, w 384), fc1 (r 384, w 1536), fc2 (r 1536 + 384,
                         # w 384) floats per token = 6912; + block 9's K slice (r 384, w 384); + the weights once per launch
                         "algorithmic_bytes_per_step": 4.0 * (B * ((S // 8) ** 2 + 1) * (9 * 6912 + 768) + 9 * 4608 * 384 + 384 * 384),

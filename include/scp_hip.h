@@ -150,6 +150,12 @@ int scp_vit_linear_rows(const float* A, const float* W, const float* vec0, const
                         int N, int K, int epilogue, void* stream);
 /* stats[rows,2] = (mean, 1/sqrt(biased var + eps)) of every row of x[rows,C] (nn.LayerNorm's statistics), C <= 1536 */
 int scp_row_mean_rstd(const float* x, float* stats, int rows, int C, float eps, void* stream);
+/* Kernel-duration clock of the linear layers (measurement aid for bench.py's roofline, not used by the training path): between
+ * begin and end the i-th scp_vit_linear* launch records into slots[2 i] the earliest workgroup start and into slots[2 i + 1] the
+ * latest workgroup end, in 100 MHz s_memrealtime ticks (the caller fills the buffer with (~0, 0) pairs; device memory) -- the
+ * span rocprofv3's kernel trace reports as the launch's duration.  end returns the number of launches recorded. */
+int scp_kernel_clock_begin(unsigned long long* slots, int nslots);
+int scp_kernel_clock_end(void);
 
 /* ---- dense correspondence: masked softmax / soft-argmax over an all-pairs score tensor ------------
  * scores S[N,P,Q], Q contiguous.  A score is "masked" (treated as the constant -1e5, like

@@ -64,7 +64,18 @@ struct GemmArgs {
     const int* m_dev;      // optional: the row count lives on the device (<= M); the plan is then redone in the kernel
     const int* a_rows;     // optional: GEMM row m reads A row a_rows[m] ...
     const int* c_rows;     // ... and its rowstat / resid / C row is c_rows[m] (row gather / scatter without a copy)
+    unsigned long long* clock;   // optional (scp_kernel_clock_begin): [0] = min start, [1] = max end over the workgroups, 100 MHz ticks
 };
+
+// kernel-duration clock: first workgroup start to last workgroup end -- what rocprofv3's kernel trace reports as the launch's
+// duration -- taken inside the kernel, so that bench.py can state the roofline on the same clock as the committed profile even
+// while other streams hold part of the device (HIP events around a launch also contain the time it waits for CUs)
+__device__ __forceinline__ void clock_start(const GemmArgs& g) {
+    if (g.clock && threadIdx.x == 0) atomicMin(g.clock, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+__device__ __forceinline__ void clock_end(const GemmArgs& g) {
+    if (g.clock && threadIdx.x == 0) atomicMax(g.clock + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
 
 // Which tiles a launch is made of (host and device agree on it; with m_dev the device redoes it for its own row count).
 struct Plan {
@@ -177,7 +188,9 @@ __global__ __launch_bounds__(THREADS, 2) void vit_gemm_kernel(const GemmArgs g) 
         const int lid = xcd_order(t, p.nbig);
         if (lid >= p.nbig) return;
         const int bm = lid / g.nblk_n, bn = lid - bm * g.nblk_n;
+        clock_start(g);
         run_tile<BigCfg, EPI, INDEXED>(g, lds, M, bm * BigCfg::BM, bn * BN);
+        clock_end(g);
         return;
     }
     t -= p.big_pad;
@@ -198,7 +211,9 @@ __global__ __launch_bounds__(THREADS, 2) void vit_gemm_kernel(const GemmArgs g) 
         bn = r - sub * g.nblk_n;
         m0 = p.panels * BigCfg::BM + sub * QM;
     }
+    clock_start(g);
     run_tile<QtrCfg, EPI, INDEXED>(g, lds, M, m0, bn * BN);
+    clock_end(g);
 }
 
 // per-row LayerNorm statistics (mean, rstd = 1 / sqrt(var + eps)), biased variance as nn.LayerNorm, two-pass over registers.
@@ -288,6 +303,10 @@ __global__ __launch_bounds__(256) void row_stats384_kernel(const float* __restri
     }
 }
 
+// scp_kernel_clock_begin / _end: while a slot buffer is installed every vit_linear launch gets the next slot
+unsigned long long* g_clock_slots = nullptr;
+int g_clock_n = 0, g_clock_i = 0;
+
 int device_slots() {
     static int slots = 0;
     if (!slots) {
@@ -328,6 +347,7 @@ int vit_linear_impl(const float* A, const float* W, const float* vec0, const flo
     g.M = M; g.N = N; g.K = K; g.m_dev = m_dev; g.a_rows = a_rows; g.c_rows = c_rows;
     g.nblk_n = (N + BN - 1) / BN;
     g.slots = device_slots();
+    g.clock = (g_clock_slots && g_clock_i < g_clock_n) ? g_clock_slots + 2 * (g_clock_i++) : nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (epilogue) {
         case SCP_GEMM_BIAS: launch<SCP_GEMM_BIAS>(g, st); break;
@@ -362,4 +382,19 @@ extern "C" int scp_row_mean_rstd(const float* x, float* stats, int rows, int C, 
         hipLaunchKernelGGL(row_stats_kernel, dim3((rows + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), x, stats, rows,
                            C, eps);
     return scp::check_launch("row_mean_rstd");
+}
+
+extern "C" int scp_kernel_clock_begin(unsigned long long* slots, int nslots) {
+    if (!slots || nslots <= 0) return scp::fail(hipErrorInvalidValue, "kernel_clock_begin: empty slot buffer");
+    g_clock_slots = slots;
+    g_clock_n = nslots;
+    g_clock_i = 0;
+    return 0;
+}
+
+extern "C" int scp_kernel_clock_end(void) {
+    const int used = g_clock_i;
+    g_clock_slots = nullptr;
+    g_clock_n = g_clock_i = 0;
+    return used;
 }
