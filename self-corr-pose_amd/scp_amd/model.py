@@ -74,12 +74,29 @@ class MeshNet(nn.Module):
         if not opts.train:
             return pred_v, faces, tex, imatch, match, match_conf, rotation, translation, scale, pointcorr
 
-        (mask_render, tex_render, depth_render, match_gt, imatch_gt, tex_mask, depth_mask, match_mask,
-         depth_weight) = self.renderer.render_all(pred_v, faces, tex, foc_crop, pp_crop, rotation, translation, scale)
-
         occ_arg = occ if opts.use_occ else None
+        # The soft-texture pass and its loss share nothing with the mask / depth / canonical-xyz group but their inputs: on the
+        # GPU they run on a second side stream.  Both chains are rasteriser launches (VALU-bound, far from filling the device)
+        # strung together by small latency-bound kernels, forward and -- autograd replays nodes on their forward stream --
+        # backward; side by side they shorten the step's serial middle part.
+        tex_side = opts.train and img.is_cuda and tex is not None and getattr(self, "overlap_texture_pass", True)
+        if tex_side:
+            if getattr(self, "_tex_stream", None) is None:
+                self._tex_stream = torch.cuda.Stream(device=img.device)
+            main = torch.cuda.current_stream(img.device)
+            self._tex_stream.wait_stream(main)
+            with torch.cuda.stream(self._tex_stream):
+                tex_render, tex_mask = self.renderer.render_texture(pred_v, faces, tex, foc_crop, pp_crop, rotation, translation)
+                texture_loss = wts.tex_wt * losses.compute_texture_loss(img, mask, tex_render, tex_mask, occ_arg).mean(0)
+            for t in (pred_v, faces, tex, foc_crop, pp_crop, rotation, translation, img, mask) + ((occ_arg,) if occ_arg is not None else ()):
+                t.record_stream(self._tex_stream)
+        else:
+            tex_render, tex_mask = self.renderer.render_texture(pred_v, faces, tex, foc_crop, pp_crop, rotation, translation)
+            texture_loss = wts.tex_wt * losses.compute_texture_loss(img, mask, tex_render, tex_mask, occ_arg).mean(0)
+        (mask_render, depth_render, match_gt, imatch_gt, depth_mask, match_mask,
+         depth_weight) = self.renderer.render_depth_group(pred_v, faces, foc_crop, pp_crop, rotation, translation)
+
         mask_loss = wts.mask_wt * losses.compute_mask_loss(img, mask, mask_render, occ_arg).mean(0)
-        texture_loss = wts.tex_wt * losses.compute_texture_loss(img, mask, tex_render, tex_mask, occ_arg).mean(0)
         if opts.use_depth:
             if opts.depth_loss_chamfer:
                 raise NotImplementedError("depth_loss_chamfer is off in every shipped config")
@@ -103,6 +120,9 @@ class MeshNet(nn.Module):
             cycle_loss = self.corr_net.compute_rotation_cycle_loss(img, mask, img_feat, self.encoder,
                                                                    angle=self.rotation_angle)[0] * wts.cycle_loss_wt
 
+        if tex_side:
+            torch.cuda.current_stream(img.device).wait_stream(self._tex_stream)
+            texture_loss.record_stream(torch.cuda.current_stream(img.device))
         total_loss = (mask_loss + symmetry_loss + triangle_loss + deform_loss + pullfar_loss + texture_loss +
                       match_loss + imatch_loss + cycle_loss_pt + cycle_loss)
         if opts.use_depth:

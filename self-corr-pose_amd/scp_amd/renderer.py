@@ -34,7 +34,18 @@ class Renderer:
         return render(self.renderer_depth, mean_v, faces, None, foc_crop, pp_crop, rotation, translation,
                       rotation_detach=True, translation_detach=True, render_depth=True)
 
-    def render_all(self, pred_v, faces, tex, foc_crop, pp_crop, rotation, translation, scale):
+    def render_texture(self, pred_v, faces, tex, foc_crop, pp_crop, rotation, translation):
+        """the soft-texture pass (sigma 1e-3, gamma 1e-2, softmax colours): (tex_render [B,3,H,W], tex_mask [B,H,W]).  It shares
+        nothing with the depth group below but its inputs, so MeshNet runs it (and the texture loss) on a side stream."""
+        if tex is None:
+            return None, None
+        tex_out = render(self.renderer_softtex, pred_v, faces, tex, foc_crop, pp_crop, rotation, translation,
+                         texture_type=self.mesh.texture_type)
+        return tex_out[:, :3], tex_out[:, -1]
+
+    def render_depth_group(self, pred_v, faces, foc_crop, pp_crop, rotation, translation):
+        """mask, depth and canonical-xyz ("hardtex") passes + the projected vertices and their visibility weight:
+        (mask_render, depth_render, match_gt, imatch_gt, depth_mask, match_mask, depth_weight)"""
         cam = (foc_crop, pp_crop, rotation, translation)
         # The mask pass and the depth pass share sigma, distance function and alpha aggregation, so
         # their alpha planes are bit-identical (SURVEY F7; checked in tests/test_softras_gpu.py) and the
@@ -44,12 +55,6 @@ class Renderer:
         fuse_mask = bool(self.opts.use_depth) and getattr(self, "share_mask_with_depth", True)
         if not fuse_mask:
             mask_render = render(self.renderer_mask, pred_v, faces, None, *cam, render_mask=True)[:, -1]
-
-        if tex is not None:
-            tex_out = render(self.renderer_softtex, pred_v, faces, tex, *cam, texture_type=self.mesh.texture_type)
-            tex_mask, tex_render = tex_out[:, -1], tex_out[:, :3]
-        else:
-            tex_mask = tex_render = None
 
         # The canonical-xyz ("hardtex") pass rasterises the same projected faces with the same sigma / distance /
         # alpha functions as the depth pass (renderer.py:17-24: only gamma and the rgb aggregation differ), and its
@@ -79,5 +84,11 @@ class Renderer:
         with torch.no_grad():  # visibility weight, detached in the reference (:69-71)
             seen = F.grid_sample(depth_render[:, None], imatch_gt.permute(0, 2, 1)[:, None], align_corners=False)[:, 0, 0]
             depth_weight = (-5 * F.relu(cam_v[:, :, 2] - seen)).exp()
+        return mask_render, depth_render, match_gt, imatch_gt, depth_mask, match_mask, depth_weight
 
+    def render_all(self, pred_v, faces, tex, foc_crop, pp_crop, rotation, translation, scale):
+        """the reference's 9-tuple (renderer.py:38-73)"""
+        tex_render, tex_mask = self.render_texture(pred_v, faces, tex, foc_crop, pp_crop, rotation, translation)
+        (mask_render, depth_render, match_gt, imatch_gt, depth_mask, match_mask,
+         depth_weight) = self.render_depth_group(pred_v, faces, foc_crop, pp_crop, rotation, translation)
         return mask_render, tex_render, depth_render, match_gt, imatch_gt, tex_mask, depth_mask, match_mask, depth_weight
