@@ -105,18 +105,34 @@ class PretrainedCorrespondence(nn.Module):
         self._side_stream.wait_stream(torch.cuda.current_stream(img.device))
         with torch.cuda.stream(self._side_stream):
             feats = self.net(img, None if mask is None else self._keep_tokens(mask))
+            # the mutual-nearest-neighbour matching of the re-paired batch (score GEMM, dual argmax, top-k) needs nothing but
+            # the features and the masks either: it stays on the side stream instead of the main stream's critical path
+            matched = self._match_pairs(feats, mask) if mask is not None else None
         img.record_stream(self._side_stream)
         if mask is not None:
             mask.record_stream(self._side_stream)
-        self._prefetched = (img, feats)
+        self._prefetched = (img, feats, matched)
+
+    def _match_pairs(self, feats, mask):
+        src_idx, tgt_idx = pair_indices(self.divide_kind, self.opts.batch_size, self.opts.repeat, feats.device)
+        return self.match_features(feats[src_idx], feats[tgt_idx], mask[src_idx], mask[tgt_idx], self.half_grid(src_idx.shape[0]))
 
     def _features(self, img, mask=None):
+        """(DINO features once per unique image, their pair matching) -- from the side stream if prefetch_features started them"""
         pre = getattr(self, "_prefetched", None)
         self._prefetched = None
         if pre is not None and pre[0] is img:
-            torch.cuda.current_stream(img.device).wait_stream(self._side_stream)
-            return pre[1]
-        return self.net(img, None if mask is None else self._keep_tokens(mask))
+            main = torch.cuda.current_stream(img.device)
+            main.wait_stream(self._side_stream)
+            feats, matched = pre[1], pre[2]
+            if matched is None:
+                matched = self._match_pairs(feats, mask)
+            else:
+                for t in matched:
+                    t.record_stream(main)
+            return feats, matched
+        feats = self.net(img, None if mask is None else self._keep_tokens(mask))
+        return feats, self._match_pairs(feats, mask)
 
     def compute_cycle_loss(self, img, mask, depth_weight, pointcorr):
         num_verts = pointcorr.shape[-1]
@@ -125,9 +141,7 @@ class PretrainedCorrespondence(nn.Module):
         hh, wh = self.hf // 2, self.wf // 2
         grid = self.half_grid(n)
 
-        feats = self._features(img, mask)                                        # once per unique image
-        pts_src, pts_tgt, indices_src, indices_tgt, mask_k = self.match_features(
-            feats[src_idx], feats[tgt_idx], mask[src_idx], mask[tgt_idx], grid)
+        feats, (pts_src, pts_tgt, indices_src, indices_tgt, mask_k) = self._features(img, mask)      # once per unique image
 
         # bilinear half-resolution (= exact 2x2 mean) of the score maps, once per image
         pooled = ops.pool2x2_scores(pointcorr, self.hf, self.wf)                                    # b,p,v
