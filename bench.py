@@ -578,7 +578,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[2]: B=32 (batch_size 8 x repeat 4) 256x256 per GPU, 642v/1280f mesh, "
                                    "laptop_wild6d flags, full training step (fwd+bwd+clip+AdamW)",
-                       "images_per_sec": world * args.steps * B / elapsed, "parallelism": "dp%d" % world},
+                       "images_per_sec": world * args.steps * B / elapsed, "parallelism": "dp%d" % world,
+                       "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else 0,
+                       "gradient_buckets": len(tr.grads.buckets), "buckets_launched_inside_backward": tr.grads.launched_in_backward},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

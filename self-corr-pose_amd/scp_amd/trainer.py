@@ -71,6 +71,14 @@ class Trainer:
         if opts.model_path:
             self.model.load_network(opts.model_path)
         freeze_batchnorm_affine(self.model)
+        # BatchNorm under data parallelism.  DEFAULT (sync_bn=False): every rank normalises with the statistics of its own 32
+        # images -- the semantics the fused convolution + BatchNorm ops implement (scp_amd/fused_conv.py: the statistics are
+        # finalised by the last workgroup of the rank's own convolution launch, no collective) and what the reference does on one
+        # GPU; checkpoints carry the rank-averaged running statistics (save()).  sync_bn=True reproduces the reference's
+        # multi-GPU choice (trainer.py:67 SyncBatchNorm.convert_sync_batchnorm): the modules become torch's SyncBatchNorm, which
+        # the fused ops do not take (type check) -- those layers then run own convolution -> torch SyncBatchNorm (one stat
+        # all-gather per layer over RCCL) -> ReLU as separate ops.
+        self.sync_bn = bool(sync_bn)
         if sync_bn:
             self.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.model, process_group)
         self.model = self.model.to(self.device)

@@ -190,3 +190,22 @@ def test_half_resolution_features_are_the_even_pixels_of_the_full_map():
     c = opts.n_corr_feat
     hf = int(round(full.shape[-1] ** 0.5))
     torch.testing.assert_close(half, full.reshape(2, c, hf, hf)[:, :, ::2, ::2].reshape(2, c, -1), rtol=1e-5, atol=1e-6)
+
+
+def test_sync_batchnorm_modules_take_the_stock_path():
+    """Trainer(sync_bn=True) (the reference's multi-GPU choice, trainer.py:67) converts the trunk's BatchNorms to torch's
+    SyncBatchNorm; the fused convolution + BatchNorm op must then decline (it implements per-rank statistics only) instead of
+    silently normalising with local statistics"""
+    import torch
+    from scp_amd import fused_conv
+    conv = torch.nn.Conv2d(64, 64, 3, 1, 1, bias=False)
+    bn = torch.nn.SyncBatchNorm(64)
+    calls = []
+    orig = fused_conv._ConvBNAct.apply
+    try:
+        fused_conv._ConvBNAct.apply = staticmethod(lambda *a, **k: calls.append(1) or orig(*a, **k))
+        bn.eval()                     # SyncBatchNorm's training forward needs a GPU process group; the dispatch is what is checked
+        y = fused_conv.conv_bn_act(torch.randn(2, 64, 8, 8), conv, bn, relu=True)
+    finally:
+        fused_conv._ConvBNAct.apply = orig
+    assert not calls and y.shape == (2, 64, 8, 8)
