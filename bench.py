@@ -18,7 +18,7 @@ Extra JSON objects (tier contract):
                 bound "mfma": `achieved` = algorithmic flops of the launches (2 M N K each) / their duration, both summed
                 over the timed region and measured with HIP events on the launch stream; peak = 157.3 TFLOP/s (fp32 MFMA).
                 `traffic` = HBM bytes per step of those launches from rocprofv3 FETCH_SIZE / WRITE_SIZE passes, read from
-                profiles/r02_traffic.json when that file matches the problem size, else null.
+                profiles/r03_traffic.json when that file matches the problem size, else null.
                 "others": the ViT attention kernel (mfma), the SoftRas backward of the sigma=1e-3 pass (fp32 VALU on active
                 (pixel,face) pairs; HBM figure for the record) and the fused correspondence kernels, same method.
   cpu_baseline  the same step on the host CPU cores (torch CPU + the C oracle rasteriser), rank 0, N=1 only: ONE full
@@ -140,7 +140,7 @@ class KernelClock:
 
 
 INIT_STEPS = 3
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")   # written by tools/traffic_report.py from rocprofv3 PMC passes
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")   # written by tools/traffic_report.py from rocprofv3 PMC passes
 
 
 def measured_traffic(key, size_tag):
@@ -544,7 +544,7 @@ def main():
             roofline = {"kernel": "vit_gemm_kernel family (fp32 MFMA GEMM + fused LayerNorm / GELU / bias+residual epilogues; "
                                   "%d launches per step, M = %d tokens)" % (per_step, B * ((S // 8) ** 2 + 1)),
                         "bound": "mfma", "achieved": tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TF,
-                        "traffic": measured_traffic("vit_gemm", size_tag), "traffic_source": "profiles/r02_traffic.json (per step)",
+                        "traffic": measured_traffic("vit_gemm", size_tag), "traffic_source": "profiles/r03_traffic.json (per step)",
                         "clock": "in-kernel s_memrealtime stamps: first workgroup start to last workgroup end of every full launch "
                                  "of the timed region (= rocprofv3 kernel-trace duration; profiles/r03_kernel_stats_timed_window.csv)",
                         "avg_launch_ms": cms / cn, "algorithmic_flops_per_launch": cfl / cn,

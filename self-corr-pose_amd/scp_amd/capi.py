@@ -10,7 +10,8 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libscp_hip.so")
+# SCP_HIP_LIB: an alternative build of the same library (A/B of kernel variants from tools/); the default is the in-tree build
+LIB_PATH = os.environ.get("SCP_HIP_LIB") or os.path.join(_PKG, "lib", "libscp_hip.so")
 ABI_VERSION = 1
 
 
