@@ -12,5 +12,6 @@ f=$(ls /tmp/trace_$tag/*/*kernel_trace.csv | head -1)
 cd $R
 tail -4 gpurun_out/${tag}_probe.log
 python tools/profile_summary.py --timeline $f multi_tensor_apply_kernel 40 250 > gpurun_out/${tag}_timeline.txt
+python tools/profile_summary.py --chain $f multi_tensor_apply_kernel 40 > gpurun_out/${tag}_middle_chain.txt
 python tools/profile_summary.py --trace $f multi_tensor_apply_kernel 150 60 > gpurun_out/${tag}_kernel_stats_replay_window.csv
 head -3 gpurun_out/${tag}_kernel_stats_replay_window.csv

@@ -140,8 +140,46 @@ def timeline(path, marker, skip, bin_us=500.0):
               + " ".join("%5.2f" % queues[k][i] for k in sorted(queues)))
 
 
+def chain_census(path, marker, skip, start_key="fvm_forward", end_key="bn_bwd", top=40):
+    """the step's serial middle part (from the first `start_key` launch of a step to the first `end_key` launch after it): kernels
+    aggregated by name, device-idle time and how much of the window had exactly one kernel resident"""
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    marks = [int(r["Start_Timestamp"]) for r in rows if marker in r["Kernel_Name"]]
+    bounds = [marks[0]] + [b for a, b in zip(marks, marks[1:]) if b - a > 5e6]
+    t0, t1 = bounds[skip], bounds[skip + 1]
+    step = [r for r in rows if t0 <= int(r["Start_Timestamp"]) < t1]
+    a = next(int(r["Start_Timestamp"]) for r in step if start_key in r["Kernel_Name"])
+    b = next(int(r["Start_Timestamp"]) for r in step if end_key in r["Kernel_Name"] and int(r["Start_Timestamp"]) > a)
+    win = [r for r in step if int(r["End_Timestamp"]) > a and int(r["Start_Timestamp"]) < b]
+    agg = {}
+    for r in win:
+        d = min(int(r["End_Timestamp"]), b) - max(int(r["Start_Timestamp"]), a)
+        e = agg.setdefault(short(r["Kernel_Name"])[:70], [0, 0])
+        e[0] += 1
+        e[1] += d
+    # coverage profile
+    ev = []
+    for r in win:
+        ev.append((max(int(r["Start_Timestamp"]), a), 1))
+        ev.append((min(int(r["End_Timestamp"]), b), -1))
+    ev.sort()
+    depth, last, hist = 0, a, {}
+    for t, d in ev:
+        hist[min(depth, 3)] = hist.get(min(depth, 3), 0) + (t - last)
+        depth += d
+        last = t
+    print("# serial middle part of one step: %.2f ms (%s -> %s), %d launches" % ((b - a) / 1e6, start_key, end_key, len(win)))
+    print("# resident kernels 0 / 1 / 2 / >=3: " + " / ".join("%.2f ms" % (hist.get(k, 0) / 1e6) for k in range(4)))
+    print("kernel,calls,total_us")
+    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+        print('"%s",%d,%.1f' % (k, c, t / 1e3))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "--timeline":
+    if sys.argv[1] == "--chain":
+        chain_census(sys.argv[2], sys.argv[3], int(sys.argv[4]))
+    elif sys.argv[1] == "--timeline":
         timeline(sys.argv[2], sys.argv[3], int(sys.argv[4]), float(sys.argv[5]) if len(sys.argv) > 5 else 500.0)
     elif sys.argv[1] == "--gaps":
         gaps(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 25)
