@@ -392,6 +392,31 @@ int scp_upsample2x_bilinear_backward_bf16(const void* grad_out, void* grad_in, i
  * qkv GEMM), out [B,N,H*64] bf16; products on the bf16 matrix cores with fp32 accumulation, softmax statistics in fp32. */
 int scp_vit_attention_bf16_forward(const void* qkv, void* out, int B, int N, int H, int head_dim, float scale, void* stream);
 
+/* ---- image-space losses of the step, fused --------------------------------------------------------------------
+ * Replace compute_mask_loss / compute_depth_loss / compute_match_loss (model/util/loss_utils.py:236-244, :273-284, :317-320, called
+ * from model/model.py:206-214) on the renders as the step holds them:
+ *   depth_out [B,4,H,W] depth render (plane 2 = depth_pred, plane 3 = alpha = mask_pred = depth_mask),
+ *   match_out [B,4,H,W] canonical-xyz render (planes 0..2 = match_gt, plane 3 = match_mask), match [B,3,H,W],
+ *   depth / mask [B,H,W] data.  W a power of two in [32,1024].
+ * forward: parts [scp_image_losses_parts()*4] scratch kept for backward, rowsum [B*H,3] = per-row means of the (mask pyramid, depth,
+ *   match) terms: loss_mask[b] = 0.2 * mean_h rowsum[b,h,0], loss_depth[b] = mean_h rowsum[b,h,1], loss_match[b] = mean_h rowsum[b,h,2].
+ * backward: g_* [B] upstream gradients of the three loss vectors -> grad_depth_out [B,4,H,W], grad_match [B,3,H,W] and
+ *   gsum [B*H]; then scp_image_losses_backward_scale with G = sum(gsum) (device scalar) adds the gradient that reaches depth_pred
+ *   through the batch-global depth_scale. */
+int scp_image_losses_parts(void);
+int scp_image_losses_forward(const float* depth_out, const float* depth, const float* mask, const float* match, const float* match_out,
+                             int B, int H, int W, float* parts, float* rowsum, void* stream);
+int scp_image_losses_backward(const float* depth_out, const float* depth, const float* mask, const float* match, const float* match_out,
+                              const float* parts, const float* g_mask, const float* g_depth, const float* g_match, int B, int H, int W,
+                              float* grad_depth_out, float* grad_match, float* gsum, void* stream);
+int scp_image_losses_backward_scale(const float* depth_out, const float* parts, const float* G, int B, int H, int W,
+                                    float* grad_depth_out, void* stream);
+/* compute_texture_loss (loss_utils.py:246-252) on tex_out [B,4,H,W] (rgb + alpha of the soft-texture pass), img [B,3,H,W], mask [B,H,W]:
+ * rowsum [B*H] per-row means (loss[b] = mean_h rowsum[b,h]); backward: g_tex [B] -> grad_tex_out [B,4,H,W]. */
+int scp_texture_loss_forward(const float* tex_out, const float* img, const float* mask, int B, int H, int W, float* rowsum, void* stream);
+int scp_texture_loss_backward(const float* tex_out, const float* img, const float* mask, const float* g_tex, int B, int H, int W,
+                              float* grad_tex_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,6 +104,12 @@ SYMBOLS = {
     "scp_add_layernorm_forward": (ctypes.c_int, [_P, _P, _P, _P, _F, ctypes.c_long, _I, _P, _P, _P]),
     "scp_vit_attention_forward": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "scp_vit_attention_forward_rows": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "scp_image_losses_parts": (ctypes.c_int, []),
+    "scp_image_losses_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "scp_image_losses_backward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "scp_image_losses_backward_scale": (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "scp_texture_loss_forward": (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "scp_texture_loss_backward": (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "scp_dual_softmax_backward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _F,
                                                 _I, _I, _I, _P]),
 }

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import dino, losses
+from . import dino, fused_losses, losses
 from .correspondence import Correspondence
 from .encoder import Encoder
 from .mesh import CanonicalMesh
@@ -75,6 +75,7 @@ class MeshNet(nn.Module):
             return pred_v, faces, tex, imatch, match, match_conf, rotation, translation, scale, pointcorr
 
         occ_arg = occ if opts.use_occ else None
+        cam = (foc_crop, pp_crop, rotation, translation)
         # The soft-texture pass and its loss share nothing with the mask / depth / canonical-xyz group but their inputs: on the
         # GPU they run on a second side stream.  Both chains are rasteriser launches (VALU-bound, far from filling the device)
         # strung together by small latency-bound kernels, forward and -- autograd replays nodes on their forward stream --
@@ -86,23 +87,29 @@ class MeshNet(nn.Module):
             main = torch.cuda.current_stream(img.device)
             self._tex_stream.wait_stream(main)
             with torch.cuda.stream(self._tex_stream):
-                tex_render, tex_mask = self.renderer.render_texture(pred_v, faces, tex, foc_crop, pp_crop, rotation, translation)
-                texture_loss = wts.tex_wt * losses.compute_texture_loss(img, mask, tex_render, tex_mask, occ_arg).mean(0)
+                texture_loss = wts.tex_wt * self._texture_loss(pred_v, faces, tex, cam, img, mask, occ_arg).mean(0)
             for t in (pred_v, faces, tex, foc_crop, pp_crop, rotation, translation, img, mask) + ((occ_arg,) if occ_arg is not None else ()):
                 t.record_stream(self._tex_stream)
         else:
-            tex_render, tex_mask = self.renderer.render_texture(pred_v, faces, tex, foc_crop, pp_crop, rotation, translation)
-            texture_loss = wts.tex_wt * losses.compute_texture_loss(img, mask, tex_render, tex_mask, occ_arg).mean(0)
-        (mask_render, depth_render, match_gt, imatch_gt, depth_mask, match_mask,
-         depth_weight) = self.renderer.render_depth_group(pred_v, faces, foc_crop, pp_crop, rotation, translation)
-
-        mask_loss = wts.mask_wt * losses.compute_mask_loss(img, mask, mask_render, occ_arg).mean(0)
-        if opts.use_depth:
-            if opts.depth_loss_chamfer:
-                raise NotImplementedError("depth_loss_chamfer is off in every shipped config")
-            depth_loss_sub, _ = losses.compute_depth_loss(depth, depth_render, depth_mask, mask)
-            depth_loss = wts.depth_wt * depth_loss_sub.mean(0)
-        match_loss = wts.match_wt * losses.compute_match_loss(match, match_gt, match_mask, mask).mean(0)
+            texture_loss = wts.tex_wt * self._texture_loss(pred_v, faces, tex, cam, img, mask, occ_arg).mean(0)
+        # fused per-pixel losses (csrc/losses.hip) when they cover the configuration, the torch compositions otherwise
+        fused = (getattr(self, "fuse_image_losses", True) and occ_arg is None and opts.use_depth and not opts.depth_loss_chamfer
+                 and self.renderer.shares_mask_with_depth() and fused_losses.covers(img, mask, depth, match))
+        if fused:
+            depth_out, match_out, imatch_gt, depth_weight = self.renderer.render_depth_group(pred_v, faces, *cam, raw=True)
+            mask_sub, depth_sub, match_sub = fused_losses.depth_group_losses(depth_out, match_out, match, depth, mask)
+            mask_loss, depth_loss = wts.mask_wt * mask_sub.mean(0), wts.depth_wt * depth_sub.mean(0)
+            match_loss = wts.match_wt * match_sub.mean(0)
+        else:
+            (mask_render, depth_render, match_gt, imatch_gt, depth_mask, match_mask,
+             depth_weight) = self.renderer.render_depth_group(pred_v, faces, *cam)
+            mask_loss = wts.mask_wt * losses.compute_mask_loss(img, mask, mask_render, occ_arg).mean(0)
+            if opts.use_depth:
+                if opts.depth_loss_chamfer:
+                    raise NotImplementedError("depth_loss_chamfer is off in every shipped config")
+                depth_loss_sub, _ = losses.compute_depth_loss(depth, depth_render, depth_mask, mask)
+                depth_loss = wts.depth_wt * depth_loss_sub.mean(0)
+            match_loss = wts.match_wt * losses.compute_match_loss(match, match_gt, match_mask, mask).mean(0)
         imatch_loss = wts.imatch_wt * losses.compute_imatch_loss(imatch, imatch_gt, depth_weight).mean(0)
 
         symmetry_loss = wts.symmetry_wt * self.mesh.compute_symmetry_loss(pred_v, faces)
@@ -144,6 +151,13 @@ class MeshNet(nn.Module):
             aux_output["cam_loss"] = cam_loss
         self.last_pose = (rotation.detach(), translation.detach())
         return total_loss, aux_output
+
+    def _texture_loss(self, pred_v, faces, tex, cam, img, mask, occ):
+        """soft-texture pass + texture loss [B]"""
+        if tex is not None and occ is None and getattr(self, "fuse_image_losses", True) and fused_losses.covers(img, mask):
+            return fused_losses.texture_loss(self.renderer.render_texture_raw(pred_v, faces, tex, *cam), img, mask)
+        tex_render, tex_mask = self.renderer.render_texture(pred_v, faces, tex, *cam)
+        return losses.compute_texture_loss(img, mask, tex_render, tex_mask, occ)
 
     def load_network(self, model_path, iter=0):
         states = torch.load(model_path, map_location="cpu")

@@ -39,20 +39,31 @@ class Renderer:
         nothing with the depth group below but its inputs, so MeshNet runs it (and the texture loss) on a side stream."""
         if tex is None:
             return None, None
-        tex_out = render(self.renderer_softtex, pred_v, faces, tex, foc_crop, pp_crop, rotation, translation,
-                         texture_type=self.mesh.texture_type)
+        tex_out = self.render_texture_raw(pred_v, faces, tex, foc_crop, pp_crop, rotation, translation)
         return tex_out[:, :3], tex_out[:, -1]
 
-    def render_depth_group(self, pred_v, faces, foc_crop, pp_crop, rotation, translation):
+    def render_texture_raw(self, pred_v, faces, tex, foc_crop, pp_crop, rotation, translation):
+        """the soft-texture pass' [B,4,H,W] output (rgb + alpha) as the rasteriser leaves it: what fused_losses.texture_loss reads"""
+        return render(self.renderer_softtex, pred_v, faces, tex, foc_crop, pp_crop, rotation, translation,
+                      texture_type=self.mesh.texture_type)
+
+    def shares_mask_with_depth(self):
+        return bool(self.opts.use_depth) and getattr(self, "share_mask_with_depth", True)
+
+    def render_depth_group(self, pred_v, faces, foc_crop, pp_crop, rotation, translation, raw=False):
         """mask, depth and canonical-xyz ("hardtex") passes + the projected vertices and their visibility weight:
-        (mask_render, depth_render, match_gt, imatch_gt, depth_mask, match_mask, depth_weight)"""
+        (mask_render, depth_render, match_gt, imatch_gt, depth_mask, match_mask, depth_weight).
+        raw=True (needs shares_mask_with_depth()): (depth_out [B,4,H,W], match_out [B,4,H,W], imatch_gt, depth_weight) -- the two
+        rasteriser outputs undivided, for fused_losses.depth_group_losses."""
         cam = (foc_crop, pp_crop, rotation, translation)
         # The mask pass and the depth pass share sigma, distance function and alpha aggregation, so
         # their alpha planes are bit-identical (SURVEY F7; checked in tests/test_softras_gpu.py) and the
         # mask pass' gradient reaches the geometry only through alpha: taking the mask from the depth
         # pass' alpha channel is the same forward value and -- by linearity of the backward in the
         # incoming alpha gradient -- the same gradient, with one rasterisation + one backward less.
-        fuse_mask = bool(self.opts.use_depth) and getattr(self, "share_mask_with_depth", True)
+        fuse_mask = self.shares_mask_with_depth()
+        if raw and not fuse_mask:
+            raise RuntimeError("render_depth_group(raw=True) needs the mask shared with the depth pass")
         if not fuse_mask:
             mask_render = render(self.renderer_mask, pred_v, faces, None, *cam, render_mask=True)[:, -1]
 
@@ -75,7 +86,7 @@ class Renderer:
             mask_render = depth_out[:, 3]
         if not self.opts.use_depth:
             depth_out = depth_out.detach()
-        depth_mask, depth_render = depth_out[:, 3], depth_out[:, 2].clone()
+        depth_mask, depth_render = depth_out[:, 3], (depth_out[:, 2] if raw else depth_out[:, 2].clone())
         match_mask, match_gt = match_out[:, -1], match_out[:, :3]
 
         # projected vertex positions: differentiable w.r.t. rotation / translation (renderer.py:63-67)
@@ -84,6 +95,8 @@ class Renderer:
         with torch.no_grad():  # visibility weight, detached in the reference (:69-71)
             seen = F.grid_sample(depth_render[:, None], imatch_gt.permute(0, 2, 1)[:, None], align_corners=False)[:, 0, 0]
             depth_weight = (-5 * F.relu(cam_v[:, :, 2] - seen)).exp()
+        if raw:
+            return depth_out, match_out, imatch_gt, depth_weight
         return mask_render, depth_render, match_gt, imatch_gt, depth_mask, match_mask, depth_weight
 
     def render_all(self, pred_v, faces, tex, foc_crop, pp_crop, rotation, translation, scale):
