@@ -137,17 +137,23 @@ int scp_fvm_backward(const float* img_feat, const float* mesh_feat, const float*
  *   SCP_GEMM_BIAS_RESIDUAL   C = acc + vec0[n] + resid[m,n]                      (resid may alias C: in-place residual stream)
  *   SCP_GEMM_LN              C = rstd[m] * (acc - mean[m] * vec0[n]) + vec1[n]   = LayerNorm(A) Wo^T + b when W = gamma o Wo,
  *                            vec0[n] = sum_k W[n,k], vec1[n] = sum_k beta[k] Wo[n,k] + b[n], rowstat = scp_row_mean_rstd(A)
- *   SCP_GEMM_LN_GELU         the same followed by the erf GELU */
-enum { SCP_GEMM_BIAS = 0, SCP_GEMM_BIAS_RESIDUAL = 1, SCP_GEMM_LN = 2, SCP_GEMM_LN_GELU = 3 };
-int scp_vit_linear(const float* A, const float* W, const float* vec0, const float* vec1, const float* rowstat,
+ *   SCP_GEMM_LN_GELU         the same followed by the erf GELU
+ * `epilogue | SCP_GEMM_W_SPLIT3`: W points to the planes [3][N][K] bf16 written by scp_split_bf16x3(W fp32) and the products run
+ *   on the bf16 matrix cores with EXACTLY split operands (every fp32 value is the sum of three bf16 values; the six leading
+ *   partial products of the nine are accumulated in fp32, the dropped ones are below 2^-24 of |a b|): same accuracy against
+ *   float64 as the fp32 matrix-core path at ~1.5x its rate (csrc/gemm_core_split.h).  A stays fp32. */
+enum { SCP_GEMM_BIAS = 0, SCP_GEMM_BIAS_RESIDUAL = 1, SCP_GEMM_LN = 2, SCP_GEMM_LN_GELU = 3, SCP_GEMM_W_SPLIT3 = 0x100 };
+int scp_vit_linear(const float* A, const void* W, const float* vec0, const float* vec1, const float* rowstat,
                    const float* resid, float* C, int M, int N, int K, int epilogue, void* stream);
 /* the same for a SELECTION of rows made on the device: rows_dev[0] (clamped to [0, max_rows]) rows are computed; GEMM row m
  * reads A row a_rows[m] and uses rowstat / resid / C row c_rows[m] (int32 index lists of >= max_rows entries; NULL = identity).
  * The rows are the foreground tokens of the last ViT block (scp_amd/dino.py); the host never waits for their number and nothing
  * is gathered or scattered by a copy. */
-int scp_vit_linear_rows(const float* A, const float* W, const float* vec0, const float* vec1, const float* rowstat,
+int scp_vit_linear_rows(const float* A, const void* W, const float* vec0, const float* vec1, const float* rowstat,
                         const float* resid, float* C, const int* rows_dev, int max_rows, const int* a_rows, const int* c_rows,
                         int N, int K, int epilogue, void* stream);
+/* planes[3][n] bf16 (h, m, l) with x[i] = h[i] + m[i] + l[i] exactly: the weight format of SCP_GEMM_W_SPLIT3 */
+int scp_split_bf16x3(const float* x, void* planes, size_t n, void* stream);
 /* stats[rows,2] = (mean, 1/sqrt(biased var + eps)) of every row of x[rows,C] (nn.LayerNorm's statistics), C <= 1536 */
 int scp_row_mean_rstd(const float* x, float* stats, int rows, int C, float eps, void* stream);
 /* Kernel-duration clock of the linear layers (measurement aid for bench.py's roofline, not used by the training path): between

@@ -141,6 +141,12 @@ struct GemmCore {
         src.set(A, W, m0, n0, M, N, K, wave, lane);
     }
 
+    // the interface csrc/gemm_core_split.h shares (vit_gemm.hip picks a core per launch)
+    template <class FA, class FW>
+    __device__ __forceinline__ void set_rows(const float* A, const void* W, int N, int K, FA a_row, FW w_row) {
+        src.set_rows(A, static_cast<const float*>(W), K, wave, lane, a_row, w_row);
+    }
+
     // fragment read R (0 .. NREAD-1) of half C of the chunk in stage S
     template <int S, int C, int R>
     __device__ __forceinline__ void read(Frag& f) {

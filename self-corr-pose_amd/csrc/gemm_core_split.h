@@ -1,0 +1,196 @@
+// self-corr-pose_amd/csrc/gemm_core_split.h -- fp32 GEMM main loop on the bf16 matrix cores by EXACT operand splitting:
+//     acc[M-tile][N-tile] += A[rows][K] * W[cols][K]^T,   A fp32, W given as three bf16 planes, accumulation in fp32.
+//
+// Every fp32 number x is the exact sum of three bf16 numbers h + m + l (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): each
+// residual is exactly representable in fp32 and has at most 16 resp. 8 significant bits left).  A product a*b is then the sum of
+// nine bf16 x bf16 products, each EXACT in fp32; the six largest (hh, hm, mh, hl, lh, mm) are evaluated with
+// v_mfma_f32_32x32x16_bf16 and accumulated in fp32, the three dropped ones (ml, lm, ll) are below 2^-24 |a b| each -- the size of
+// the rounding of one fp32 fused multiply-add.  Measured against float64 the result is as close as the fp32-MFMA kernel's
+// (tools/probes/gemm_split.hip prints both; tests/test_vit_gpu.py holds both to the same tolerance).
+//
+// Why: v_mfma_f32_32x32x2_f32 does 2 K-steps per 64 cycles, v_mfma_f32_32x32x16_bf16 16 K-steps per 32 cycles: six bf16 MFMAs
+// per 16 K-steps cost 192 cycles against 512 for eight fp32 MFMAs -- a 2.67x higher ceiling for the same fp32-accurate result
+// (dense bf16 peak / 6 = 417 TFLOP/s of fp32-equivalent work against 157 TFLOP/s).
+//
+// Layout.  The A tile is staged exactly as in gemm_core.h (LDS-DMA of fp32 rows, 64 B per row and chunk of 16 k, XOR-swizzled
+// source); a lane's two ds_read_b128 of it are the 8 consecutive k of row (lane & 31) at k offset 8 (lane >> 5) -- the A operand
+// layout of the 32x32x16 MFMA -- and are split in registers (VALU, in the shadow of the running MFMAs).  W is constant for the
+// frozen ViT and pre-split once on the host side into planes [3][N][K] bf16; a chunk of a plane is 32 B per row (two 16-B slots,
+// slot s of row r stored at s ^ ((r >> 3) & 1)), moved by the same LDS-DMA.
+//
+// Ring: two stages, one barrier per chunk -- top of chunk kc: vmcnt(0) [my pieces of chunk kc landed], s_barrier [everyone's
+// did, and everyone has finished reading the other stage], issue the DMA of chunk kc+1 into the other stage, compute chunk kc.
+// MFMAs, splits and fragment reads are left to the compiler's scheduler here (48 MFMAs of 32 cycles per wavefront and chunk
+// against 14 ds_read_b128 and ~180 VALU instructions: nothing is tight), only the DMA and the synchronisation are asm.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gemm_core.h"
+
+namespace scp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+template <int WM_, int WN_, int NWM_, int NWN_, int MINBLK_>
+struct SplitCfg {
+    static constexpr int WM = WM_, WN = WN_, NWM = NWM_, NWN = NWN_, NSTAGE = 2, MINBLK = MINBLK_;
+    static constexpr int BM = 32 * WM * NWM, BN = 32 * WN * NWN, BK = 16;
+    static constexpr int NW = NWM * NWN, THREADS = 64 * NW;
+    static constexpr int A_PIECES = BM / 16;                  // 16 rows x 64 B
+    static constexpr int W_GROUPS = BN / 32, W_PIECES = 3 * W_GROUPS;   // 32 rows x 32 B, three planes
+    static_assert(A_PIECES % NW == 0 && W_PIECES % NW == 0, "pieces are dealt evenly to the wavefronts");
+    static constexpr int A_PER = A_PIECES / NW, W_PER = W_PIECES / NW, PER = A_PER + W_PER;
+    static constexpr int A_BYTES = BM * 64, PLANE_BYTES = BN * 32;
+    static constexpr int STAGE_BYTES = A_BYTES + 3 * PLANE_BYTES, LDS_BYTES = NSTAGE * STAGE_BYTES;
+    static constexpr int NT = WM * WN;
+};
+
+struct Split3 { bf16x8 h, m, l; };
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 pair (round to nearest even): one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {lo, hi};
+    const bf16x2 r = __builtin_convertvector(v, bf16x2);
+    return __builtin_bit_cast(unsigned, r);
+}
+// x = h + m + l exactly, pairwise: 11 VALU instructions per two values (cvt, 2 unpack, 2 sub, cvt, 2 unpack, 2 sub, cvt)
+__device__ __forceinline__ Split3 split3(f32x8 x) {
+    u32x4 h, m, l;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const float x0 = x[2 * p], x1 = x[2 * p + 1];
+        h[p] = pack_bf16(x0, x1);
+        const float r0 = x0 - __uint_as_float(h[p] << 16), r1 = x1 - __uint_as_float(h[p] & 0xffff0000u);
+        m[p] = pack_bf16(r0, r1);
+        const float s0 = r0 - __uint_as_float(m[p] << 16), s1 = r1 - __uint_as_float(m[p] & 0xffff0000u);
+        l[p] = pack_bf16(s0, s1);
+    }
+    Split3 s;
+    s.h = __builtin_bit_cast(bf16x8, h);
+    s.m = __builtin_bit_cast(bf16x8, m);
+    s.l = __builtin_bit_cast(bf16x8, l);
+    return s;
+}
+
+template <class CFG>
+struct SplitGemmCore {
+    struct Acc { f32x16 t[CFG::NT]; };
+
+    const char* a_base;
+    const char* w_base;
+    unsigned a_off[CFG::A_PER], w_off[CFG::W_PER];
+    char* lds;                     // generic pointer to the ring (compiler-visible reads)
+    unsigned lds0;                 // its LDS byte address (DMA destinations)
+    unsigned a_rd[2], w_rd;        // lane's fragment byte offsets inside a stage (tile 0)
+    int wave, lane;
+
+    __device__ __forceinline__ SplitGemmCore(float* lds_) {
+        lds = reinterpret_cast<char*>(lds_);
+        lds0 = SCP_LDS_ADDR(lds_);
+        lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int half = lane >> 5, l31 = lane & 31;
+        const int ra = row_base() + l31, rw = col_base() + l31;
+#pragma unroll
+        for (int c = 0; c < 2; c++) a_rd[c] = ra * 64 + 16 * ((2 * half + c) ^ ((ra >> 2) & 3));
+        w_rd = CFG::A_BYTES + rw * 32 + 16 * (half ^ ((rw >> 3) & 1));
+    }
+    __device__ __forceinline__ int row_base() const { return 32 * CFG::WM * (wave / CFG::NWN); }
+    __device__ __forceinline__ int col_base() const { return 32 * CFG::WN * (wave % CFG::NWN); }
+
+    // A [M,K] fp32 row-major; W3 = planes [3][N][K] bf16 (h, m, l); a_row / w_row map a tile row to its source row
+    template <class FA, class FW>
+    __device__ __forceinline__ void set_rows(const float* A, const void* W3, int N, int K, FA a_row, FW w_row) {
+        a_base = reinterpret_cast<const char*>(A);
+        w_base = reinterpret_cast<const char*>(W3);
+        {
+            const int prow = lane >> 2, pslot = lane & 3, chunk = pslot ^ ((prow >> 2) & 3);
+#pragma unroll
+            for (int i = 0; i < CFG::A_PER; i++)
+                a_off[i] = ((unsigned)a_row(16 * (wave * CFG::A_PER + i) + prow) * (unsigned)K + 4u * chunk) * 4u;
+        }
+        {
+            const int prow = lane >> 1, pslot = lane & 1;
+#pragma unroll
+            for (int i = 0; i < CFG::W_PER; i++) {
+                const int q = wave * CFG::W_PER + i, plane = q / CFG::W_GROUPS, r = 32 * (q % CFG::W_GROUPS) + prow;
+                const int slot = pslot ^ ((r >> 3) & 1);
+                w_off[i] = ((unsigned)plane * (unsigned)N * (unsigned)K + (unsigned)w_row(r) * (unsigned)K + 8u * slot) * 2u;
+            }
+        }
+    }
+    __device__ __forceinline__ void set_linear_sources(const float* A, const void* W3, int m0, int n0, int M, int N, int K) {
+        set_rows(A, W3, N, K, [&](int r) { return min(m0 + r, M - 1); }, [&](int r) { return min(n0 + r, N - 1); });
+    }
+
+    __device__ __forceinline__ void issue(int kc, int stage) const {
+        const unsigned dst = lds0 + stage * CFG::STAGE_BYTES;
+        static_for<0, CFG::A_PER>([&](auto i) {
+            constexpr int I = decltype(i)::value;
+            glds16(a_off[I], a_base + (size_t)kc * 64, dst + (unsigned)(wave * CFG::A_PER + I) * 1024u);
+        });
+        static_for<0, CFG::W_PER>([&](auto i) {
+            constexpr int I = decltype(i)::value;
+            glds16(w_off[I], w_base + (size_t)kc * 32, dst + CFG::A_BYTES + (unsigned)(wave * CFG::W_PER + I) * 1024u);
+        });
+    }
+
+    template <int S>
+    __device__ __forceinline__ void compute(Acc& acc) const {
+        const char* st = lds + S * CFG::STAGE_BYTES;
+        bf16x8 wf[3][CFG::WN];
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int j = 0; j < CFG::WN; j++) wf[p][j] = *reinterpret_cast<const bf16x8*>(st + w_rd + p * CFG::PLANE_BYTES + j * 1024);
+#pragma unroll
+        for (int i = 0; i < CFG::WM; i++) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(st + a_rd[0] + i * 2048);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(st + a_rd[1] + i * 2048);
+            const f32x8 x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const Split3 a = split3(x);
+            // smallest terms first; six products per accumulator tile, tiles interleaved so that consecutive MFMAs are independent
+#pragma unroll
+            for (int j = 0; j < CFG::WN; j++) acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, wf[1][j], acc.t[i * CFG::WN + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < CFG::WN; j++) acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, wf[0][j], acc.t[i * CFG::WN + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < CFG::WN; j++) acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, wf[2][j], acc.t[i * CFG::WN + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < CFG::WN; j++) acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, wf[0][j], acc.t[i * CFG::WN + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < CFG::WN; j++) acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, wf[1][j], acc.t[i * CFG::WN + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < CFG::WN; j++) acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, wf[0][j], acc.t[i * CFG::WN + j], 0, 0, 0);
+        }
+    }
+
+    // acc = sum over nk chunks of 16 k (nk even and >= 2)
+    __device__ __forceinline__ void run(Acc& acc, int nk) {
+#pragma unroll
+        for (int t = 0; t < CFG::NT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc.t[t][r] = 0.f;
+        issue(0, 0);
+        for (int kc = 0; kc < nk; kc += 2) {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#ifndef SCP_SPLIT_PROBE_NODMA
+            issue(kc + 1, 1);
+#else
+            if (kc == 0) issue(kc + 1, 1);
+#endif
+            compute<0>(acc);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#ifndef SCP_SPLIT_PROBE_NODMA
+            if (kc + 2 < nk) issue(kc + 2, 0);
+#endif
+            compute<1>(acc);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+};
+
+}  // namespace scp

@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 
 #include "gemm_core.h"
+#include "gemm_core_split.h"
 #include "scp_common.h"
 #include "scp_hip.h"
 
@@ -47,13 +48,19 @@ using scp::f32x4;
 
 using BigCfg = scp::GemmCfg<4, 2, 2, 2, 2, 2>;      // 256 x 128, 2-stage ring = 48 KiB
 using QtrCfg = scp::GemmCfg<1, 2, 2, 2, 2, 2>;      //  64 x 128
+// the same two tile shapes on the bf16 matrix cores with exactly split operands (csrc/gemm_core_split.h): selected per call by
+// SCP_GEMM_W_SPLIT3, W then points to the three bf16 planes of the weight (scp_split_bf16x3)
+using BigSplit = scp::SplitCfg<4, 2, 2, 2, 2>;      // 256 x 128, 2-stage ring = 56 KiB
+using QtrSplit = scp::SplitCfg<1, 2, 2, 2, 2>;      //  64 x 128
 constexpr int THREADS = 256;
 constexpr int BN = 128, QM = 64;                    // column block; row quarter
 static_assert(BigCfg::BN == BN && QtrCfg::BN == BN && BigCfg::BM == 4 * QM && QtrCfg::BM == QM, "tile shapes");
+static_assert(BigSplit::BN == BN && QtrSplit::BN == BN && BigSplit::BM == 4 * QM && QtrSplit::BM == QM, "tile shapes");
+static_assert(BigSplit::THREADS == THREADS && BigCfg::THREADS == THREADS, "one block size");
 
 struct GemmArgs {
     const float* A;        // [M, K]
-    const float* W;        // [N, K]
+    const void* W;         // [N, K] fp32, or the planes [3][N][K] bf16 of the split path
     const float* vec0;     // EPI_LN*: s[N]            EPI_BIAS*: bias[N]
     const float* vec1;     // EPI_LN*: t[N]
     const float* rowstat;  // EPI_LN*: (mean, rstd)[M]
@@ -107,12 +114,11 @@ __device__ __forceinline__ int xcd_order(int t, int n) {
     return (t & 7) * per_xcd + (t >> 3);
 }
 
-template <class CFG, int EPI, bool INDEXED>
+template <class CFG, class Core, int EPI, bool INDEXED>
 __device__ __forceinline__ void run_tile(const GemmArgs& g, float* lds, int M, int m0, int n0) {
-    using Core = scp::GemmCore<CFG>;
     Core core(lds);
-    core.src.set_rows(
-        g.A, g.W, g.K, core.wave, core.lane,
+    core.set_rows(
+        g.A, g.W, g.N, g.K,
         [&](int r) {
             const int m = min(m0 + r, M - 1);
             return (INDEXED && g.a_rows) ? g.a_rows[m] : m;
@@ -175,9 +181,13 @@ __device__ __forceinline__ void run_tile(const GemmArgs& g, float* lds, int M, i
     }
 }
 
-template <int EPI, bool INDEXED>
+template <int EPI, bool INDEXED, bool SPLIT>
 __global__ __launch_bounds__(THREADS, 2) void vit_gemm_kernel(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float lds[BigCfg::LDS_BYTES / 4];
+    using Big = std::conditional_t<SPLIT, BigSplit, BigCfg>;
+    using Qtr = std::conditional_t<SPLIT, QtrSplit, QtrCfg>;
+    using BigCore = std::conditional_t<SPLIT, scp::SplitGemmCore<BigSplit>, scp::GemmCore<BigCfg>>;
+    using QtrCore = std::conditional_t<SPLIT, scp::SplitGemmCore<QtrSplit>, scp::GemmCore<QtrCfg>>;
+    __shared__ __attribute__((aligned(16))) float lds[Big::LDS_BYTES / 4];
     // row count: host value, or read from the device (rows selected by an earlier kernel, no host round trip)
     int M = g.M;
     if (g.m_dev) M = min(max(__builtin_amdgcn_readfirstlane(*g.m_dev), 0), g.M);
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(THREADS, 2) void vit_gemm_kernel(const GemmArgs g) 
         if (lid >= p.nbig) return;
         const int bm = lid / g.nblk_n, bn = lid - bm * g.nblk_n;
         clock_start(g);
-        run_tile<BigCfg, EPI, INDEXED>(g, lds, M, bm * BigCfg::BM, bn * BN);
+        run_tile<Big, BigCore, EPI, INDEXED>(g, lds, M, bm * Big::BM, bn * BN);
         clock_end(g);
         return;
     }
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(THREADS, 2) void vit_gemm_kernel(const GemmArgs g) 
         m0 = p.panels * BigCfg::BM + sub * QM;
     }
     clock_start(g);
-    run_tile<QtrCfg, EPI, INDEXED>(g, lds, M, m0, bn * BN);
+    run_tile<Qtr, QtrCore, EPI, INDEXED>(g, lds, M, m0, bn * BN);
     clock_end(g);
 }
 
@@ -303,6 +313,19 @@ __global__ __launch_bounds__(256) void row_stats384_kernel(const float* __restri
     }
 }
 
+// x -> planes [3][n] bf16 with x = h + m + l exactly (csrc/gemm_core_split.h)
+__global__ void split_bf16x3_kernel(const float* __restrict__ x, __bf16* __restrict__ planes, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    const __bf16 h = (__bf16)v;
+    const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    planes[i] = h;
+    planes[n + i] = m;
+    planes[2 * n + i] = (__bf16)(r1 - (float)m);
+}
+
 // scp_kernel_clock_begin / _end: while a slot buffer is installed every vit_linear launch gets the next slot
 unsigned long long* g_clock_slots = nullptr;
 int g_clock_n = 0, g_clock_i = 0;
@@ -319,26 +342,41 @@ int device_slots() {
     return slots;
 }
 
-template <int EPI>
+template <int EPI, bool SPLIT>
 void launch(const GemmArgs& g, hipStream_t st) {
     const Plan p = make_plan(g.M, g.nblk_n, g.slots);
     // with a device-side row count the kernel redoes the plan: its big segment is never longer than the host's (nbig is
     // monotone in M) and its quarter segment never longer than quarter_cap
     const int grid = p.big_pad + (g.m_dev ? quarter_cap(g.nblk_n, g.slots) : p.q_pad);
     // the row-index variant is a separate instantiation: the plain one keeps its register allocation
-    if (g.a_rows || g.c_rows) hipLaunchKernelGGL((vit_gemm_kernel<EPI, true>), dim3(max(grid, 1)), dim3(THREADS), 0, st, g);
-    else hipLaunchKernelGGL((vit_gemm_kernel<EPI, false>), dim3(max(grid, 1)), dim3(THREADS), 0, st, g);
+    if (g.a_rows || g.c_rows) hipLaunchKernelGGL((vit_gemm_kernel<EPI, true, SPLIT>), dim3(max(grid, 1)), dim3(THREADS), 0, st, g);
+    else hipLaunchKernelGGL((vit_gemm_kernel<EPI, false, SPLIT>), dim3(max(grid, 1)), dim3(THREADS), 0, st, g);
 }
 
 }  // namespace
 
 namespace {
-int vit_linear_impl(const float* A, const float* W, const float* vec0, const float* vec1, const float* rowstat, const float* resid,
+template <bool SPLIT>
+int dispatch(const GemmArgs& g, int epilogue, hipStream_t st) {
+    switch (epilogue) {
+        case SCP_GEMM_BIAS: launch<SCP_GEMM_BIAS, SPLIT>(g, st); break;
+        case SCP_GEMM_BIAS_RESIDUAL: launch<SCP_GEMM_BIAS_RESIDUAL, SPLIT>(g, st); break;
+        case SCP_GEMM_LN: launch<SCP_GEMM_LN, SPLIT>(g, st); break;
+        case SCP_GEMM_LN_GELU: launch<SCP_GEMM_LN_GELU, SPLIT>(g, st); break;
+        default: return scp::fail(hipErrorInvalidValue, "vit_linear: unknown epilogue");
+    }
+    return 0;
+}
+
+int vit_linear_impl(const float* A, const void* W, const float* vec0, const float* vec1, const float* rowstat, const float* resid,
                     float* C, int M, const int* m_dev, const int* a_rows, const int* c_rows, int N, int K, int epilogue, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return scp::fail(hipErrorInvalidValue, "vit_linear: empty problem");
     if (K % (BigCfg::NSTAGE * BigCfg::BK) != 0) return scp::fail(hipErrorInvalidValue, "vit_linear: K must be a multiple of 32");
     if ((size_t)M * (size_t)K >= (1ull << 30) || (size_t)N * (size_t)K >= (1ull << 30))
         return scp::fail(hipErrorInvalidValue, "vit_linear: operand larger than 2^30 elements");
+    const bool split = (epilogue & SCP_GEMM_W_SPLIT3) != 0;
+    epilogue &= ~SCP_GEMM_W_SPLIT3;
+    if (split && 3 * (size_t)N * (size_t)K >= (1ull << 31)) return scp::fail(hipErrorInvalidValue, "vit_linear: split weight larger than 2^32 bytes");
     const bool ln = epilogue == SCP_GEMM_LN || epilogue == SCP_GEMM_LN_GELU;
     if (!vec0 || (ln && (!vec1 || !rowstat)) || (epilogue == SCP_GEMM_BIAS_RESIDUAL && !resid))
         return scp::fail(hipErrorInvalidValue, "vit_linear: missing epilogue operand");
@@ -349,23 +387,18 @@ int vit_linear_impl(const float* A, const float* W, const float* vec0, const flo
     g.slots = device_slots();
     g.clock = (g_clock_slots && g_clock_i < g_clock_n) ? g_clock_slots + 2 * (g_clock_i++) : nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    switch (epilogue) {
-        case SCP_GEMM_BIAS: launch<SCP_GEMM_BIAS>(g, st); break;
-        case SCP_GEMM_BIAS_RESIDUAL: launch<SCP_GEMM_BIAS_RESIDUAL>(g, st); break;
-        case SCP_GEMM_LN: launch<SCP_GEMM_LN>(g, st); break;
-        case SCP_GEMM_LN_GELU: launch<SCP_GEMM_LN_GELU>(g, st); break;
-        default: return scp::fail(hipErrorInvalidValue, "vit_linear: unknown epilogue");
-    }
+    const int bad = split ? dispatch<true>(g, epilogue, st) : dispatch<false>(g, epilogue, st);
+    if (bad) return bad;
     return scp::check_launch("vit_linear");
 }
 }  // namespace
 
-extern "C" int scp_vit_linear(const float* A, const float* W, const float* vec0, const float* vec1, const float* rowstat,
+extern "C" int scp_vit_linear(const float* A, const void* W, const float* vec0, const float* vec1, const float* rowstat,
                               const float* resid, float* C, int M, int N, int K, int epilogue, void* stream) {
     return vit_linear_impl(A, W, vec0, vec1, rowstat, resid, C, M, nullptr, nullptr, nullptr, N, K, epilogue, stream);
 }
 
-extern "C" int scp_vit_linear_rows(const float* A, const float* W, const float* vec0, const float* vec1, const float* rowstat,
+extern "C" int scp_vit_linear_rows(const float* A, const void* W, const float* vec0, const float* vec1, const float* rowstat,
                                    const float* resid, float* C, const int* rows_dev, int max_rows, const int* a_rows,
                                    const int* c_rows, int N, int K, int epilogue, void* stream) {
     if (!rows_dev) return scp::fail(hipErrorInvalidValue, "vit_linear_rows: null row count");
@@ -397,4 +430,12 @@ extern "C" int scp_kernel_clock_end(void) {
     g_clock_slots = nullptr;
     g_clock_n = g_clock_i = 0;
     return used;
+}
+
+extern "C" int scp_split_bf16x3(const float* x, void* planes, size_t n, void* stream) {
+    if (n == 0) return 0;
+    if (!x || !planes) return scp::fail(hipErrorInvalidValue, "split_bf16x3: null argument");
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       static_cast<__bf16*>(planes), n);
+    return scp::check_launch("split_bf16x3");
 }

@@ -57,6 +57,7 @@ SYMBOLS = {
     "scp_fvm_backward": (ctypes.c_int, [_P] * 5 + [ctypes.c_float] * 2 + [ctypes.c_int] * 5 + [_P] * 10),
     "scp_kernel_clock_begin": (ctypes.c_int, [_P, _I]),
     "scp_kernel_clock_end": (ctypes.c_int, []),
+    "scp_split_bf16x3": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P]),
     "scp_row_mean_rstd": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, _P]),
     "scp_softargmax_cols_workspace": (ctypes.c_size_t, [_I, _I, _I]),
     "scp_softargmax_cols_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P, _P, _P, ctypes.c_size_t, _P]),

@@ -144,10 +144,30 @@ def add_layernorm(x, branch, norm):
 GEMM_BIAS, GEMM_BIAS_RESIDUAL, GEMM_LN, GEMM_LN_GELU = 0, 1, 2, 3      # include/scp_hip.h SCP_GEMM_*
 
 
+GEMM_W_SPLIT3 = 0x100                                                    # include/scp_hip.h SCP_GEMM_W_SPLIT3
+# "split": products on the bf16 matrix cores with exactly split operands (fp32 = h + m + l in bf16, six partial products, fp32
+# accumulation -- csrc/gemm_core_split.h; as close to float64 as the fp32 matrix cores, ~1.5x their rate).
+# "fp32": v_mfma_f32_32x32x2_f32.  SCP_VIT_GEMM=fp32 in the environment selects the latter for a whole process.
+GEMM_MODE = os.environ.get("SCP_VIT_GEMM", "split")
+
+
+def split_weight(w):
+    """planes [3,N,K] bf16 (h, m, l) with w = h + m + l exactly (scp_split_bf16x3).  The ViT blocks keep the planes of their
+    frozen weights next to the LayerNorm-folded copies (_Block._folded); a call without `w_split` splits on the fly."""
+    from . import capi
+    w = w.detach().contiguous()
+    planes = torch.empty((3,) + tuple(w.shape), dtype=torch.bfloat16, device=w.device)
+    capi.check(capi.lib().scp_split_bf16x3(capi.dev_ptr(w, "w"), ctypes.c_void_p(planes.data_ptr()), w.numel(),
+                                           capi.current_stream()), "scp_split_bf16x3")
+    return planes
+
+
 def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilogue=GEMM_BIAS, rows=None, a_rows=None, c_rows=None,
-               max_rows=None):
-    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T) on the fp32 matrix cores (csrc/vit_gemm.hip, include/scp_hip.h
-    scp_vit_linear); `resid` may be `out` itself (in-place residual stream).  Forward only, GPU tensors only.
+               max_rows=None, mode=None, w_split=None):
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T) on the matrix cores (csrc/vit_gemm.hip, include/scp_hip.h scp_vit_linear);
+    `resid` may be `out` itself (in-place residual stream).  Forward only, GPU tensors only.  `mode` (default GEMM_MODE):
+    "split" = bf16 matrix cores on exactly split operands (`w_split` = split_weight(w) if the caller keeps it), "fp32" = fp32
+    matrix cores; both are fp32-accurate.
     Row selection made on the device (scp_vit_linear_rows): `rows` = int32 device scalar, only the first rows[0] GEMM rows
     are computed and the host never reads the count; GEMM row m reads a[a_rows[m]] and uses rowstat / resid / out row
     c_rows[m] (int32 index lists, None = identity); untouched rows of `out` keep their contents."""
@@ -159,8 +179,20 @@ def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilog
     if out is None:
         out = torch.empty(m, n, dtype=torch.float32, device=a.device)
     L = capi.lib()
+    mode = GEMM_MODE if mode is None else mode
+    if mode == "split":
+        if w_split is None:
+            w_split = split_weight(w)
+        if not (w_split.is_cuda and w_split.dtype == torch.bfloat16 and w_split.is_contiguous() and tuple(w_split.shape) == (3, n, k)):
+            raise RuntimeError("vit_linear: w_split must be the contiguous [3,%d,%d] bfloat16 planes of w" % (n, k))
+        w_ptr = ctypes.c_void_p(w_split.data_ptr())
+        epilogue = epilogue | GEMM_W_SPLIT3
+    elif mode == "fp32":
+        w_ptr = capi.dev_ptr(w, "w")
+    else:
+        raise RuntimeError("vit_linear: unknown mode %r" % (mode,))
     if rows is None:
-        code = L.scp_vit_linear(capi.dev_ptr(a, "a"), capi.dev_ptr(w, "w"), capi.dev_ptr(vec0, "vec0"),
+        code = L.scp_vit_linear(capi.dev_ptr(a, "a"), w_ptr, capi.dev_ptr(vec0, "vec0"),
                                 capi.opt_ptr(vec1, "vec1"), capi.opt_ptr(rowstat, "rowstat"),
                                 capi.opt_ptr(resid, "resid"), capi.dev_ptr(out, "out"), m, n, k, epilogue,
                                 capi.current_stream())
@@ -170,7 +202,7 @@ def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilog
                 raise RuntimeError("vit_linear: %s must be a contiguous int32 device tensor" % name)
         max_rows = min(m, out.shape[0]) if max_rows is None else max_rows
         ip = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
-        code = L.scp_vit_linear_rows(capi.dev_ptr(a, "a"), capi.dev_ptr(w, "w"), capi.dev_ptr(vec0, "vec0"),
+        code = L.scp_vit_linear_rows(capi.dev_ptr(a, "a"), w_ptr, capi.dev_ptr(vec0, "vec0"),
                                      capi.opt_ptr(vec1, "vec1"), capi.opt_ptr(rowstat, "rowstat"),
                                      capi.opt_ptr(resid, "resid"), capi.dev_ptr(out, "out"), ip(rows), max_rows, ip(a_rows),
                                      ip(c_rows), n, k, epilogue, capi.current_stream())
@@ -215,14 +247,22 @@ class _Block(nn.Module):
 
     # ---- fused path (fp32, GPU): four GEMM launches + two row-statistics launches + attention per block -------------
     def _folded(self):
-        """(gamma1 o Wqkv, s, t), (gamma2 o W1, s, t), rebuilt when any of the frozen tensors changes (load_state_dict)"""
+        """(gamma1 o Wqkv, s, t), (gamma2 o W1, s, t), rebuilt when any of the frozen tensors changes (load_state_dict);
+        the bf16 planes of the five weight matrices the fused path multiplies with are rebuilt with them (self._planes)"""
         src = (self.norm1.weight, self.norm1.bias, self.attn.qkv.weight, self.attn.qkv.bias,
-               self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias)
-        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in src)
+               self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias, self.attn.proj.weight, self.mlp.fc2.weight)
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in src) + (GEMM_MODE,)
         if getattr(self, "_fold_key", None) != key:
             with torch.no_grad():
                 self._fold = (fold_layernorm(self.norm1, self.attn.qkv.weight, self.attn.qkv.bias),
                               fold_layernorm(self.norm2, self.mlp.fc1.weight, self.mlp.fc1.bias))
+                c = self.norm1.weight.shape[0]
+                wq, w1 = self._fold[0][0], self._fold[1][0]
+                if GEMM_MODE == "split" and wq.is_cuda:
+                    self._planes = dict(qkv=split_weight(wq), k=split_weight(wq[c:2 * c]), fc1=split_weight(w1),
+                                        proj=split_weight(self.attn.proj.weight), fc2=split_weight(self.mlp.fc2.weight))
+                else:
+                    self._planes = dict(qkv=None, k=None, fc1=None, proj=None, fc2=None)
             self._fold_key = key
         return self._fold
 
@@ -231,11 +271,12 @@ class _Block(nn.Module):
         (vision_transformer_flexible.py:126-132)."""
         (wq, sq, tq), (w1, s1, t1) = self._folded()
         a = self.attn
-        qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN)
+        sp = self._planes
+        qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN, w_split=sp["qkv"])
         y = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, x2d.shape[1] // a.num_heads, a.scale)
-        vit_linear(y.view(b * n, -1), a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL)
-        h = vit_linear(x2d, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), epilogue=GEMM_LN_GELU)
-        vit_linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL)
+        vit_linear(y.view(b * n, -1), a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["proj"])
+        h = vit_linear(x2d, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), epilogue=GEMM_LN_GELU, w_split=sp["fc1"])
+        vit_linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["fc2"])
         return x2d
 
     def tail_keys_fused(self, x2d, b, n, keep, key_block):
@@ -248,7 +289,8 @@ class _Block(nn.Module):
         (wq, sq, tq), (w1, s1, t1) = self._folded()
         a = self.attn
         c = x2d.shape[1]
-        qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN)
+        sp = self._planes
+        qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN, w_split=sp["qkv"])
         # attention: keys / values of all tokens, queries only for the kept ones (per image, compacted to the front of the
         # query slots; their outputs land on their own rows)
         k8 = keep.to(torch.uint8)
@@ -262,15 +304,17 @@ class _Block(nn.Module):
         sel = dict(rows=rows, max_rows=m)
         # x[idx] += proj(y[idx]);  h = gelu(fc1(LN2 x[idx]));  x[idx] += fc2(h);  k[idx] = Wk LN1(x[idx]) -- rows addressed
         # through the index list inside the GEMM (no gather / scatter copies); statistics are taken for all rows (11 us)
-        vit_linear(y, a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, a_rows=idx, c_rows=idx, **sel)
+        vit_linear(y, a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, a_rows=idx, c_rows=idx,
+                   w_split=sp["proj"], **sel)
         h = torch.empty(m, w1.shape[0], dtype=torch.float32, device=x2d.device)           # only the kept rows are written / read
-        vit_linear(x2d, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), out=h, epilogue=GEMM_LN_GELU, a_rows=idx, c_rows=idx, **sel)
+        vit_linear(x2d, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), out=h, epilogue=GEMM_LN_GELU, a_rows=idx, c_rows=idx,
+                   w_split=sp["fc1"], **sel)
         vit_linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, a_rows=idx, c_rows=idx,
-                   **sel)
+                   w_split=sp["fc2"], **sel)
         (kq, ks, kt), _ = key_block._folded()
         k = torch.zeros(m, c, dtype=torch.float32, device=x2d.device)
         vit_linear(x2d, kq[c:2 * c], ks[c:2 * c], kt[c:2 * c], row_mean_rstd(x2d, key_block.norm1.eps), out=k, epilogue=GEMM_LN,
-                   a_rows=idx, c_rows=idx, **sel)
+                   a_rows=idx, c_rows=idx, w_split=key_block._planes["k"], **sel)
         heads = key_block.attn.num_heads
         return k.view(b, n, heads, c // heads).permute(0, 2, 1, 3)
 
@@ -278,7 +322,8 @@ class _Block(nn.Module):
         """K third of qkv(LN1(x)): [b, heads, n, d]  (the only part of block 9 the DINO features need)"""
         (wq, sq, tq), _ = self._folded()
         c = x2d.shape[1]
-        k = vit_linear(x2d, wq[c:2 * c], sq[c:2 * c], tq[c:2 * c], row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN)
+        k = vit_linear(x2d, wq[c:2 * c], sq[c:2 * c], tq[c:2 * c], row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN,
+                       w_split=self._planes["k"])
         return k.view(b, n, self.attn.num_heads, c // self.attn.num_heads).permute(0, 2, 1, 3)
 
 

@@ -134,9 +134,18 @@ def test_bf16_attention_vs_fp32_oracle(B, N, H):
 # ------------------------------------------------------------------------------------------------------------------
 # fp32-MFMA linear layers with fused LayerNorm / GELU / residual (csrc/vit_gemm.hip)
 # ------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(params=["split", "fp32"])
+def gemm_mode(request):
+    """both matrix-core paths of scp_vit_linear: bf16 cores on exactly split operands (the default) and fp32 cores"""
+    from scp_amd import dino
+    old, dino.GEMM_MODE = dino.GEMM_MODE, request.param
+    yield request.param
+    dino.GEMM_MODE = old
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,K,N", [(1025 * 3, 384, 1152), (130, 64, 200), (32, 1536, 384), (257, 384, 1536), (1, 32, 1)])
-def test_vit_linear_epilogues_vs_float64(M, K, N):
+def test_vit_linear_epilogues_vs_float64(M, K, N, gemm_mode):
     """all four epilogues, ragged M (remainder panel path) and N not a multiple of the 128-column tile, against float64.
     Tolerance 1e-5 of the output scale (fp32 accumulation over K <= 1536 in MFMA order)."""
     from scp_amd import dino
@@ -172,7 +181,7 @@ def test_vit_linear_epilogues_vs_float64(M, K, N):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,N", [(2, 1025), (3, 197)])
-def test_fused_block_matches_oracle(B, N):
+def test_fused_block_matches_oracle(B, N, gemm_mode):
     """one transformer block through the fused path (2 row-stat + 4 GEMM + attention launches) against the oracle's
     spelled-out Block.forward in float64; also block 9's K slice"""
     from scp_amd import dino
@@ -197,7 +206,32 @@ def test_fused_block_matches_oracle(B, N):
 
 
 @pytest.mark.gpu
-def test_vit_linear_with_device_row_count():
+def test_split_path_is_as_accurate_as_the_fp32_cores():
+    """The split path is an fp32 computation, not a reduced-precision one: every operand is represented exactly (three bf16 terms)
+    and only partial products below 2^-24 |a b| are dropped.  Against float64 its error must not exceed the fp32 matrix cores' on
+    the same data -- wide dynamic range in A (exponents over 2^+-6), K = 1536, M crossing the big / quarter tile boundary."""
+    from scp_amd import dino
+    g = torch.Generator().manual_seed(17)
+    M, K, N = 1025 * 2 + 37, 1536, 384
+    a = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-6, 7, (M, K), generator=g).float())).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05 * torch.exp2(torch.randint(-4, 5, (N, K), generator=g).float())).cuda()
+    b = torch.zeros(N, device="cuda")
+    ref = a.double() @ w.double().t()
+    planes = dino.split_weight(w)
+    assert torch.equal(planes.float().double().sum(0), w.double()), "w = h + m + l must hold exactly"
+    err = {}
+    for mode in ("split", "fp32"):
+        got = dino.vit_linear(a, w, b, mode=mode)
+        d = got.double() - ref
+        err[mode] = (d.abs().max().item(), d.square().mean().sqrt().item())
+    scale = ref.abs().max().item()
+    print("max / rms error vs float64 (scale %.3e): split %.3e / %.3e, fp32 cores %.3e / %.3e" % ((scale,) + err["split"] + err["fp32"]))
+    assert err["split"][0] <= 1.25 * err["fp32"][0] and err["split"][1] <= 1.1 * err["fp32"][1]
+    assert err["split"][0] <= 2e-6 * scale
+
+
+@pytest.mark.gpu
+def test_vit_linear_with_device_row_count(gemm_mode):
     """scp_vit_linear_rows: only the first rows[0] rows are computed (bitwise equal to the full launch), the rest is untouched"""
     from scp_amd import dino
     g = torch.Generator().manual_seed(5)

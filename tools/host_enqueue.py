@@ -43,3 +43,14 @@ wall = time.perf_counter() - t_all
 print("host enqueue per step: " + ", ".join("%s %.2f ms" % (k, v / N * 1e3) for k, v in acc.items()))
 print("host loop %.2f ms/step, synchronised %.2f ms/step (queue drained %.2f ms after the last enqueue)"
       % (host / N * 1e3, wall / N * 1e3, (wall - host) * 1e3))
+
+# pure host cost: each step starts on an EMPTY queue (synchronised before), so no enqueue can block on a full queue
+costs = []
+for _ in range(10):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.step(data)
+    costs.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+costs.sort()
+print("host time of one step enqueued on an empty queue: median %.2f ms, min %.2f ms" % (costs[len(costs) // 2] * 1e3, costs[0] * 1e3))
