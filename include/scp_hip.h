@@ -287,21 +287,23 @@ int scp_batchnorm_act_backward_bf16(const void* dy, const void* x, const void* y
  *   partials (or NULL): [2][tiles_m][Cout] per-tile column sums of the RAW output, then of its squares, over the tile's
  *   rows_per_tile output pixels (scp_conv_nhwc_partial_rows gives both numbers) -- the BatchNorm that follows folds them into
  *   its batch statistics instead of re-reading y (scp_batchnorm_act_forward_partials).
+ *   w_split (or NULL): the planes [3][Cout][k k Cin] bf16 of w (scp_split_bf16x3 on the channels_last weight); then the products
+ *   run on the bf16 matrix cores with exactly split operands (csrc/gemm_core_split.h; fp32-accurate) and w may be NULL.
  * The input gradient of a stride-1 convolution is the same call with dy as x, Cin <-> Cout and w transposed + flipped
  * ([Cin,k,k,Cout], tap (k-1-ky, k-1-kx)).  Requires Cin a power of two >= 32, k in {1, 3}, stride in {1, 2}
  * (else hipErrorInvalidValue: the caller keeps its library convolution -- the 7x7 stem does).
  * scp_conv_nhwc_weight_grad: dw [Cout,k,k,Cin] = sum over output pixels of dy[p][co] x[p + tap][ci]; x [N,H,W,Cin],
  *   dy [N,Ho,Wo,Cout]; workspace >= scp_conv_nhwc_weight_grad_workspace(...) bytes (partial sums of the pixel split, folded in a
  *   fixed order: deterministic); dbias (or NULL): [Cout] = sum over pixels of dy. */
-int scp_conv_nhwc_forward(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int H, int W,
-                          int Cin, int Cout, int ksize, int stride, int leaky, float slope, void* stream);
-int scp_conv_nhwc_partial_rows(int N, int H, int W, int Cout, int ksize, int stride, int* tiles_m, int* rows_per_tile);
+int scp_conv_nhwc_forward(const float* x, const float* w, const void* w_split, const float* bias, float* y, float* partials, int N,
+                          int H, int W, int Cin, int Cout, int ksize, int stride, int leaky, float slope, void* stream);
+int scp_conv_nhwc_partial_rows(int N, int H, int W, int Cout, int ksize, int stride, int split, int* tiles_m, int* rows_per_tile);
 /* convolution (no bias) + the batch statistics of the nn.BatchNorm2d that follows it (training mode), one launch: the per-tile
  * partial sums go to `workspace` (>= 2 * tiles_m * Cout floats), the last workgroup of the launch (ticket: a zeroed device word,
  * re-armed by the kernel) folds them in fp64 in tile order and writes save_mean / save_invstd / save_scale (= gamma invstd) /
  * save_shift (= beta - mean scale) [Cout] and the running-statistics update exactly as scp_batchnorm_act_forward does.
  * scp_batchnorm_apply then produces relu(y scale + shift [+ skip]); scp_batchnorm_act_backward takes the saved statistics. */
-int scp_conv_nhwc_forward_bn(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride,
+int scp_conv_nhwc_forward_bn(const float* x, const float* w, const void* w_split, float* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride,
                              const float* gamma, const float* beta, float* running_mean, float* running_var,
                              long long* batches_tracked, float momentum, float eps, float* save_mean, float* save_invstd,
                              float* save_scale, float* save_shift, void* workspace, size_t workspace_bytes, unsigned* ticket,

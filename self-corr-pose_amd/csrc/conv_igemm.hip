@@ -25,6 +25,7 @@
 
 #include "bn_common.h"
 #include "gemm_core.h"
+#include "gemm_core_split.h"
 #include "scp_common.h"
 #include "scp_hip.h"
 
@@ -35,6 +36,7 @@ using scp::f32x16;
 struct ConvArgs {
     const float* x;        // [N, H, W, Cin]
     const float* w;        // [Cout, taps, Cin]
+    const void* w_split;   // or its planes [3][Cout][taps * Cin] bf16 (scp_split_bf16x3): main loop of csrc/gemm_core_split.h
     const float* bias;     // [Cout] or nullptr
     float* y;              // [N, Ho, Wo, Cout]
     float* partials;       // [2][tiles_m][Cout] (sums, then sums of squares) or nullptr
@@ -56,18 +58,18 @@ __device__ __forceinline__ void bufload16(unsigned voff, __amdgpu_buffer_rsrc_t 
                  : "memory");
 }
 
+// A-tile source of the implicit GEMM (shared by the fp32 and the split main loop): tile row r = output pixel, chunk kc = 16
+// channels of one tap
 template <class CFG, int TAPS>
-struct ConvSource {
+struct ConvASource {
     __amdgpu_buffer_rsrc_t rsrc;
-    const char* w_base;
-    unsigned a_pix[CFG::A_PER], tap_ok[CFG::A_PER], w_off[CFG::W_PER];
+    unsigned a_pix[CFG::A_PER], tap_ok[CFG::A_PER];
     int Win, Cin, lg_cpt;
 
-    __device__ __forceinline__ void set(const ConvArgs& g, int m0, int n0, int wave, int lane) {
+    __device__ __forceinline__ void set(const ConvArgs& g, int m0, int wave, int lane) {
         const int prow = lane >> 2, pslot = lane & 3;
         const int chunk = pslot ^ ((prow >> 2) & 3);
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, (int)g.x_bytes, 0x00020000);
-        w_base = reinterpret_cast<const char*>(g.w);
         Win = g.W; Cin = g.Cin; lg_cpt = g.lg_cpt;
         const int hw = g.Ho * g.Wo;
 #pragma unroll
@@ -90,6 +92,33 @@ struct ConvSource {
             }
             tap_ok[i] = ok;
         }
+    }
+    template <int I>
+    __device__ __forceinline__ void issue(int kc, unsigned stage_lds, int wave) const {
+        const int tap = kc >> lg_cpt, c = kc - (tap << lg_cpt);
+        int delta = 64 * c;
+        if (TAPS == 9) {
+            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;                   // tap / 3, tap % 3 for tap < 9
+            delta += ((ky - 1) * Win + (kx - 1)) * Cin * 4;
+        }
+        const bool ok = (tap_ok[I] >> tap) & 1u;
+        const unsigned voff = ok ? a_pix[I] + (unsigned)delta : 0x80000000u;      // beyond the descriptor: zeros
+        bufload16(voff, rsrc, stage_lds + (unsigned)(wave * CFG::A_PER + I) * 1024u);
+    }
+};
+
+// both operands of the fp32 main loop (csrc/gemm_core.h)
+template <class CFG, int TAPS>
+struct ConvSource {
+    ConvASource<CFG, TAPS> a;
+    const char* w_base;
+    unsigned w_off[CFG::W_PER];
+
+    __device__ __forceinline__ void set(const ConvArgs& g, int m0, int n0, int wave, int lane) {
+        const int prow = lane >> 2, pslot = lane & 3;
+        const int chunk = pslot ^ ((prow >> 2) & 3);
+        a.set(g, m0, wave, lane);
+        w_base = reinterpret_cast<const char*>(g.w);
 #pragma unroll
         for (int i = 0; i < CFG::W_PER; i++) {
             const int r = 16 * (wave * CFG::W_PER + i) + prow;
@@ -99,15 +128,7 @@ struct ConvSource {
     template <int I>
     __device__ __forceinline__ void issue(int kc, unsigned stage_lds, int wave) const {
         if constexpr (I < CFG::A_PER) {
-            const int tap = kc >> lg_cpt, c = kc - (tap << lg_cpt);
-            int delta = 64 * c;
-            if (TAPS == 9) {
-                const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;                   // tap / 3, tap % 3 for tap < 9
-                delta += ((ky - 1) * Win + (kx - 1)) * Cin * 4;
-            }
-            const bool ok = (tap_ok[I] >> tap) & 1u;
-            const unsigned voff = ok ? a_pix[I] + (unsigned)delta : 0x80000000u;      // beyond the descriptor: zeros
-            bufload16(voff, rsrc, stage_lds + (unsigned)(wave * CFG::A_PER + I) * 1024u);
+            a.template issue<I>(kc, stage_lds, wave);
         } else {
             scp::glds16(w_off[I - CFG::A_PER], w_base + (size_t)kc * (CFG::BK * 4),
                         stage_lds + CFG::W_BASE_BYTES + (unsigned)(wave * CFG::W_PER + (I - CFG::A_PER)) * 1024u);
@@ -131,10 +152,16 @@ __device__ __forceinline__ void finalize_statistics(const ConvArgs& g, float* ld
     for (int i = 0; i < 4; i++) scp_bn::finalize_channel(g.fin, 4 * tc + i, true, sa[i], sb[i]);
 }
 
-template <class CFG, int TAPS, int EPI, bool STATS>
-__global__ __launch_bounds__(CFG::THREADS, 2) void conv_igemm_kernel(const ConvArgs g) {
+// the split twin of a tile shape: same wavefront grid and MFMA tiles per wavefront
+template <class CFG>
+using SplitOf = scp::SplitCfg<CFG::WM, CFG::WN, CFG::NWM, CFG::NWN, CFG::MINBLK>;
+
+template <class FCFG, int TAPS, int EPI, bool STATS, bool SPLIT>
+__global__ __launch_bounds__(FCFG::THREADS, 2) void conv_igemm_kernel(const ConvArgs g) {
+    using CFG = std::conditional_t<SPLIT, SplitOf<FCFG>, FCFG>;
     __shared__ __attribute__((aligned(16))) float lds[CFG::LDS_BYTES / 4];
-    using Core = scp::GemmCore<CFG, ConvSource<CFG, TAPS>>;
+    using Core = std::conditional_t<SPLIT, scp::SplitGemmCore<SplitOf<FCFG>, ConvASource<SplitOf<FCFG>, TAPS>>,
+                                    scp::GemmCore<FCFG, ConvSource<FCFG, TAPS>>>;
     // tile order: workgroup t runs on XCD t % 8; consecutive tiles of one XCD walk the column blocks of one pixel panel
     const int total = g.tiles_m * g.nblk_n;
     const int per_xcd = (total + 7) >> 3;
@@ -147,7 +174,12 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void conv_igemm_kernel(const ConvA
     const int bm = lid / g.nblk_n, bn = lid - bm * g.nblk_n;
     const int m0 = bm * CFG::BM, n0 = bn * CFG::BN;
     Core core(lds);
-    core.src.set(g, m0, n0, core.wave, core.lane);
+    if constexpr (SPLIT) {
+        core.asrc.set(g, m0, core.wave, core.lane);
+        core.set_w_rows(g.w_split, g.Cout, g.K, [&](int r) { return min(n0 + r, g.Cout - 1); });
+    } else {
+        core.src.set(g, m0, n0, core.wave, core.lane);
+    }
     typename Core::Acc acc;
     core.run(acc, g.K / CFG::BK);
 
@@ -215,6 +247,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void conv_igemm_kernel(const ConvA
 using Cfg256x64 = scp::GemmCfg<2, 2, 4, 1, 2, 2>;     // 64-channel layers at 64 x 64 resolution
 using Cfg64x128 = scp::GemmCfg<1, 2, 2, 2, 2, 2>;
 using Cfg64x64 = scp::GemmCfg<1, 1, 2, 2, 2, 2>;
+using Cfg128x128 = scp::GemmCfg<2, 2, 2, 2, 2, 2>;    // split main loop only: its per-chunk overheads want >= 24 MFMAs per wavefront
 
 template <class CFG, int TAPS>
 void launch_cfg(ConvArgs& g, bool leaky, bool stats, hipStream_t st) {
@@ -222,43 +255,60 @@ void launch_cfg(ConvArgs& g, bool leaky, bool stats, hipStream_t st) {
     g.tiles_m = (g.M + CFG::BM - 1) / CFG::BM;
     const int total = g.tiles_m * g.nblk_n;
     const dim3 grid(((total + 7) >> 3) << 3), block(CFG::THREADS);
+    if (g.w_split) {
+        if (leaky) {
+            if (stats) hipLaunchKernelGGL((conv_igemm_kernel<CFG, TAPS, EPI_BIAS_LEAKY, true, true>), grid, block, 0, st, g);
+            else hipLaunchKernelGGL((conv_igemm_kernel<CFG, TAPS, EPI_BIAS_LEAKY, false, true>), grid, block, 0, st, g);
+        } else {
+            if (stats) hipLaunchKernelGGL((conv_igemm_kernel<CFG, TAPS, EPI_RAW, true, true>), grid, block, 0, st, g);
+            else hipLaunchKernelGGL((conv_igemm_kernel<CFG, TAPS, EPI_RAW, false, true>), grid, block, 0, st, g);
+        }
+        return;
+    }
     if (leaky) {
-        if (stats) hipLaunchKernelGGL((conv_igemm_kernel<CFG, TAPS, EPI_BIAS_LEAKY, true>), grid, block, 0, st, g);
-        else hipLaunchKernelGGL((conv_igemm_kernel<CFG, TAPS, EPI_BIAS_LEAKY, false>), grid, block, 0, st, g);
+        if (stats) hipLaunchKernelGGL((conv_igemm_kernel<CFG, TAPS, EPI_BIAS_LEAKY, true, false>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((conv_igemm_kernel<CFG, TAPS, EPI_BIAS_LEAKY, false, false>), grid, block, 0, st, g);
     } else {
-        if (stats) hipLaunchKernelGGL((conv_igemm_kernel<CFG, TAPS, EPI_RAW, true>), grid, block, 0, st, g);
-        else hipLaunchKernelGGL((conv_igemm_kernel<CFG, TAPS, EPI_RAW, false>), grid, block, 0, st, g);
+        if (stats) hipLaunchKernelGGL((conv_igemm_kernel<CFG, TAPS, EPI_RAW, true, false>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((conv_igemm_kernel<CFG, TAPS, EPI_RAW, false, false>), grid, block, 0, st, g);
     }
 }
 
 // tile shape of a layer: the widest tile that still gives the machine >= 256 workgroups
-int pick_cfg(long M, int Cout) {
+int pick_cfg(long M, int Cout, bool split) {
     if (Cout <= 64) return 0;                                                      // 256 x 64
     const long t128 = ((M + 63) / 64) * ((Cout + 127) / 128);
+    if (split) {
+        // the split main loop does 2.7x less matrix-pipe work per chunk while its barriers, DMA waits and operand splits stay:
+        // the largest tile that still gives every CU a workgroup
+        // (measured per layer, tools/conv_bench.py: 128 x 128 on half the CUs and 64 x 128 are both slower than 64 x 64 there)
+        if (((M + 127) / 128) * ((Cout + 127) / 128) >= 256) return 3;             // 128 x 128
+    }
     // 64 x 128 while that still gives >= 384 workgroups, else 64 x 64 (measured inside the step: filling the machine with the
     // smaller tile beats the larger tile on half the CUs, 39.8 vs 40.4 ms)
     return t128 >= 384 ? 1 : 2;
 }
-int tile_rows(int cfg) { return cfg == 0 ? Cfg256x64::BM : 64; }
+int tile_rows(int cfg) { return cfg == 0 ? Cfg256x64::BM : cfg == 3 ? Cfg128x128::BM : 64; }
 
 }  // namespace
 
-extern "C" int scp_conv_nhwc_partial_rows(int N, int H, int W, int Cout, int ksize, int stride, int* tiles_m, int* rows_per_tile) {
+extern "C" int scp_conv_nhwc_partial_rows(int N, int H, int W, int Cout, int ksize, int stride, int split, int* tiles_m,
+                                          int* rows_per_tile) {
     const int pad = ksize / 2;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const long M = (long)N * Ho * Wo;
-    const int rows = tile_rows(pick_cfg(M, Cout));
+    const int rows = tile_rows(pick_cfg(M, Cout, split != 0));
     if (tiles_m) *tiles_m = (int)((M + rows - 1) / rows);
     if (rows_per_tile) *rows_per_tile = rows;
     return 0;
 }
 
 namespace {
-int conv_forward_impl(const float* x, const float* w, const float* bias, float* y, float* partials, unsigned* ticket,
+int conv_forward_impl(const float* x, const float* w, const void* w_split, const float* bias, float* y, float* partials, unsigned* ticket,
                       const scp_bn::FwdFinalize* fin, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int leaky,
                       float slope, void* stream) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return scp::fail(hipErrorInvalidValue, "conv_nhwc: empty problem");
-    if (!x || !w || !y || (leaky && !bias)) return scp::fail(hipErrorInvalidValue, "conv_nhwc: null argument");
+    if (!x || (!w && !w_split) || !y || (leaky && !bias)) return scp::fail(hipErrorInvalidValue, "conv_nhwc: null argument");
     if (ksize != 1 && ksize != 3) return scp::fail(hipErrorInvalidValue, "conv_nhwc: kernel size must be 1 or 3");
     if (stride != 1 && stride != 2) return scp::fail(hipErrorInvalidValue, "conv_nhwc: stride must be 1 or 2");
     const int cpt = Cin / 16;
@@ -266,7 +316,7 @@ int conv_forward_impl(const float* x, const float* w, const float* bias, float* 
     if (fin && (Cout < 16 || Cout > 1024 || (Cout & (Cout - 1)))) return scp::fail(hipErrorInvalidValue, "conv_nhwc: BatchNorm statistics need a power-of-two Cout in [16,1024]");
     const int pad = ksize / 2;
     ConvArgs g{};
-    g.x = x; g.w = w; g.bias = bias; g.y = y; g.partials = partials; g.ticket = ticket;
+    g.x = x; g.w = w; g.w_split = w_split; g.bias = bias; g.y = y; g.partials = partials; g.ticket = ticket;
     g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.stride = stride; g.slope = slope;
     g.Ho = (H + 2 * pad - ksize) / stride + 1;
     g.Wo = (W + 2 * pad - ksize) / stride + 1;
@@ -283,27 +333,30 @@ int conv_forward_impl(const float* x, const float* w, const float* bias, float* 
         g.fin.R = M;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int cfg = pick_cfg(M, Cout);
+    const int cfg = pick_cfg(M, Cout, w_split != nullptr);
     const bool stats = partials != nullptr;
     if (ksize == 3) {
         if (cfg == 0) launch_cfg<Cfg256x64, 9>(g, leaky, stats, st);
         else if (cfg == 1) launch_cfg<Cfg64x128, 9>(g, leaky, stats, st);
+        else if (cfg == 3) launch_cfg<Cfg128x128, 9>(g, leaky, stats, st);
         else launch_cfg<Cfg64x64, 9>(g, leaky, stats, st);
     } else {
         if (cfg == 0) launch_cfg<Cfg256x64, 1>(g, leaky, stats, st);
         else if (cfg == 1) launch_cfg<Cfg64x128, 1>(g, leaky, stats, st);
+        else if (cfg == 3) launch_cfg<Cfg128x128, 1>(g, leaky, stats, st);
         else launch_cfg<Cfg64x64, 1>(g, leaky, stats, st);
     }
     return scp::check_launch("conv_nhwc_forward");
 }
 }  // namespace
 
-extern "C" int scp_conv_nhwc_forward(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int H, int W,
-                                     int Cin, int Cout, int ksize, int stride, int leaky, float slope, void* stream) {
-    return conv_forward_impl(x, w, bias, y, partials, nullptr, nullptr, N, H, W, Cin, Cout, ksize, stride, leaky, slope, stream);
+extern "C" int scp_conv_nhwc_forward(const float* x, const float* w, const void* w_split, const float* bias, float* y, float* partials,
+                                     int N, int H, int W, int Cin, int Cout, int ksize, int stride, int leaky, float slope,
+                                     void* stream) {
+    return conv_forward_impl(x, w, w_split, bias, y, partials, nullptr, nullptr, N, H, W, Cin, Cout, ksize, stride, leaky, slope, stream);
 }
 
-extern "C" int scp_conv_nhwc_forward_bn(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int ksize,
+extern "C" int scp_conv_nhwc_forward_bn(const float* x, const float* w, const void* w_split, float* y, int N, int H, int W, int Cin, int Cout, int ksize,
                                         int stride, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                         long long* batches_tracked, float momentum, float eps, float* save_mean, float* save_invstd,
                                         float* save_scale, float* save_shift, void* workspace, size_t workspace_bytes, unsigned* ticket,
@@ -311,9 +364,9 @@ extern "C" int scp_conv_nhwc_forward_bn(const float* x, const float* w, float* y
     if (!save_mean || !save_invstd || !save_scale || !save_shift || !workspace || !ticket)
         return scp::fail(hipErrorInvalidValue, "conv_nhwc_forward_bn: null argument");
     int tiles_m = 0;
-    scp_conv_nhwc_partial_rows(N, H, W, Cout, ksize, stride, &tiles_m, nullptr);
+    scp_conv_nhwc_partial_rows(N, H, W, Cout, ksize, stride, w_split != nullptr, &tiles_m, nullptr);
     if (workspace_bytes < (size_t)2 * tiles_m * Cout * sizeof(float)) return scp::fail(hipErrorInvalidValue, "conv_nhwc_forward_bn: workspace too small");
     const scp_bn::FwdFinalize fin{0, gamma, beta, running_mean, running_var, batches_tracked, momentum, eps, save_mean, save_invstd,
                                   save_scale, save_shift};
-    return conv_forward_impl(x, w, nullptr, y, static_cast<float*>(workspace), ticket, &fin, N, H, W, Cin, Cout, ksize, stride, 0, 0.f, stream);
+    return conv_forward_impl(x, w, w_split, nullptr, y, static_cast<float*>(workspace), ticket, &fin, N, H, W, Cin, Cout, ksize, stride, 0, 0.f, stream);
 }

@@ -39,8 +39,9 @@ struct SplitCfg {
     static constexpr int NW = NWM * NWN, THREADS = 64 * NW;
     static constexpr int A_PIECES = BM / 16;                  // 16 rows x 64 B
     static constexpr int W_GROUPS = BN / 32, W_PIECES = 3 * W_GROUPS;   // 32 rows x 32 B, three planes
-    static_assert(A_PIECES % NW == 0 && W_PIECES % NW == 0, "pieces are dealt evenly to the wavefronts");
-    static constexpr int A_PER = A_PIECES / NW, W_PER = W_PIECES / NW, PER = A_PER + W_PER;
+    static_assert(A_PIECES % NW == 0, "A pieces are dealt evenly to the wavefronts");
+    // W piece q goes to wavefront q % NW (its (q / NW)-th); with BN = 64 the six pieces leave two wavefronts with one only
+    static constexpr int A_PER = A_PIECES / NW, W_PER = (W_PIECES + NW - 1) / NW;
     static constexpr int A_BYTES = BM * 64, PLANE_BYTES = BN * 32;
     static constexpr int STAGE_BYTES = A_BYTES + 3 * PLANE_BYTES, LDS_BYTES = NSTAGE * STAGE_BYTES;
     static constexpr int NT = WM * WN;
@@ -75,13 +76,33 @@ __device__ __forceinline__ Split3 split3(f32x8 x) {
     return s;
 }
 
+// A-tile source of the plain GEMM: A[M, K] fp32 row-major, one row per tile row (callers clamp rows to the matrix)
 template <class CFG>
+struct LinearASource {
+    const char* a_base;
+    unsigned a_off[CFG::A_PER];
+    template <class FA>
+    __device__ __forceinline__ void set_rows(const float* A, int K, int wave, int lane, FA a_row) {
+        const int prow = lane >> 2, pslot = lane & 3, chunk = pslot ^ ((prow >> 2) & 3);
+        a_base = reinterpret_cast<const char*>(A);
+#pragma unroll
+        for (int i = 0; i < CFG::A_PER; i++)
+            a_off[i] = ((unsigned)a_row(16 * (wave * CFG::A_PER + i) + prow) * (unsigned)K + 4u * chunk) * 4u;
+    }
+    // piece I of this wavefront for chunk kc -> A part of the stage at `stage_lds`
+    template <int I>
+    __device__ __forceinline__ void issue(int kc, unsigned stage_lds, int wave) const {
+        glds16(a_off[I], a_base + (size_t)kc * 64, stage_lds + (unsigned)(wave * CFG::A_PER + I) * 1024u);
+    }
+};
+
+template <class CFG, class ASRC = LinearASource<CFG>>
 struct SplitGemmCore {
     struct Acc { f32x16 t[CFG::NT]; };
 
-    const char* a_base;
+    ASRC asrc;
     const char* w_base;
-    unsigned a_off[CFG::A_PER], w_off[CFG::W_PER];
+    unsigned w_off[CFG::W_PER];
     char* lds;                     // generic pointer to the ring (compiler-visible reads)
     unsigned lds0;                 // its LDS byte address (DMA destinations)
     unsigned a_rd[2], w_rd;        // lane's fragment byte offsets inside a stage (tile 0)
@@ -101,26 +122,23 @@ struct SplitGemmCore {
     __device__ __forceinline__ int row_base() const { return 32 * CFG::WM * (wave / CFG::NWN); }
     __device__ __forceinline__ int col_base() const { return 32 * CFG::WN * (wave % CFG::NWN); }
 
-    // A [M,K] fp32 row-major; W3 = planes [3][N][K] bf16 (h, m, l); a_row / w_row map a tile row to its source row
+    // W3 = planes [3][N][K] bf16 (h, m, l); w_row maps a tile row (output column) to its source row
+    template <class FW>
+    __device__ __forceinline__ void set_w_rows(const void* W3, int N, int K, FW w_row) {
+        w_base = reinterpret_cast<const char*>(W3);
+        const int prow = lane >> 1, pslot = lane & 1;
+#pragma unroll
+        for (int i = 0; i < CFG::W_PER; i++) {
+            const int q = min(wave + CFG::NW * i, CFG::W_PIECES - 1), plane = q / CFG::W_GROUPS, r = 32 * (q % CFG::W_GROUPS) + prow;
+            const int slot = pslot ^ ((r >> 3) & 1);
+            w_off[i] = ((unsigned)plane * (unsigned)N * (unsigned)K + (unsigned)w_row(r) * (unsigned)K + 8u * slot) * 2u;
+        }
+    }
+    // the interface gemm_core.h's GemmCore shares (vit_gemm.hip picks a core per launch): A [M,K] fp32 row-major
     template <class FA, class FW>
     __device__ __forceinline__ void set_rows(const float* A, const void* W3, int N, int K, FA a_row, FW w_row) {
-        a_base = reinterpret_cast<const char*>(A);
-        w_base = reinterpret_cast<const char*>(W3);
-        {
-            const int prow = lane >> 2, pslot = lane & 3, chunk = pslot ^ ((prow >> 2) & 3);
-#pragma unroll
-            for (int i = 0; i < CFG::A_PER; i++)
-                a_off[i] = ((unsigned)a_row(16 * (wave * CFG::A_PER + i) + prow) * (unsigned)K + 4u * chunk) * 4u;
-        }
-        {
-            const int prow = lane >> 1, pslot = lane & 1;
-#pragma unroll
-            for (int i = 0; i < CFG::W_PER; i++) {
-                const int q = wave * CFG::W_PER + i, plane = q / CFG::W_GROUPS, r = 32 * (q % CFG::W_GROUPS) + prow;
-                const int slot = pslot ^ ((r >> 3) & 1);
-                w_off[i] = ((unsigned)plane * (unsigned)N * (unsigned)K + (unsigned)w_row(r) * (unsigned)K + 8u * slot) * 2u;
-            }
-        }
+        asrc.set_rows(A, K, wave, lane, a_row);
+        set_w_rows(W3, N, K, w_row);
     }
     __device__ __forceinline__ void set_linear_sources(const float* A, const void* W3, int m0, int n0, int M, int N, int K) {
         set_rows(A, W3, N, K, [&](int r) { return min(m0 + r, M - 1); }, [&](int r) { return min(n0 + r, N - 1); });
@@ -128,13 +146,11 @@ struct SplitGemmCore {
 
     __device__ __forceinline__ void issue(int kc, int stage) const {
         const unsigned dst = lds0 + stage * CFG::STAGE_BYTES;
-        static_for<0, CFG::A_PER>([&](auto i) {
-            constexpr int I = decltype(i)::value;
-            glds16(a_off[I], a_base + (size_t)kc * 64, dst + (unsigned)(wave * CFG::A_PER + I) * 1024u);
-        });
+        static_for<0, CFG::A_PER>([&](auto i) { asrc.template issue<decltype(i)::value>(kc, dst, wave); });
         static_for<0, CFG::W_PER>([&](auto i) {
             constexpr int I = decltype(i)::value;
-            glds16(w_off[I], w_base + (size_t)kc * 32, dst + CFG::A_BYTES + (unsigned)(wave * CFG::W_PER + I) * 1024u);
+            if ((I + 1) * CFG::NW <= CFG::W_PIECES || wave + CFG::NW * I < CFG::W_PIECES)      // wavefront-uniform
+                glds16(w_off[I], w_base + (size_t)kc * 32, dst + CFG::A_BYTES + (unsigned)(wave + CFG::NW * I) * 1024u);
         });
     }
 
@@ -153,22 +169,21 @@ struct SplitGemmCore {
             const f32x8 x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             const Split3 a = split3(x);
             // smallest terms first; six products per accumulator tile, tiles interleaved so that consecutive MFMAs are independent
+            auto mac = [&](const bf16x8& av, int p) {
 #pragma unroll
-            for (int j = 0; j < CFG::WN; j++) acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, wf[1][j], acc.t[i * CFG::WN + j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < CFG::WN; j++) acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, wf[0][j], acc.t[i * CFG::WN + j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < CFG::WN; j++) acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, wf[2][j], acc.t[i * CFG::WN + j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < CFG::WN; j++) acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, wf[0][j], acc.t[i * CFG::WN + j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < CFG::WN; j++) acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, wf[1][j], acc.t[i * CFG::WN + j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < CFG::WN; j++) acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, wf[0][j], acc.t[i * CFG::WN + j], 0, 0, 0);
+                for (int j = 0; j < CFG::WN; j++)
+                    acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wf[p][j], acc.t[i * CFG::WN + j], 0, 0, 0);
+            };
+            mac(a.m, 1);
+            mac(a.l, 0);
+            mac(a.h, 2);
+            mac(a.m, 0);
+            mac(a.h, 1);
+            mac(a.h, 0);
         }
     }
 
-    // acc = sum over nk chunks of 16 k (nk even and >= 2)
+    // acc = sum over nk chunks of 16 k (nk even and >= 2).  On return all LDS accesses and DMAs of this wavefront have completed.
     __device__ __forceinline__ void run(Acc& acc, int nk) {
 #pragma unroll
         for (int t = 0; t < CFG::NT; t++)
@@ -177,16 +192,10 @@ struct SplitGemmCore {
         issue(0, 0);
         for (int kc = 0; kc < nk; kc += 2) {
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#ifndef SCP_SPLIT_PROBE_NODMA
             issue(kc + 1, 1);
-#else
-            if (kc == 0) issue(kc + 1, 1);
-#endif
             compute<0>(acc);
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#ifndef SCP_SPLIT_PROBE_NODMA
             if (kc + 2 < nk) issue(kc + 2, 0);
-#endif
             compute<1>(acc);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

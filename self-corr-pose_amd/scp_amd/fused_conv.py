@@ -60,18 +60,59 @@ def _conv_out_shape(x, weight, stride):
     return n, weight.shape[0], (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
 
 
-def _conv_forward(x, weight, bias, stride, leaky, slope):
+# "split": the convolutions' products run on the bf16 matrix cores with exactly split operands (csrc/gemm_core_split.h: every
+# fp32 value = three bf16 terms, six partial products, fp32 accumulation -- fp32-accurate, ~1.4x the fp32 cores' rate at the
+# part's power limit).  "fp32": v_mfma_f32_32x32x2_f32.  SCP_CONV_GEMM=fp32 in the environment selects the latter.
+import os
+CONV_MODE = os.environ.get("SCP_CONV_GEMM", "split")
+
+
+def split_planes(t):
+    """planes [3, *t.shape] bf16 with t = h + m + l exactly (scp_split_bf16x3); t contiguous fp32"""
+    planes = torch.empty((3,) + tuple(t.shape), dtype=torch.bfloat16, device=t.device)
+    capi.check(capi.lib().scp_split_bf16x3(_ptr(t), _ptr(planes), t.numel(), capi.current_stream()), "split_bf16x3")
+    return planes
+
+
+def weight_planes(conv, with_dgrad):
+    """The split operands of a convolution's weight for this weight version, kept on the module: "fwd" = planes of
+    [Cout, k, k, Cin], "dgrad" = planes of the flipped / transposed [Cin, k, k, Cout] the input gradient multiplies with.
+    Both encoder passes of a step (and their backward passes) share them; they are rebuilt when the optimizer has stepped.
+    Built on the stream of the first forward of the step (the main stream, which every side stream has waited for)."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device))
+    cache = conv.__dict__.get("_scp_planes")
+    if cache is None or cache["key"] != key:
+        cache = conv.__dict__["_scp_planes"] = {"key": key}
+    with torch.no_grad():
+        if "fwd" not in cache:
+            cache["fwd"] = split_planes(w.detach().permute(0, 2, 3, 1).contiguous())
+        if with_dgrad and "dgrad" not in cache:
+            cache["dgrad"] = split_planes(w.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous())
+    return cache
+
+
+def _planes_arg(conv, x, stride):
+    """what the fused ops get as their `planes` argument: the module's cache in split mode, None for the fp32 cores"""
+    if CONV_MODE != "split":
+        return None
+    need_dx = torch.is_grad_enabled() and x.requires_grad and _own_dgrad_ok(conv.weight, stride)
+    return weight_planes(conv, need_dx)
+
+
+def _conv_forward(x, weight, bias, stride, leaky, slope, planes=None):
     """raw own forward: x, weight channels_last; returns a channels_last tensor"""
     L = capi.lib()
     n, cin, h, w = x.shape
     cout, k = weight.shape[0], weight.shape[2]
     y = torch.empty(_conv_out_shape(x, weight, stride), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    capi.check(L.scp_conv_nhwc_forward(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), _ptr(None), n, h, w, cin, cout, k, stride,
-                                       int(leaky), float(slope), capi.current_stream()), "conv_nhwc_forward")
+    capi.check(L.scp_conv_nhwc_forward(_ptr(x), _ptr(None if planes else weight), _ptr(planes["fwd"] if planes else None), _ptr(bias),
+                                       _ptr(y), _ptr(None), n, h, w, cin, cout, k, stride, int(leaky), float(slope),
+                                       capi.current_stream()), "conv_nhwc_forward")
     return y
 
 
-def _conv_backward(x, weight, g, stride, need_dx, need_dw):
+def _conv_backward(x, weight, g, stride, need_dx, need_dw, planes=None):
     """(dx, dw) of y = conv(x, weight) for the output gradient g; all channels_last.  Own kernels where they apply."""
     L = capi.lib()
     n, cin, h, w = x.shape
@@ -81,10 +122,11 @@ def _conv_backward(x, weight, g, stride, need_dx, need_dw):
     own_dw = need_dw and _own_wgrad_ok(x.shape, weight, stride)
     if own_dx:
         # the forward kernel on dy with the weights as [Cin, k, k, Cout], taps flipped
-        wt = weight.flip(2, 3).permute(1, 2, 3, 0).contiguous()
+        wt3 = planes.get("dgrad") if planes else None
+        wt = None if wt3 is not None else weight.flip(2, 3).permute(1, 2, 3, 0).contiguous()
         dx = torch.empty(x.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-        capi.check(L.scp_conv_nhwc_forward(_ptr(g), _ptr(wt), _ptr(None), _ptr(dx), _ptr(None), n, h, w, cout, cin, k, 1, 0, 0.0,
-                                           capi.current_stream()), "conv_nhwc_forward (input gradient)")
+        capi.check(L.scp_conv_nhwc_forward(_ptr(g), _ptr(wt), _ptr(wt3), _ptr(None), _ptr(dx), _ptr(None), n, h, w, cout, cin, k, 1, 0,
+                                           0.0, capi.current_stream()), "conv_nhwc_forward (input gradient)")
     if own_dw:
         ws_bytes = L.scp_conv_nhwc_weight_grad_workspace(n, h, w, cin, cout, 3, 1)
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
@@ -105,20 +147,22 @@ def _conv_backward(x, weight, g, stride, need_dx, need_dw):
 
 class _ConvBNAct(Function):
     @staticmethod
-    def forward(ctx, x, weight, skip, gamma, beta, bn, relu, stride):
+    def forward(ctx, x, weight, skip, gamma, beta, bn, relu, stride, planes):
         L = capi.lib()
-        x, weight = _nhwc(x), _nhwc(weight)
+        x = _nhwc(x)
+        weight = weight if planes else _nhwc(weight)      # split mode: the kernels read the planes, `weight` only gives shapes
         n, cin, h, w = x.shape
         cout, k = weight.shape[0], weight.shape[2]
         conv = torch.empty(_conv_out_shape(x, weight, stride), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         rows = conv.shape[0] * conv.shape[2] * conv.shape[3]
         stats = torch.empty(4, cout, dtype=torch.float32, device=x.device)
         tiles = ctypes.c_int()
-        L.scp_conv_nhwc_partial_rows(n, h, w, cout, k, stride, ctypes.byref(tiles), None)
+        L.scp_conv_nhwc_partial_rows(n, h, w, cout, k, stride, int(planes is not None), ctypes.byref(tiles), None)
         ws = torch.empty(2 * tiles.value * cout, dtype=torch.float32, device=x.device)
         momentum = 0.1 if bn.momentum is None else bn.momentum
         capi.check(L.scp_conv_nhwc_forward_bn(
-            _ptr(x), _ptr(weight), _ptr(conv), n, h, w, cin, cout, k, stride, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean),
+            _ptr(x), _ptr(None if planes else weight), _ptr(planes["fwd"] if planes else None), _ptr(conv), n, h, w, cin, cout, k,
+            stride, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean),
             _ptr(bn.running_var), _ptr(bn.num_batches_tracked if bn.track_running_stats else None), float(momentum), float(bn.eps),
             _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(ws), ws.numel() * 4, capi.ticket(x.device),
             capi.current_stream()), "conv_nhwc_forward_bn")
@@ -130,6 +174,7 @@ class _ConvBNAct(Function):
         residual_relu = relu and skip is not None
         ctx.save_for_backward(x, weight, conv, y if residual_relu else None, stats)
         ctx.cfg = (rows, cout, bool(relu), skip is not None, gamma is not None, beta is not None, stride)
+        ctx.planes = planes
         return y
 
     @staticmethod
@@ -152,17 +197,19 @@ class _ConvBNAct(Function):
             capi.current_stream()), "batchnorm_act_backward")
         if has_skip and dskip is None:
             dskip = dy
-        dx, dw = _conv_backward(x, weight, dconv, stride, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return dx, dw, (dskip if has_skip else None), dgamma, dbeta, None, None, None
+        dx, dw = _conv_backward(x, weight, dconv, stride, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.planes)
+        return dx, dw, (dskip if has_skip else None), dgamma, dbeta, None, None, None, None
 
 
 class _ConvBiasLeaky(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, slope, stride):
-        x, weight = _nhwc(x), _nhwc(weight)
-        y = _conv_forward(x, weight, bias, stride, True, slope)
+    def forward(ctx, x, weight, bias, slope, stride, planes):
+        x = _nhwc(x)
+        weight = weight if planes else _nhwc(weight)
+        y = _conv_forward(x, weight, bias, stride, True, slope, planes)
         ctx.save_for_backward(x, weight, y)
         ctx.cfg = (float(slope), stride)
+        ctx.planes = planes
         return y
 
     @staticmethod
@@ -180,8 +227,8 @@ class _ConvBiasLeaky(Function):
         # gradient of the pre-activation (mask from the sign of the output: slope > 0 keeps it) + bias gradient, one pass
         capi.check(L.scp_bias_leaky_relu_backward(_ptr(dy), _ptr(y), slope, rows, c, _ptr(g), _ptr(dbias), _ptr(ws), ws_bytes,
                                                   capi.ticket(y.device), capi.current_stream()), "bias_leaky_relu_backward")
-        dx, dw = _conv_backward(x, weight, g, stride, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return dx, dw, dbias, None, None
+        dx, dw = _conv_backward(x, weight, g, stride, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.planes)
+        return dx, dw, dbias, None, None, None
 
 
 def _fused_ok(x, conv, stride):
@@ -196,7 +243,7 @@ def conv_bn_act(x, conv, bn, skip=None, relu=False):
     c = conv.weight.shape[0]
     if (conv.bias is None and _fused_ok(x, conv, stride) and type(bn) is nn.BatchNorm2d and (bn.training or bn.running_mean is None)
             and 16 <= c <= 1024 and _pow2(c) and (skip is None or skip.dtype == torch.float32) and not torch.is_autocast_enabled()):
-        return _ConvBNAct.apply(x, conv.weight, skip, bn.weight, bn.bias, bn, relu, stride)
+        return _ConvBNAct.apply(x, conv.weight, skip, bn.weight, bn.bias, bn, relu, stride, _planes_arg(conv, x, stride))
     return bn_act(conv(x), bn, skip=skip, relu=relu)
 
 
@@ -207,5 +254,5 @@ def conv_bias_leaky(x, conv, slope=0.1, stride=None):
     c = conv.weight.shape[0]
     if (conv.bias is not None and _fused_ok(x, conv, stride) and 16 <= c <= 1024 and _pow2(c) and slope > 0
             and not torch.is_autocast_enabled()):
-        return _ConvBiasLeaky.apply(x, conv.weight, conv.bias, slope, stride)
+        return _ConvBiasLeaky.apply(x, conv.weight, conv.bias, slope, stride, _planes_arg(conv, x, stride))
     return fused_bn.conv_bias_leaky(x, conv, slope, stride)

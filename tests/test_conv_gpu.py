@@ -17,9 +17,21 @@ pytestmark = pytest.mark.gpu
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+CORE = "split"      # which main loop _conv() drives: bf16 cores on exactly split operands, or the fp32 cores
+
+
+@pytest.fixture(params=["split", "fp32"], autouse=True)
+def conv_core(request):
+    global CORE
+    CORE = request.param
+    yield request.param
+    CORE = "split"
+
+
 def _conv(x_nhwc, w_khwc, bias=None, stride=1, leaky=False, slope=0.1, partials=False):
-    from scp_amd import capi
+    from scp_amd import capi, fused_conv
     L = capi.lib()
+    w3 = fused_conv.split_planes(w_khwc) if CORE == "split" else None
     n, h, w, cin = x_nhwc.shape
     cout, k = w_khwc.shape[0], w_khwc.shape[1]
     ho = (h + 2 * (k // 2) - k) // stride + 1
@@ -28,10 +40,10 @@ def _conv(x_nhwc, w_khwc, bias=None, stride=1, leaky=False, slope=0.1, partials=
     part = None
     if partials:
         tm, rows = ctypes.c_int(), ctypes.c_int()
-        L.scp_conv_nhwc_partial_rows(n, h, w, cout, k, stride, ctypes.byref(tm), ctypes.byref(rows))
+        L.scp_conv_nhwc_partial_rows(n, h, w, cout, k, stride, int(CORE == "split"), ctypes.byref(tm), ctypes.byref(rows))
         part = torch.full((2, tm.value, cout), float("nan"), device="cuda")
-    capi.check(L.scp_conv_nhwc_forward(P(x_nhwc), P(w_khwc), P(bias), P(y), P(part), n, h, w, cin, cout, k, stride, int(leaky), slope,
-                                       capi.current_stream()), "conv_nhwc_forward")
+    capi.check(L.scp_conv_nhwc_forward(P(x_nhwc), P(None if w3 is not None else w_khwc), P(w3), P(bias), P(y), P(part), n, h, w, cin, cout,
+                                       k, stride, int(leaky), slope, capi.current_stream()), "conv_nhwc_forward")
     return (y, part, rows.value) if partials else y
 
 
@@ -108,6 +120,6 @@ def test_conv_rejects_shapes_it_does_not_cover():
     x = torch.randn(1, 4, 4, 24, device="cuda")      # Cin not a power of two >= 32
     wt = torch.randn(8, 3, 3, 24, device="cuda")
     y = torch.empty(1, 4, 4, 8, device="cuda")
-    assert L.scp_conv_nhwc_forward(P(x), P(wt), P(None), P(y), P(None), 1, 4, 4, 24, 8, 3, 1, 0, 0.0, capi.current_stream()) != 0
-    assert L.scp_conv_nhwc_forward(P(x), P(wt), P(None), P(y), P(None), 1, 4, 4, 32, 8, 7, 2, 0, 0.0, capi.current_stream()) != 0   # the 7x7 stem stays on MIOpen
+    assert L.scp_conv_nhwc_forward(P(x), P(wt), P(None), P(None), P(y), P(None), 1, 4, 4, 24, 8, 3, 1, 0, 0.0, capi.current_stream()) != 0
+    assert L.scp_conv_nhwc_forward(P(x), P(wt), P(None), P(None), P(y), P(None), 1, 4, 4, 32, 8, 7, 2, 0, 0.0, capi.current_stream()) != 0   # the 7x7 stem stays on MIOpen
     assert L.scp_conv_nhwc_weight_grad_workspace(2, 12, 12, 64, 64, 3, 1) == 0                                                 # not a power-of-two map

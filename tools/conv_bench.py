@@ -11,12 +11,13 @@ import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "self-corr-pose_amd"))
-from scp_amd import capi  # noqa: E402
+from scp_amd import capi, fused_conv  # noqa: E402
 
 torch.backends.cudnn.benchmark = True
 L = capi.lib()
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+SPLIT = os.environ.get("SCP_CONV_GEMM", "split") == "split"     # own kernels: bf16 cores on split operands, or fp32 cores
 # (name, Cin, Cout, k, stride, H_in, count per encoder pass)
 LAYERS = [("stem 7x7/2", 3, 64, 7, 2, 256, 1), ("layer1 3x3", 64, 64, 3, 1, 64, 4), ("layer2.0 3x3/2", 64, 128, 3, 2, 64, 1),
           ("layer2 3x3", 128, 128, 3, 1, 32, 3), ("layer2 down 1x1/2", 64, 128, 1, 2, 64, 1), ("layer3.0 3x3/2", 128, 256, 3, 2, 32, 1),
@@ -56,14 +57,16 @@ for name, cin, cout, k, s, h, cnt in LAYERS:
     xn, wn, gn = x.detach().permute(0, 2, 3, 1), w.detach().permute(0, 2, 3, 1), g.permute(0, 2, 3, 1)      # NHWC views of the same storage
     assert xn.is_contiguous() and wn.is_contiguous() and gn.is_contiguous()
     if k in (1, 3) and cin >= 32:
+        wn3 = fused_conv.split_planes(wn) if SPLIT else None
         yo = torch.empty(B, ho, ho, cout, device="cuda")
-        of = t(lambda: capi.check(L.scp_conv_nhwc_forward(P(xn), P(wn), P(None), P(yo), P(None), B, h, h, cin, cout, k, s, 0, 0.0,
+        of = t(lambda: capi.check(L.scp_conv_nhwc_forward(P(xn), P(None if SPLIT else wn), P(wn3), P(None), P(yo), P(None), B, h, h, cin, cout, k, s, 0, 0.0,
                                                           capi.current_stream()), "fwd"))
         assert (yo - y.detach().permute(0, 2, 3, 1)).abs().max() <= 2e-4 * y.abs().max()
         if s == 1:
             wt = w.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous()
+            wt3 = fused_conv.split_planes(wt) if SPLIT else None
             dxo = torch.empty(B, h, h, cin, device="cuda")
-            od = t(lambda: capi.check(L.scp_conv_nhwc_forward(P(gn), P(wt), P(None), P(dxo), P(None), B, h, h, cout, cin, k, 1, 0, 0.0,
+            od = t(lambda: capi.check(L.scp_conv_nhwc_forward(P(gn), P(None if SPLIT else wt), P(wt3), P(None), P(dxo), P(None), B, h, h, cout, cin, k, 1, 0, 0.0,
                                                               capi.current_stream()), "dgrad"))
             if k == 3:
                 ws_bytes = L.scp_conv_nhwc_weight_grad_workspace(B, h, h, cin, cout, 3, 1)

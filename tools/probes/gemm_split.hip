@@ -17,7 +17,8 @@ namespace {
 template <class CFG, class CORE, class WT>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINBLK) void gemm_kernel(const float* __restrict__ A, const WT* __restrict__ W,
                                                                          float* __restrict__ C, int M, int N, int K, int nblk_n,
-                                                                         int per_xcd, int panels) {
+                                                                         int per_xcd, int panels, long long* clk) {
+    const long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = blockIdx.x;
     const int lid = (t & 7) * per_xcd + (t >> 3);
@@ -40,6 +41,11 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINBLK) void gemm_kernel(const f
                 if (m < M && n < N) C[(size_t)m * N + n] = acc.t[i * CFG::WN + j][r];
             }
         }
+    if (clk && (threadIdx.x & 63) == 0) {
+        const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd((unsigned long long*)clk, (unsigned long long)(t1 - t0));
+        atomicAdd((unsigned long long*)clk + 1, (unsigned long long)(r1 - r0));
+    }
 }
 
 __global__ void naive_kernel(const float* A, const float* W, double* C, int M, int N, int K) {
@@ -71,7 +77,7 @@ void run(const char* name, const float* A, const WT* W, float* C, const std::vec
     const int nblk_n = (N + CFG::BN - 1) / CFG::BN, panels = (M + CFG::BM - 1) / CFG::BM;
     const int per_xcd = (panels * nblk_n + 7) / 8, grid = per_xcd * 8;
     hipMemset(C, 0, (size_t)M * N * 4);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG::THREADS), lds_bytes, 0, A, W, C, M, N, K, nblk_n, per_xcd, panels);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG::THREADS), lds_bytes, 0, A, W, C, M, N, K, nblk_n, per_xcd, panels, (long long*)nullptr);
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) { printf("%s: launch failed: %s\n", name, hipGetErrorString(e)); exit(1); }
     hipMemcpy(h0.data(), C, (size_t)M * N * 4, hipMemcpyDeviceToHost);
@@ -84,12 +90,20 @@ void run(const char* name, const float* A, const WT* W, float* C, const std::vec
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int reps = 20;
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG::THREADS), lds_bytes, 0, A, W, C, M, N, K, nblk_n, per_xcd, panels);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG::THREADS), lds_bytes, 0, A, W, C, M, N, K, nblk_n, per_xcd, panels, (long long*)nullptr);
     hipEventRecord(e0);
-    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG::THREADS), lds_bytes, 0, A, W, C, M, N, K, nblk_n, per_xcd, panels);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG::THREADS), lds_bytes, 0, A, W, C, M, N, K, nblk_n, per_xcd, panels, (long long*)nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     ms /= reps;
+    {
+        long long* clk; hipMalloc(&clk, 16); hipMemset(clk, 0, 16);
+        for (int i = 0; i < 5; i++) hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG::THREADS), lds_bytes, 0, A, W, C, M, N, K, nblk_n, per_xcd, panels, clk);
+        hipDeviceSynchronize();
+        long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+        printf("    shader clock while this kernel runs: %.3f GHz\n", (double)h[0] / (double)h[1] * 0.1);
+        hipFree(clk);
+    }
     printf("%-30s M=%6d N=%5d K=%5d  %d WG/CU LDS %3d KB grid %5d: %7.1f us  %6.1f TFLOP/s(fp32-equiv)   max err %.2e rms err %.2e of rms %.2e (rel %.2e), scale %.2e\n",
            name, M, N, K, per_cu, lds_bytes / 1024, grid, ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12, maxerr, sqrt(sq / ((double)M * N)),
            sqrt(sqr / ((double)M * N)), sqrt(sq / sqr), scale);
