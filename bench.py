@@ -14,9 +14,11 @@ ImageNet / DINO checkpoints).  Weak scaling: every rank processes its own 32 ima
 
 Extra JSON objects (tier contract):
   roofline      the dominant hand-written kernel family of the step = vit_gemm_kernel (csrc/vit_gemm.hip: the 37 linear
-                layers of the DINO ViT on the fp32 matrix cores with LayerNorm / GELU / residual fused, ~8 ms of a step).
-                bound "mfma": `achieved` = algorithmic flops of the launches (2 M N K each) / their duration, both summed
-                over the timed region and measured with HIP events on the launch stream; peak = 157.3 TFLOP/s (fp32 MFMA).
+                layers of the DINO ViT with LayerNorm / GELU / residual fused).  Default main loop: fp32 products on the bf16
+                matrix cores with exactly split operands (csrc/gemm_core_split.h; fp32-accurate); SCP_VIT_GEMM=fp32 selects the
+                fp32 matrix cores.  bound "mfma": `achieved` = algorithmic flops of the launches (2 M N K each) / their
+                duration on the kernel-duration clock; peak = 2500 / 6 = 416.7 TFLOP/s of fp32-equivalent work (six bf16 MFMA
+                products per algorithmic one), or 157.3 TFLOP/s (fp32 MFMA) in fp32 mode; `vs_fp32_mfma_peak` is always there.
                 `traffic` = HBM bytes per step of those launches from rocprofv3 FETCH_SIZE / WRITE_SIZE passes, read from
                 profiles/r03_traffic.json when that file matches the problem size, else null.
                 "others": the ViT attention kernel (mfma), the SoftRas backward of the sigma=1e-3 pass (fp32 VALU on active
@@ -183,7 +185,8 @@ def isolated_gemms(M, C=384, iters=20):
         v0, v1 = torch.randn(N, device="cuda"), torch.randn(N, device="cuda")
         st = torch.rand(M, 2, device="cuda")
         out = torch.randn(M, N, device="cuda")
-        run = lambda: dino_mod.vit_linear(a, w, v0, v1, st, out, out=out, epilogue=epi)
+        w3 = dino_mod.split_weight(w) if dino_mod.GEMM_MODE == "split" else None
+        run = lambda: dino_mod.vit_linear(a, w, v0, v1, st, out, out=out, epilogue=epi, w_split=w3)
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -196,7 +199,22 @@ def isolated_gemms(M, C=384, iters=20):
         ms_total += e0.elapsed_time(e1) / iters
         fl_total += 2.0 * M * N * K
     tf = fl_total / (ms_total * 1e-3) / 1e12
-    return {"block_ms": ms_total, "achieved": tf, "frac": tf / FP32_VALU_PEAK_TF}
+    return {"block_ms": ms_total, "achieved": tf, "frac": tf / gemm_peak_tf(), "vs_fp32_mfma_peak": tf / FP32_VALU_PEAK_TF}
+
+
+def fused_conv_mode():
+    from scp_amd import fused_conv
+    return fused_conv.CONV_MODE
+
+
+BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix-core peak
+
+
+def gemm_peak_tf():
+    """peak of the ViT linear layers' main loop in algorithmic (fp32-equivalent) flops: the fp32 matrix cores' 157.3 TFLOP/s, or --
+    split mode, six v_mfma_f32_32x32x16_bf16 per 16 k of an exactly split fp32 product -- a sixth of the dense bf16 peak"""
+    import scp_amd.dino as dino_mod
+    return BF16_MFMA_PEAK_TF / 6.0 if dino_mod.GEMM_MODE == "split" else FP32_VALU_PEAK_TF
 
 
 def build_trainer(device, world, batch_size=8, repeat=4, seed=0, mixed_bf16=None):
@@ -541,9 +559,21 @@ def main():
                 cfl, cms, cn = fl, gemm_total_ms, gemm_launches
                 tf = tf_events
             per_step = gemm_calls / args.steps
-            roofline = {"kernel": "vit_gemm_kernel family (fp32 MFMA GEMM + fused LayerNorm / GELU / bias+residual epilogues; "
-                                  "%d launches per step, M = %d tokens)" % (per_step, B * ((S // 8) ** 2 + 1)),
-                        "bound": "mfma", "achieved": tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TF,
+            split = dino_mod.GEMM_MODE == "split"
+            peak = gemm_peak_tf()
+            roofline = {"kernel": "vit_gemm_kernel family (%s + fused LayerNorm / GELU / bias+residual epilogues; "
+                                  "%d launches per step, M = %d tokens)" % (
+                                      "fp32 GEMM on the bf16 matrix cores with exactly split operands (3 bf16 terms per fp32 value, "
+                                      "6 partial products, fp32 accumulation)" if split else "fp32 MFMA GEMM",
+                                      per_step, B * ((S // 8) ** 2 + 1)),
+                        "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                        "peak_note": ("algorithmic fp32 flops (2 M N K); peak = dense bf16 MFMA peak 2500 / 6 executed products per "
+                                      "algorithmic one; executed matrix-core flops are 6x `achieved`" if split else
+                                      "algorithmic fp32 flops (2 M N K) against the fp32 MFMA peak"),
+                        "vs_fp32_mfma_peak": tf / FP32_VALU_PEAK_TF,
+                        "arithmetic": ("fp32-accurate: operands represented exactly, dropped partial products < 2^-24 |a b|; error "
+                                       "vs float64 not above the fp32 matrix cores' (tests/test_vit_gpu.py); SCP_VIT_GEMM=fp32 "
+                                       "selects the fp32 cores" if split else "v_mfma_f32_32x32x2_f32"),
                         "traffic": measured_traffic("vit_gemm", size_tag), "traffic_source": "profiles/r03_traffic.json (per step)",
                         "clock": "in-kernel s_memrealtime stamps: first workgroup start to last workgroup end of every full launch "
                                  "of the timed region (= rocprofv3 kernel-trace duration; profiles/r03_kernel_stats_timed_window.csv)",
@@ -555,11 +585,15 @@ def main():
                         "launches_per_step": per_step, "timed_launches": cn,
                         "ms_per_step": cms / cn * per_step,
                         "events": {"what": "HIP events on the ViT stream around every 5th launch (includes waiting for CUs)",
-                                   "achieved": tf_events, "frac": tf_events / FP32_VALU_PEAK_TF,
+                                   "achieved": tf_events, "frac": tf_events / peak,
                                    "avg_launch_ms": gemm_total_ms / gemm_launches, "timed_launches": gemm_launches},
-                        "sustained_clock_note": "fp32 MFMA on random data runs the part at ~1.95 GHz (tools/probes/gemm_v3.hip: "
-                                                "s_memtime / s_memrealtime), i.e. 128 TFLOP/s is what 100 % matrix-pipe occupancy "
-                                                "delivers; peak above is the nominal 2.4 GHz figure",
+                        "sustained_clock_note": ("dense bf16 MFMA on these operands runs the part at 1.4-1.7 GHz (power limit; "
+                                                 "tools/probes/gemm_split.hip: s_memtime / s_memrealtime per kernel), i.e. 100 % "
+                                                 "matrix-pipe occupancy delivers ~250-290 TFLOP/s of fp32-equivalent work; peak "
+                                                 "above is the nominal 2.4 GHz figure" if split else
+                                                 "fp32 MFMA on random data runs the part at ~1.95 GHz (tools/probes/gemm_v3.hip: "
+                                                 "s_memtime / s_memrealtime), i.e. 128 TFLOP/s is what 100 % matrix-pipe occupancy "
+                                                 "delivers; peak above is the nominal 2.4 GHz figure"),
                         # per block: qkv (r 384, w 1152), proj (r 384 + 384 residual, w 384), fc1 (r 384, w 1536), fc2 (r 1536 + 384,
                         # w 384) floats per token = 6912; + block 9's K slice (r 384, w 384); + the weights once per launch
                         "algorithmic_bytes_per_step": 4.0 * (B * ((S // 8) ** 2 + 1) * (9 * 6912 + 768) + 9 * 4608 * 384 + 384 * 384),
@@ -580,7 +614,11 @@ def main():
                                    "laptop_wild6d flags, full training step (fwd+bwd+clip+AdamW)",
                        "images_per_sec": world * args.steps * B / elapsed, "parallelism": "dp%d" % world,
                        "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else 0,
-                       "gradient_buckets": len(tr.grads.buckets), "buckets_launched_inside_backward": tr.grads.launched_in_backward},
+                       "gradient_buckets": len(tr.grads.buckets), "buckets_launched_inside_backward": tr.grads.launched_in_backward,
+                       "matrix_cores": {"vit_linear": dino_mod.GEMM_MODE, "encoder_conv_fwd_dgrad": fused_conv_mode(),
+                                        "note": "split = bf16 MFMA on exactly split fp32 operands, fp32 accumulate (fp32-accurate); "
+                                                "fp32 = v_mfma_f32_32x32x2_f32; attention, weight gradients and the 7x7 stem run "
+                                                "on the fp32 cores"}},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

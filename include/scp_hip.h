@@ -400,6 +400,14 @@ int scp_upsample2x_bilinear_backward_bf16(const void* grad_out, void* grad_in, i
  * qkv GEMM), out [B,N,H*64] bf16; products on the bf16 matrix cores with fp32 accumulation, softmax statistics in fp32. */
 int scp_vit_attention_bf16_forward(const void* qkv, void* out, int B, int N, int H, int head_dim, float scale, void* stream);
 
+/* ---- ViT attention on the bf16 matrix cores with exactly split operands (csrc/vit_attn_split.hip) ------------------------------
+ * Same operator, layouts and accuracy as scp_vit_attention_forward[_rows] (q_rows / q_count both NULL = all queries): the qkv
+ * tensor is first re-laid into bf16 operand planes in `workspace` (>= scp_vit_attention_split_workspace(B, N, H) bytes), then
+ * Q K^T and P V run as six bf16 MFMA products per fp32 product, accumulated in fp32; softmax statistics in fp32. */
+size_t scp_vit_attention_split_workspace(int B, int N, int H);
+int scp_vit_attention_split_forward(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale, const int* q_rows,
+                                    const int* q_count, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- image-space losses of the step, fused --------------------------------------------------------------------
  * Replace compute_mask_loss / compute_depth_loss / compute_match_loss (model/util/loss_utils.py:236-244, :273-284, :317-320, called
  * from model/model.py:206-214) on the renders as the step holds them:

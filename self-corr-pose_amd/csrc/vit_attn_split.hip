@@ -1,0 +1,352 @@
+// self-corr-pose_amd/csrc/vit_attn_split.hip -- the ViT attention of csrc/vit_attn.hip (same operator, same fp32 accuracy) with
+// both products on the bf16 matrix cores through EXACT operand splitting (csrc/gemm_core_split.h: every fp32 value = three bf16
+// terms, the six leading partial products of nine accumulated in fp32, dropped terms < 2^-24 of |a b|).
+//
+// Replaces Attention.forward of third-party/zsp/zsp/method/vision_transformer_flexible.py:85-101 (q k^T * scale -> softmax -> @ v).
+//
+// Two launches per attention:
+//   1. scp_vit_qkv_split: qkv [B,N,3,H,64] fp32 -> bf16 planes
+//        Qp [3][B H][Npad][64]   (Q pre-multiplied by scale * log2(e) in fp32, then split),
+//        Kp [3][B H][Npad][64],
+//        Vt [3][B H][64][Npad]   TRANSPOSED (a row = one head dimension over the keys), keys permuted inside every block of 32 so
+//                                that a lane's 8 keys of a P.V k-step are contiguous (see slot_key below);
+//      Npad = N rounded up to 32, padding rows / columns are zeros.  One memory-bound pass (the next step is to have the qkv GEMM's
+//      epilogue write these planes directly).
+//   2. vit_attention_split_kernel: flash-style like csrc/vit_attn.hip -- one wavefront owns 32 queries, keeps the TRANSPOSED score
+//      tile S^T[key][query] = K Q^T in its accumulator so that softmax statistics are lane-local, and feeds the exponentiated
+//      accumulator straight back as the B operand of O^T += V^T P^T.  With v_mfma_f32_32x32x16_bf16 a lane's B operand is 8
+//      consecutive k: accumulator registers 8 ks .. 8 ks + 7 of lane half hf are the keys slot_key(16 ks + 8 hf + i) of the tile --
+//      the order Vt is stored in, so P needs no cross-lane movement: it is split in registers (3 x 4 VGPRs per k-step).
+//      K / V planes arrive by LDS-DMA (double buffered, one barrier per tile), 16-B slots XOR-swizzled through the source address
+//      so that every ds_read_b128 is bank-conflict free; Q's planes live in 48 VGPRs.
+//      Per key tile and wavefront: 24 + 24 MFMAs of 32 cycles (fp32 cores: 32 + 32 of 64 cycles), 24 ds_read_b128,
+//      ~90 VALU for the split of P besides the softmax itself.
+// Roofline: 4 N^2 64 flop per (image, head) of fp32-equivalent work; six bf16 MFMA products per algorithmic one.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "scp_common.h"
+#include "scp_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HD = 64, KT = 32;
+constexpr float RESCALE_THR = 16.f;   // log2 units
+
+__device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+// key (0..31) stored at slot s of a 32-key block of Vt: slots 8 g .. 8 g + 7 are the accumulator rows of registers 8 (g >> 1) ..
+// + 7 of lane half (g & 1)
+__host__ __device__ inline int slot_key(int s) {
+    const int g = s >> 3, i = s & 7;
+    return 16 * (g >> 1) + 4 * (g & 1) + (i & 3) + 8 * (i >> 2);
+}
+
+__device__ __forceinline__ float other_half(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return (threadIdx.x & 32) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// x0, x1 -> packed (h, m, l) pairs with x = h + m + l exactly
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = pack_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = pack_bf16(r0, r1);
+    l = pack_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+}
+
+#define SCP_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define SCP_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// ---- 1. operand planes -------------------------------------------------------------------------------------------------------
+// grid (Npad / 32, B H), 256 threads: thread = (token t = tid >> 3, 8 dims d0 = 8 (tid & 7)) for Q and K;
+// for V the 32 x 64 tile goes through LDS and thread = (d = tid >> 2, slot group g = tid & 3) writes 8 keys of one dimension.
+__global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict__ qkv, __bf16* __restrict__ Qp, __bf16* __restrict__ Kp,
+                                                        __bf16* __restrict__ Vt, int N, int Npad, int H, float scale_log2e) {
+    __shared__ float vt[KT][HD + 1];
+    const int tile = blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int tid = threadIdx.x;
+    const size_t row_stride = (size_t)3 * H * HD;
+    const size_t plane_qk = (size_t)gridDim.y * Npad * HD, plane_v = plane_qk;
+    {
+        const int t = tid >> 3, d0 = 8 * (tid & 7);
+        const int tok = tile * KT + t;
+        float q[8], k[8], v[8];
+        if (tok < N) {
+            const float* src = qkv + ((size_t)b * N + tok) * row_stride + (size_t)h * HD + d0;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const float4 a = *reinterpret_cast<const float4*>(src + 4 * i);
+                const float4 c = *reinterpret_cast<const float4*>(src + (size_t)H * HD + 4 * i);
+                const float4 e = *reinterpret_cast<const float4*>(src + (size_t)2 * H * HD + 4 * i);
+                q[4 * i] = a.x * scale_log2e; q[4 * i + 1] = a.y * scale_log2e; q[4 * i + 2] = a.z * scale_log2e; q[4 * i + 3] = a.w * scale_log2e;
+                k[4 * i] = c.x; k[4 * i + 1] = c.y; k[4 * i + 2] = c.z; k[4 * i + 3] = c.w;
+                v[4 * i] = e.x; v[4 * i + 1] = e.y; v[4 * i + 2] = e.z; v[4 * i + 3] = e.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) q[i] = k[i] = v[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) vt[t][d0 + i] = v[i];
+        u32x4 qh, qm, ql, kh, km, kl;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            split_pair(q[2 * p], q[2 * p + 1], qh[p], qm[p], ql[p]);
+            split_pair(k[2 * p], k[2 * p + 1], kh[p], km[p], kl[p]);
+        }
+        const size_t o = ((size_t)bh * Npad + tok) * HD + d0;
+        *reinterpret_cast<u32x4*>(Qp + o) = qh;
+        *reinterpret_cast<u32x4*>(Qp + plane_qk + o) = qm;
+        *reinterpret_cast<u32x4*>(Qp + 2 * plane_qk + o) = ql;
+        *reinterpret_cast<u32x4*>(Kp + o) = kh;
+        *reinterpret_cast<u32x4*>(Kp + plane_qk + o) = km;
+        *reinterpret_cast<u32x4*>(Kp + 2 * plane_qk + o) = kl;
+    }
+    __syncthreads();
+    {
+        const int d = tid >> 2, g = tid & 3;
+        u32x4 vh, vm, vl;
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+            split_pair(vt[slot_key(8 * g + 2 * p)][d], vt[slot_key(8 * g + 2 * p + 1)][d], vh[p], vm[p], vl[p]);
+        const size_t o = ((size_t)bh * HD + d) * Npad + (size_t)tile * KT + 8 * g;
+        *reinterpret_cast<u32x4*>(Vt + o) = vh;
+        *reinterpret_cast<u32x4*>(Vt + plane_v + o) = vm;
+        *reinterpret_cast<u32x4*>(Vt + 2 * plane_v + o) = vl;
+    }
+}
+
+// ---- 2. attention ------------------------------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void vit_attention_split_kernel(const __bf16* __restrict__ Qp, const __bf16* __restrict__ Kp,
+                                                                         const __bf16* __restrict__ Vt, float* __restrict__ out, int N,
+                                                                         int Npad, int H, const int* __restrict__ q_rows,
+                                                                         const int* __restrict__ q_count) {
+    // per buffer: K planes 3 x [32 keys][64 d] bf16 (128 B rows), V^T planes 3 x [64 d][32 keys] bf16 (64 B rows)
+    __shared__ __attribute__((aligned(16))) char k_lds[2][3 * 4096];
+    __shared__ __attribute__((aligned(16))) char v_lds[2][3 * 4096];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    // all query groups of one (image, head) on ONE XCD (see csrc/vit_attn.hip)
+    int bh = blockIdx.y, qg = blockIdx.x;
+    if ((gridDim.y & 7) == 0) {
+        const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+        const int slot = lin >> 3;
+        bh = (slot / gridDim.x) * 8 + (lin & 7);
+        qg = slot % gridDim.x;
+    }
+    const int b = bh / H, h = bh - b * H;
+    const int q0 = (qg * WAVES + wave) * 32;
+    const int n_query = q_count ? min(q_count[b], N) : N;
+    if (qg * WAVES * 32 >= n_query) return;          // workgroup-uniform
+    const size_t plane = (size_t)gridDim.y * Npad * HD;      // elements per plane (gridDim.y = B H also in the remapped order)
+    const __bf16* kbase = Kp + (size_t)bh * Npad * HD;
+    const __bf16* vbase = Vt + (size_t)bh * HD * Npad;
+    const int ntiles = Npad / KT;
+
+    // LDS-DMA pieces (1 KiB each): K plane tile = 4 pieces of 8 keys x 128 B (lane: key = lane >> 3, slot = lane & 7),
+    // V^T plane tile = 4 pieces of 16 dims x 64 B (lane: d = lane >> 2, slot = lane & 3); 12 + 12 pieces per (K, V) tile pair,
+    // dealt round-robin to the wavefronts.  The 16-B slot a lane FETCHES is permuted so that the lane-linear destination holds
+    // slot s of row r at s ^ f(r): f = (key >> 1) & 7 for K, (d >> 2) & 3 for V (conflict-free b128 reads below).
+    constexpr int PIECES = (24 + WAVES - 1) / WAVES;
+    unsigned lane_off[PIECES];      // element offset inside the (bh) matrix of the plane, tile 0
+#pragma unroll
+    for (int i = 0; i < PIECES; i++) {
+        const int j = wave + WAVES * i;
+        if (j < 12) {
+            const int pl = j >> 2, key = 8 * (j & 3) + (lane >> 3), s = (lane & 7) ^ ((key >> 1) & 7);
+            lane_off[i] = (unsigned)(pl * plane) + (unsigned)key * HD + 8u * s;
+        } else {
+            const int jj = j - 12, pl = jj >> 2, d = 16 * (jj & 3) + (lane >> 2), s = (lane & 3) ^ ((d >> 2) & 3);
+            lane_off[i] = (unsigned)(pl * plane) + (unsigned)d * (unsigned)Npad + 8u * s;
+        }
+    }
+    auto issue_tiles = [&](bool do_k, int kt_k, int bufk, bool do_v, int kt_v, int bufv) {
+#pragma unroll
+        for (int i = 0; i < PIECES; i++) {
+            const int j = wave + WAVES * i;                                            // wavefront-uniform
+            if (j >= 24) continue;
+            if (j < 12) {
+                if (do_k)
+                    __builtin_amdgcn_global_load_lds(SCP_GLOBAL_PTR(kbase + (size_t)kt_k * KT * HD + lane_off[i]),
+                                                     SCP_LDS_PTR(k_lds[bufk] + j * 1024), 16, 0, 0);
+            } else if (do_v) {
+                __builtin_amdgcn_global_load_lds(SCP_GLOBAL_PTR(vbase + (size_t)kt_v * KT + lane_off[i]),
+                                                 SCP_LDS_PTR(v_lds[bufv] + (j - 12) * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    // Q planes: B operand of K Q^T, step s covers dims 16 s .. 16 s + 15, lane half hf the dims 16 s + 8 hf .. + 7
+    bf16x8 qf[3][4];
+    {
+        int q = min(q0 + l31, n_query - 1);
+        if (q_rows) q = q_rows[(size_t)b * N + q];
+        const __bf16* qp = Qp + ((size_t)bh * Npad + q) * HD + 8 * half;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) qf[p][s] = *reinterpret_cast<const bf16x8*>(qp + (size_t)p * plane + 16 * s);
+    }
+    f32x16 o_lo, o_hi;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { o_lo[r] = 0.f; o_hi[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // fragment read offsets: K: key l31, slot 2 s + half; V^T: dim l31 (+ 32), slot 2 ks + half
+    const int k_row = l31 * 128, k_sw = (l31 >> 1) & 7;
+    const int v_row0 = l31 * 64, v_sw0 = (l31 >> 2) & 3;              // d = l31
+    const int v_row1 = (l31 + 32) * 64, v_sw1 = ((l31 + 32) >> 2) & 3;  // d = l31 + 32
+    auto mma = [](const bf16x8& a, const bf16x8& bq, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, c, 0, 0, 0); };
+    auto qk_tile = [&](int kbuf) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        const char* kb = k_lds[kbuf] + k_row;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int off = 16 * ((2 * s + half) ^ k_sw);
+            const bf16x8 kh = *reinterpret_cast<const bf16x8*>(kb + off);
+            const bf16x8 km = *reinterpret_cast<const bf16x8*>(kb + 4096 + off);
+            const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kb + 8192 + off);
+            acc = mma(km, qf[1][s], acc);
+            acc = mma(kl, qf[0][s], acc);
+            acc = mma(kh, qf[2][s], acc);
+            acc = mma(km, qf[0][s], acc);
+            acc = mma(kh, qf[1][s], acc);
+            acc = mma(kh, qf[0][s], acc);
+        }
+        return acc;
+    };
+
+    issue_tiles(true, 0, 0, true, 0, 0);
+    if (ntiles > 1) issue_tiles(true, 1, 1, false, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 s = qk_tile(0);
+    __syncthreads();   // K(0) has been read by every wavefront before iteration 0 refills k_lds[0] with K(2)
+    auto tile_step = [&](int kt, auto ragged_tag) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
+        const int buf = kt & 1;
+        issue_tiles(kt + 2 < ntiles, kt + 2, buf, kt + 1 < ntiles, kt + 1, buf ^ 1);
+        const int key_base = kt * KT;
+        float m_tile = -INFINITY;
+        if (RAGGED) {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if (key_base + acc_row(r, half) >= N) s[r] = -INFINITY;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) m_tile = fmaxf(m_tile, s[r]);
+        m_tile = fmaxf(m_tile, other_half(m_tile));
+        if (__any(m_tile > m_run + RESCALE_THR)) {       // deferred rescale (csrc/vit_attn.hip)
+            const float m_new = fmaxf(m_run, m_tile);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { o_lo[r] *= alpha; o_hi[r] *= alpha; }
+        }
+        // Q.K^T of tile t+1 on the matrix pipe with the exponentials and the split of P of tile t in its shadow
+        f32x16 s_next = qk_tile(buf ^ 1);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            s[r] = __builtin_amdgcn_exp2f(s[r] - m_run);
+            psum += s[r];
+        }
+        l_run += psum;
+        u32x4 ph[2], pm[2], pl[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int p = 0; p < 4; p++) split_pair(s[8 * ks + 2 * p], s[8 * ks + 2 * p + 1], ph[ks][p], pm[ks][p], pl[ks][p]);
+        // ---- O^T += V^T P^T: k-step ks = slots 16 ks .. 16 ks + 15 of the tile
+        const char* vb = v_lds[buf];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const bf16x8 Ph = __builtin_bit_cast(bf16x8, ph[ks]), Pm = __builtin_bit_cast(bf16x8, pm[ks]), Pl = __builtin_bit_cast(bf16x8, pl[ks]);
+            const int off0 = v_row0 + 16 * ((2 * ks + half) ^ v_sw0), off1 = v_row1 + 16 * ((2 * ks + half) ^ v_sw1);
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(vb + off0), am = *reinterpret_cast<const bf16x8*>(vb + 4096 + off0),
+                         al = *reinterpret_cast<const bf16x8*>(vb + 8192 + off0);
+            const bf16x8 bh_ = *reinterpret_cast<const bf16x8*>(vb + off1), bm = *reinterpret_cast<const bf16x8*>(vb + 4096 + off1),
+                         bl = *reinterpret_cast<const bf16x8*>(vb + 8192 + off1);
+            o_lo = mma(am, Pm, o_lo); o_hi = mma(bm, Pm, o_hi);
+            o_lo = mma(al, Ph, o_lo); o_hi = mma(bl, Ph, o_hi);
+            o_lo = mma(ah, Pl, o_lo); o_hi = mma(bh_, Pl, o_hi);
+            o_lo = mma(am, Ph, o_lo); o_hi = mma(bm, Ph, o_hi);
+            o_lo = mma(ah, Pm, o_lo); o_hi = mma(bh_, Pm, o_hi);
+            o_lo = mma(ah, Ph, o_lo); o_hi = mma(bh_, Ph, o_hi);
+        }
+        s = s_next;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    const bool ragged = (N % KT) != 0;
+    const int full = ragged ? ntiles - 1 : ntiles;
+    for (int kt = 0; kt < full; kt++) tile_step(kt, std::false_type());
+    if (ragged) tile_step(ntiles - 1, std::true_type());
+
+    const float l_tot = l_run + other_half(l_run);
+    const float inv = 1.f / l_tot;
+    const int qslot = q0 + l31;
+    if (qslot < n_query) {
+        const int q = q_rows ? q_rows[(size_t)b * N + qslot] : qslot;
+        float* op = out + ((size_t)b * N + q) * (H * HD) + (size_t)h * HD;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int d = acc_row(r, half);
+            op[d] = o_lo[r] * inv;
+            op[d + 32] = o_hi[r] * inv;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t scp_vit_attention_split_workspace(int B, int N, int H) {
+    const size_t npad = (size_t)((N + KT - 1) / KT) * KT;
+    return (size_t)9 * B * H * npad * HD * sizeof(__bf16);
+}
+
+extern "C" int scp_vit_attention_split_forward(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale,
+                                               const int* q_rows, const int* q_count, void* workspace, size_t workspace_bytes,
+                                               void* stream) {
+    if (B <= 0 || N <= 0 || H <= 0) return scp::fail(hipErrorInvalidValue, "vit_attention_split: empty problem");
+    if (head_dim != HD) return scp::fail(hipErrorInvalidValue, "vit_attention_split: head_dim must be 64");
+    if (!qkv || !out || !workspace || (q_rows == nullptr) != (q_count == nullptr))
+        return scp::fail(hipErrorInvalidValue, "vit_attention_split: null argument");
+    if (workspace_bytes < scp_vit_attention_split_workspace(B, N, H))
+        return scp::fail(hipErrorInvalidValue, "vit_attention_split: workspace too small");
+    const int npad = ((N + KT - 1) / KT) * KT;
+    const size_t plane3 = (size_t)3 * B * H * npad * HD;
+    if (plane3 >= (1ull << 31)) return scp::fail(hipErrorInvalidValue, "vit_attention_split: operand planes larger than 2^31 elements");
+    __bf16* Qp = static_cast<__bf16*>(workspace);
+    __bf16* Kp = Qp + plane3;
+    __bf16* Vt = Kp + plane3;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float sl = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(qkv_split_kernel, dim3(npad / KT, B * H), dim3(256), 0, st, qkv, Qp, Kp, Vt, N, npad, H, sl);
+    const int qtiles = (N + 31) / 32;
+    if (qtiles % 3 == 0 && qtiles % 4 != 0) {
+        hipLaunchKernelGGL(vit_attention_split_kernel<3>, dim3(qtiles / 3, B * H), dim3(192), 0, st, Qp, Kp, Vt, out, N, npad, H, q_rows,
+                           q_count);
+    } else {
+        hipLaunchKernelGGL(vit_attention_split_kernel<4>, dim3((qtiles + 3) / 4, B * H), dim3(256), 0, st, Qp, Kp, Vt, out, N, npad, H,
+                           q_rows, q_count);
+    }
+    return scp::check_launch("vit_attention_split");
+}

@@ -82,9 +82,14 @@ class _Attention(nn.Module):
         return k.reshape(b, n, self.num_heads, c // self.num_heads).permute(0, 2, 1, 3)
 
 
-def fused_attention(qkv, b, n, heads, head_dim, scale, q_rows=None, q_count=None):
-    """HIP flash-style attention on the fp32 matrix cores (csrc/vit_attn.hip): qkv [b,n,3*heads*head_dim]
-    as produced by the qkv Linear -> [b, n, heads*head_dim].  Forward only (the DINO ViT is frozen and
+# "split": Q K^T and P V on the bf16 matrix cores with exactly split operands (csrc/vit_attn_split.hip; fp32-accurate);
+# "fp32": csrc/vit_attn.hip on the fp32 matrix cores.  SCP_VIT_ATTN=fp32 in the environment selects the latter.
+ATTN_MODE = os.environ.get("SCP_VIT_ATTN", "split")
+
+
+def fused_attention(qkv, b, n, heads, head_dim, scale, q_rows=None, q_count=None, mode=None):
+    """HIP flash-style attention on the matrix cores (csrc/vit_attn_split.hip / csrc/vit_attn.hip, see ATTN_MODE): qkv
+    [b,n,3*heads*head_dim] as produced by the qkv Linear -> [b, n, heads*head_dim].  Forward only (the DINO ViT is frozen and
     always evaluated under no_grad); GPU tensors only, no CPU fallback.
     Query selection (scp_vit_attention_forward_rows): q_rows [b,n] int32 = token index of query slot j per image, q_count [b]
     int32 = number of slots; only those tokens' outputs are produced (at their own rows; the other rows stay uninitialised),
@@ -94,13 +99,26 @@ def fused_attention(qkv, b, n, heads, head_dim, scale, q_rows=None, q_count=None
         raise RuntimeError("scp_amd.dino.fused_attention is forward-only (frozen ViT)")
     qkv = qkv.contiguous()
     out = torch.empty(b, n, heads * head_dim, dtype=torch.float32, device=qkv.device)
+    mode = ATTN_MODE if mode is None else mode
+    if mode not in ("split", "fp32"):
+        raise RuntimeError("fused_attention: unknown mode %r" % (mode,))
+    if q_rows is not None:
+        for t, name, numel in ((q_rows, "q_rows", b * n), (q_count, "q_count", b)):
+            if not (t is not None and t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and t.numel() == numel):
+                raise RuntimeError("fused_attention: %s must be a contiguous int32 device tensor of %d entries" % (name, numel))
+    if mode == "split":
+        L = capi.lib()
+        ws_bytes = L.scp_vit_attention_split_workspace(b, n, heads)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device)
+        ip = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+        capi.check(L.scp_vit_attention_split_forward(capi.dev_ptr(qkv, "qkv"), capi.dev_ptr(out, "out"), b, n, heads, head_dim,
+                                                     float(scale), ip(q_rows), ip(q_count), ctypes.c_void_p(ws.data_ptr()), ws_bytes,
+                                                     capi.current_stream()), "scp_vit_attention_split_forward")
+        return out
     if q_rows is None:
         code = capi.lib().scp_vit_attention_forward(capi.dev_ptr(qkv, "qkv"), capi.dev_ptr(out, "out"), b, n, heads,
                                                     head_dim, float(scale), capi.current_stream())
     else:
-        for t, name, numel in ((q_rows, "q_rows", b * n), (q_count, "q_count", b)):
-            if not (t is not None and t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and t.numel() == numel):
-                raise RuntimeError("fused_attention: %s must be a contiguous int32 device tensor of %d entries" % (name, numel))
         code = capi.lib().scp_vit_attention_forward_rows(capi.dev_ptr(qkv, "qkv"), capi.dev_ptr(out, "out"), b, n, heads, head_dim,
                                                          float(scale), ctypes.c_void_p(q_rows.data_ptr()),
                                                          ctypes.c_void_p(q_count.data_ptr()), capi.current_stream())
