@@ -58,11 +58,14 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 // x0, x1 -> packed (h, m, l) pairs with x = h + m + l exactly
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    h = pack_bf16(x0, x1);
-    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-    m = pack_bf16(r0, r1);
-    l = pack_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+struct Pair3 { unsigned h, m, l; };
+__device__ __forceinline__ Pair3 split_pair(float x0, float x1) {
+    Pair3 r;
+    r.h = pack_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(r.h << 16), r1 = x1 - __uint_as_float(r.h & 0xffff0000u);
+    r.m = pack_bf16(r0, r1);
+    r.l = pack_bf16(r0 - __uint_as_float(r.m << 16), r1 - __uint_as_float(r.m & 0xffff0000u));
+    return r;
 }
 
 #define SCP_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -102,8 +105,9 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict_
         u32x4 qh, qm, ql, kh, km, kl;
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            split_pair(q[2 * p], q[2 * p + 1], qh[p], qm[p], ql[p]);
-            split_pair(k[2 * p], k[2 * p + 1], kh[p], km[p], kl[p]);
+            const Pair3 a = split_pair(q[2 * p], q[2 * p + 1]), c = split_pair(k[2 * p], k[2 * p + 1]);
+            qh[p] = a.h; qm[p] = a.m; ql[p] = a.l;
+            kh[p] = c.h; km[p] = c.m; kl[p] = c.l;
         }
         const size_t o = ((size_t)bh * Npad + tok) * HD + d0;
         *reinterpret_cast<u32x4*>(Qp + o) = qh;
@@ -118,8 +122,10 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict_
         const int d = tid >> 2, g = tid & 3;
         u32x4 vh, vm, vl;
 #pragma unroll
-        for (int p = 0; p < 4; p++)
-            split_pair(vt[slot_key(8 * g + 2 * p)][d], vt[slot_key(8 * g + 2 * p + 1)][d], vh[p], vm[p], vl[p]);
+        for (int p = 0; p < 4; p++) {
+            const Pair3 a = split_pair(vt[slot_key(8 * g + 2 * p)][d], vt[slot_key(8 * g + 2 * p + 1)][d]);
+            vh[p] = a.h; vm[p] = a.m; vl[p] = a.l;
+        }
         const size_t o = ((size_t)bh * HD + d) * Npad + (size_t)tile * KT + 8 * g;
         *reinterpret_cast<u32x4*>(Vt + o) = vh;
         *reinterpret_cast<u32x4*>(Vt + plane_v + o) = vm;
@@ -211,26 +217,69 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attention_split_kernel(cons
     const int v_row0 = l31 * 64, v_sw0 = (l31 >> 2) & 3;              // d = l31
     const int v_row1 = (l31 + 32) * 64, v_sw1 = ((l31 + 32) >> 2) & 3;  // d = l31 + 32
     auto mma = [](const bf16x8& a, const bf16x8& bq, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, c, 0, 0, 0); };
-    auto qk_tile = [&](int kbuf) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    // K fragments of steps sa, sa + 1 of the tile in k_lds[kbuf] (6 ds_read_b128); V^T fragments of k-step ks (6 ds_read_b128)
+    struct KFrag { bf16x8 h[2], m[2], l[2]; };
+    struct VFrag { bf16x8 h[2], m[2], l[2]; };       // [0]: d = l31, [1]: d = l31 + 32
+    auto load_k = [&](int kbuf, int sa) {
+        KFrag f;
         const char* kb = k_lds[kbuf] + k_row;
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const int off = 16 * ((2 * s + half) ^ k_sw);
-            const bf16x8 kh = *reinterpret_cast<const bf16x8*>(kb + off);
-            const bf16x8 km = *reinterpret_cast<const bf16x8*>(kb + 4096 + off);
-            const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kb + 8192 + off);
-            acc = mma(km, qf[1][s], acc);
-            acc = mma(kl, qf[0][s], acc);
-            acc = mma(kh, qf[2][s], acc);
-            acc = mma(km, qf[0][s], acc);
-            acc = mma(kh, qf[1][s], acc);
-            acc = mma(kh, qf[0][s], acc);
+        for (int i = 0; i < 2; i++) {
+            const int off = 16 * ((2 * (sa + i) + half) ^ k_sw);
+            f.h[i] = *reinterpret_cast<const bf16x8*>(kb + off);
+            f.m[i] = *reinterpret_cast<const bf16x8*>(kb + 4096 + off);
+            f.l[i] = *reinterpret_cast<const bf16x8*>(kb + 8192 + off);
         }
-        return acc;
+        return f;
     };
+    auto load_v = [&](int vbuf, int ks) {
+        VFrag f;
+        const char* vb = v_lds[vbuf];
+        const int off0 = v_row0 + 16 * ((2 * ks + half) ^ v_sw0), off1 = v_row1 + 16 * ((2 * ks + half) ^ v_sw1);
+        f.h[0] = *reinterpret_cast<const bf16x8*>(vb + off0); f.m[0] = *reinterpret_cast<const bf16x8*>(vb + 4096 + off0);
+        f.l[0] = *reinterpret_cast<const bf16x8*>(vb + 8192 + off0);
+        f.h[1] = *reinterpret_cast<const bf16x8*>(vb + off1); f.m[1] = *reinterpret_cast<const bf16x8*>(vb + 4096 + off1);
+        f.l[1] = *reinterpret_cast<const bf16x8*>(vb + 8192 + off1);
+        return f;
+    };
+    // 12 MFMAs: steps sa, sa + 1 into two independent accumulator chains (smallest terms first)
+    auto qk_half = [&](const KFrag& f, int sa, f32x16& acc0, f32x16& acc1) {
+        acc0 = mma(f.m[0], qf[1][sa], acc0); acc1 = mma(f.m[1], qf[1][sa + 1], acc1);
+        acc0 = mma(f.l[0], qf[0][sa], acc0); acc1 = mma(f.l[1], qf[0][sa + 1], acc1);
+        acc0 = mma(f.h[0], qf[2][sa], acc0); acc1 = mma(f.h[1], qf[2][sa + 1], acc1);
+        acc0 = mma(f.m[0], qf[0][sa], acc0); acc1 = mma(f.m[1], qf[0][sa + 1], acc1);
+        acc0 = mma(f.h[0], qf[1][sa], acc0); acc1 = mma(f.h[1], qf[1][sa + 1], acc1);
+        acc0 = mma(f.h[0], qf[0][sa], acc0); acc1 = mma(f.h[1], qf[0][sa + 1], acc1);
+    };
+    auto pv_step = [&](const VFrag& f, const bf16x8& Ph, const bf16x8& Pm, const bf16x8& Pl) {
+        o_lo = mma(f.m[0], Pm, o_lo); o_hi = mma(f.m[1], Pm, o_hi);
+        o_lo = mma(f.l[0], Ph, o_lo); o_hi = mma(f.l[1], Ph, o_hi);
+        o_lo = mma(f.h[0], Pl, o_lo); o_hi = mma(f.h[1], Pl, o_hi);
+        o_lo = mma(f.m[0], Ph, o_lo); o_hi = mma(f.m[1], Ph, o_hi);
+        o_lo = mma(f.h[0], Pm, o_lo); o_hi = mma(f.h[1], Pm, o_hi);
+        o_lo = mma(f.h[0], Ph, o_lo); o_hi = mma(f.h[1], Ph, o_hi);
+    };
+    auto qk_tile = [&](int kbuf) {
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc0[r] = acc1[r] = 0.f;
+        qk_half(load_k(kbuf, 0), 0, acc0, acc1);
+        qk_half(load_k(kbuf, 2), 2, acc0, acc1);
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc0[r] += acc1[r];
+        return acc0;
+    };
+    // scheduling fences: the compiler otherwise sinks every ds_read next to its MFMA and waits for it there (12 exposed LDS
+    // latencies per tile with 1.5 wavefronts per SIMD to cover them); here each group of 6 reads is issued a whole MFMA group early
+    auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
+#define SCP_INTERLEAVE12(VALU, DS)                                        \
+    do {                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);              \
+        _Pragma("unroll") for (int g_ = 0; g_ < 12; g_++) {              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
+            __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);        \
+        }                                                                \
+    } while (0)
 
     issue_tiles(true, 0, 0, true, 0, 0);
     if (ntiles > 1) issue_tiles(true, 1, 1, false, 0, 0);
@@ -242,6 +291,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attention_split_kernel(cons
         constexpr bool RAGGED = decltype(ragged_tag)::value;
         const int buf = kt & 1;
         issue_tiles(kt + 2 < ntiles, kt + 2, buf, kt + 1 < ntiles, kt + 1, buf ^ 1);
+        // ---- region 0: first half of K(t+1)'s fragments on their way while the running maximum is taken
+        const KFrag ka = load_k(buf ^ 1, 0);
         const int key_base = kt * KT;
         float m_tile = -INFINITY;
         if (RAGGED) {
@@ -260,8 +311,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attention_split_kernel(cons
 #pragma unroll
             for (int r = 0; r < 16; r++) { o_lo[r] *= alpha; o_hi[r] *= alpha; }
         }
-        // Q.K^T of tile t+1 on the matrix pipe with the exponentials and the split of P of tile t in its shadow
-        f32x16 s_next = qk_tile(buf ^ 1);
+        fence();
+        // ---- region 1: Q.K^T(t+1) steps 0,1 | reads of steps 2,3 | exponentials of tile t
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc0[r] = acc1[r] = 0.f;
+        const KFrag kb2 = load_k(buf ^ 1, 2);
+        qk_half(ka, 0, acc0, acc1);
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -269,29 +325,30 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attention_split_kernel(cons
             psum += s[r];
         }
         l_run += psum;
+        SCP_INTERLEAVE12(4, 6);
+        fence();
+        // ---- region 2: Q.K^T(t+1) steps 2,3 | reads of V(t) k-step 0 | split of P
+        const VFrag va = load_v(buf, 0);
+        qk_half(kb2, 2, acc0, acc1);
         u32x4 ph[2], pm[2], pl[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-            for (int p = 0; p < 4; p++) split_pair(s[8 * ks + 2 * p], s[8 * ks + 2 * p + 1], ph[ks][p], pm[ks][p], pl[ks][p]);
-        // ---- O^T += V^T P^T: k-step ks = slots 16 ks .. 16 ks + 15 of the tile
-        const char* vb = v_lds[buf];
+            for (int p = 0; p < 4; p++) {
+                const Pair3 a = split_pair(s[8 * ks + 2 * p], s[8 * ks + 2 * p + 1]);
+                ph[ks][p] = a.h; pm[ks][p] = a.m; pl[ks][p] = a.l;
+            }
+        SCP_INTERLEAVE12(7, 6);
+        fence();
+        // ---- region 3: O^T += V^T P^T k-step 0 | reads of k-step 1 | the two Q.K^T chains summed
+        const VFrag vb2 = load_v(buf, 1);
+        pv_step(va, __builtin_bit_cast(bf16x8, ph[0]), __builtin_bit_cast(bf16x8, pm[0]), __builtin_bit_cast(bf16x8, pl[0]));
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            const bf16x8 Ph = __builtin_bit_cast(bf16x8, ph[ks]), Pm = __builtin_bit_cast(bf16x8, pm[ks]), Pl = __builtin_bit_cast(bf16x8, pl[ks]);
-            const int off0 = v_row0 + 16 * ((2 * ks + half) ^ v_sw0), off1 = v_row1 + 16 * ((2 * ks + half) ^ v_sw1);
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(vb + off0), am = *reinterpret_cast<const bf16x8*>(vb + 4096 + off0),
-                         al = *reinterpret_cast<const bf16x8*>(vb + 8192 + off0);
-            const bf16x8 bh_ = *reinterpret_cast<const bf16x8*>(vb + off1), bm = *reinterpret_cast<const bf16x8*>(vb + 4096 + off1),
-                         bl = *reinterpret_cast<const bf16x8*>(vb + 8192 + off1);
-            o_lo = mma(am, Pm, o_lo); o_hi = mma(bm, Pm, o_hi);
-            o_lo = mma(al, Ph, o_lo); o_hi = mma(bl, Ph, o_hi);
-            o_lo = mma(ah, Pl, o_lo); o_hi = mma(bh_, Pl, o_hi);
-            o_lo = mma(am, Ph, o_lo); o_hi = mma(bm, Ph, o_hi);
-            o_lo = mma(ah, Pm, o_lo); o_hi = mma(bh_, Pm, o_hi);
-            o_lo = mma(ah, Ph, o_lo); o_hi = mma(bh_, Ph, o_hi);
-        }
-        s = s_next;
+        for (int r = 0; r < 16; r++) s[r] = acc0[r] + acc1[r];
+        SCP_INTERLEAVE12(1, 6);
+        fence();
+        // ---- region 4: k-step 1
+        pv_step(vb2, __builtin_bit_cast(bf16x8, ph[1]), __builtin_bit_cast(bf16x8, pm[1]), __builtin_bit_cast(bf16x8, pl[1]));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
@@ -340,13 +397,10 @@ extern "C" int scp_vit_attention_split_forward(const float* qkv, float* out, int
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float sl = scale * 1.4426950408889634f;
     hipLaunchKernelGGL(qkv_split_kernel, dim3(npad / KT, B * H), dim3(256), 0, st, qkv, Qp, Kp, Vt, N, npad, H, sl);
+    // four wavefronts per workgroup, two workgroups per CU = two wavefronts per SIMD (three per workgroup fit 1025 tokens without
+    // an idle wavefront, but leave every other SIMD with a single wavefront and nothing to cover its stalls: 400 vs 368 us)
     const int qtiles = (N + 31) / 32;
-    if (qtiles % 3 == 0 && qtiles % 4 != 0) {
-        hipLaunchKernelGGL(vit_attention_split_kernel<3>, dim3(qtiles / 3, B * H), dim3(192), 0, st, Qp, Kp, Vt, out, N, npad, H, q_rows,
-                           q_count);
-    } else {
-        hipLaunchKernelGGL(vit_attention_split_kernel<4>, dim3((qtiles + 3) / 4, B * H), dim3(256), 0, st, Qp, Kp, Vt, out, N, npad, H,
-                           q_rows, q_count);
-    }
+    hipLaunchKernelGGL(vit_attention_split_kernel<4>, dim3((qtiles + 3) / 4, B * H), dim3(256), 0, st, Qp, Kp, Vt, out, N, npad, H, q_rows,
+                       q_count);
     return scp::check_launch("vit_attention_split");
 }

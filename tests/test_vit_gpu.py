@@ -10,8 +10,18 @@ from oracle import vit as oracle
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["split", "fp32"])
+def attn_mode(request):
+    """both attention kernels: bf16 matrix cores on exactly split operands (csrc/vit_attn_split.hip, the default) and the fp32
+    matrix cores (csrc/vit_attn.hip); same tolerances"""
+    from scp_amd import dino
+    old, dino.ATTN_MODE = dino.ATTN_MODE, request.param
+    yield request.param
+    dino.ATTN_MODE = old
+
+
 @pytest.mark.parametrize("B,N,H", [(1, 32, 1), (2, 1025, 6), (3, 100, 2), (1, 97, 6), (2, 257, 3)])
-def test_attention_matches_oracle(B, N, H):
+def test_attention_matches_oracle(B, N, H, attn_mode):
     from scp_amd.dino import fused_attention
     g = torch.Generator().manual_seed(N + H)
     qkv = torch.randn(B, N, 3 * H * 64, generator=g) * 1.5
@@ -21,7 +31,7 @@ def test_attention_matches_oracle(B, N, H):
     assert (d <= 2e-5 + 1e-4 * ref.abs()).all(), "max abs diff %.3e" % d.max()
 
 
-def test_attention_full_size_race_screen():
+def test_attention_full_size_race_screen(attn_mode):
     """B=32, N=1025, 6 heads (the bench shape, every CU busy): repeated launches must be bit-identical
     and match the oracle on a subset -- screens for LDS ring / DMA races that small grids hide"""
     from scp_amd.dino import fused_attention
@@ -35,7 +45,7 @@ def test_attention_full_size_race_screen():
     assert (d <= 2e-5 + 1e-4 * ref.abs()).all(), "max abs diff %.3e" % d.max()
 
 
-def test_attention_peaked_softmax():
+def test_attention_peaked_softmax(attn_mode):
     """one dominant key per query (a spike forces the online-softmax rescale branch at a chosen tile)"""
     from scp_amd.dino import fused_attention
     g = torch.Generator().manual_seed(1)
@@ -48,7 +58,7 @@ def test_attention_peaked_softmax():
     assert (got - ref).abs().max() <= 1e-4 * ref.abs().max()
 
 
-def test_attention_deferred_rescale_branch():
+def test_attention_deferred_rescale_branch(attn_mode):
     """the kernel only rescales O / l when a tile maximum exceeds the running one by > 2^16; build
     inputs where (a) scores grow slowly tile after tile (never rescaled after the first tile),
     (b) a huge late key forces a rescale for SOME queries of a wavefront only, (c) every tile forces
@@ -259,7 +269,7 @@ def test_vit_linear_with_device_row_count(gemm_mode):
 
 
 @pytest.mark.gpu
-def test_dino_features_of_kept_tokens_equal_the_full_pass():
+def test_dino_features_of_kept_tokens_equal_the_full_pass(attn_mode):
     """DINO.forward(img, keep): the last block's attention queries, proj / MLP and the key projection run on the kept tokens
     only; their features equal those of the full pass, all others are zero"""
     from scp_amd import dino
