@@ -141,8 +141,11 @@ int scp_fvm_backward(const float* img_feat, const float* mesh_feat, const float*
  * `epilogue | SCP_GEMM_W_SPLIT3`: W points to the planes [3][N][K] bf16 written by scp_split_bf16x3(W fp32) and the products run
  *   on the bf16 matrix cores with EXACTLY split operands (every fp32 value is the sum of three bf16 values; the six leading
  *   partial products of the nine are accumulated in fp32, the dropped ones are below 2^-24 of |a b|): same accuracy against
- *   float64 as the fp32 matrix-core path at ~1.5x its rate (csrc/gemm_core_split.h).  A stays fp32. */
-enum { SCP_GEMM_BIAS = 0, SCP_GEMM_BIAS_RESIDUAL = 1, SCP_GEMM_LN = 2, SCP_GEMM_LN_GELU = 3, SCP_GEMM_W_SPLIT3 = 0x100 };
+ *   float64 as the fp32 matrix-core path at ~1.5x its rate (csrc/gemm_core_split.h).  A stays fp32.
+ * `epilogue | SCP_GEMM_W_BF16`: BASELINE configs[4] precision ("mixed bf16") -- W points to ONE bf16 plane [N][K] (the weight rounded
+ *   to bf16), A (fp32) is rounded to bf16 in registers, one bf16 MFMA product, fp32 accumulation and fp32 epilogue / output. */
+enum { SCP_GEMM_BIAS = 0, SCP_GEMM_BIAS_RESIDUAL = 1, SCP_GEMM_LN = 2, SCP_GEMM_LN_GELU = 3, SCP_GEMM_W_SPLIT3 = 0x100,
+       SCP_GEMM_W_BF16 = 0x200 };
 int scp_vit_linear(const float* A, const void* W, const float* vec0, const float* vec1, const float* rowstat,
                    const float* resid, float* C, int M, int N, int K, int epilogue, void* stream);
 /* the same for a SELECTION of rows made on the device: rows_dev[0] (clamped to [0, max_rows]) rows are computed; GEMM row m
@@ -403,10 +406,11 @@ int scp_vit_attention_bf16_forward(const void* qkv, void* out, int B, int N, int
 /* ---- ViT attention on the bf16 matrix cores with exactly split operands (csrc/vit_attn_split.hip) ------------------------------
  * Same operator, layouts and accuracy as scp_vit_attention_forward[_rows] (q_rows / q_count both NULL = all queries): the qkv
  * tensor is first re-laid into bf16 operand planes in `workspace` (>= scp_vit_attention_split_workspace(B, N, H) bytes), then
- * Q K^T and P V run as six bf16 MFMA products per fp32 product, accumulated in fp32; softmax statistics in fp32. */
+ * Q K^T and P V run as six bf16 MFMA products per fp32 product, accumulated in fp32; softmax statistics in fp32.
+ * exact == 0: operands rounded to bf16 instead, one product (BASELINE configs[4] precision). */
 size_t scp_vit_attention_split_workspace(int B, int N, int H);
 int scp_vit_attention_split_forward(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale, const int* q_rows,
-                                    const int* q_count, void* workspace, size_t workspace_bytes, void* stream);
+                                    const int* q_count, int exact, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- image-space losses of the step, fused --------------------------------------------------------------------
  * Replace compute_mask_loss / compute_depth_loss / compute_match_loss (model/util/loss_utils.py:236-244, :273-284, :317-320, called

@@ -32,18 +32,21 @@ namespace scp {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
-template <int WM_, int WN_, int NWM_, int NWN_, int MINBLK_>
+// NPLANES = 3: the exact split (six products).  NPLANES = 1: operands ROUNDED to bf16 (W given as one bf16 plane, A converted in
+// registers), one product -- plain bf16 matrix-core precision with fp32 accumulation, BASELINE configs[4] ("mixed bf16").
+template <int WM_, int WN_, int NWM_, int NWN_, int MINBLK_, int NPLANES_ = 3>
 struct SplitCfg {
+    static constexpr int NPLANES = NPLANES_;
     static constexpr int WM = WM_, WN = WN_, NWM = NWM_, NWN = NWN_, NSTAGE = 2, MINBLK = MINBLK_;
     static constexpr int BM = 32 * WM * NWM, BN = 32 * WN * NWN, BK = 16;
     static constexpr int NW = NWM * NWN, THREADS = 64 * NW;
     static constexpr int A_PIECES = BM / 16;                  // 16 rows x 64 B
-    static constexpr int W_GROUPS = BN / 32, W_PIECES = 3 * W_GROUPS;   // 32 rows x 32 B, three planes
+    static constexpr int W_GROUPS = BN / 32, W_PIECES = NPLANES * W_GROUPS;   // 32 rows x 32 B per plane
     static_assert(A_PIECES % NW == 0, "A pieces are dealt evenly to the wavefronts");
     // W piece q goes to wavefront q % NW (its (q / NW)-th); with BN = 64 the six pieces leave two wavefronts with one only
     static constexpr int A_PER = A_PIECES / NW, W_PER = (W_PIECES + NW - 1) / NW;
     static constexpr int A_BYTES = BM * 64, PLANE_BYTES = BN * 32;
-    static constexpr int STAGE_BYTES = A_BYTES + 3 * PLANE_BYTES, LDS_BYTES = NSTAGE * STAGE_BYTES;
+    static constexpr int STAGE_BYTES = A_BYTES + NPLANES * PLANE_BYTES, LDS_BYTES = NSTAGE * STAGE_BYTES;
     static constexpr int NT = WM * WN;
 };
 
@@ -157,9 +160,9 @@ struct SplitGemmCore {
     template <int S>
     __device__ __forceinline__ void compute(Acc& acc) const {
         const char* st = lds + S * CFG::STAGE_BYTES;
-        bf16x8 wf[3][CFG::WN];
+        bf16x8 wf[CFG::NPLANES][CFG::WN];
 #pragma unroll
-        for (int p = 0; p < 3; p++)
+        for (int p = 0; p < CFG::NPLANES; p++)
 #pragma unroll
             for (int j = 0; j < CFG::WN; j++) wf[p][j] = *reinterpret_cast<const bf16x8*>(st + w_rd + p * CFG::PLANE_BYTES + j * 1024);
 #pragma unroll
@@ -167,6 +170,13 @@ struct SplitGemmCore {
             const f32x4 lo = *reinterpret_cast<const f32x4*>(st + a_rd[0] + i * 2048);
             const f32x4 hi = *reinterpret_cast<const f32x4*>(st + a_rd[1] + i * 2048);
             const f32x8 x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if constexpr (CFG::NPLANES == 1) {
+                const bf16x8 ah = __builtin_convertvector(x, bf16x8);
+#pragma unroll
+                for (int j = 0; j < CFG::WN; j++)
+                    acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wf[0][j], acc.t[i * CFG::WN + j], 0, 0, 0);
+                continue;
+            }
             const Split3 a = split3(x);
             // smallest terms first; six products per accumulator tile, tiles interleaved so that consecutive MFMAs are independent
             auto mac = [&](const bf16x8& av, int p) {
@@ -174,12 +184,14 @@ struct SplitGemmCore {
                 for (int j = 0; j < CFG::WN; j++)
                     acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wf[p][j], acc.t[i * CFG::WN + j], 0, 0, 0);
             };
-            mac(a.m, 1);
-            mac(a.l, 0);
-            mac(a.h, 2);
-            mac(a.m, 0);
-            mac(a.h, 1);
-            mac(a.h, 0);
+            if constexpr (CFG::NPLANES == 3) {
+                mac(a.m, 1);
+                mac(a.l, 0);
+                mac(a.h, 2);
+                mac(a.m, 0);
+                mac(a.h, 1);
+                mac(a.h, 0);
+            }
         }
     }
 

@@ -134,7 +134,9 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict_
 }
 
 // ---- 2. attention ------------------------------------------------------------------------------------------------------------
-template <int WAVES>
+// EXACT: six partial products on exactly split operands; else one product on operands rounded to bf16 (the h planes alone:
+// BASELINE configs[4] precision, softmax statistics still fp32)
+template <int WAVES, bool EXACT>
 __global__ __launch_bounds__(WAVES * 64, 2) void vit_attention_split_kernel(const __bf16* __restrict__ Qp, const __bf16* __restrict__ Kp,
                                                                          const __bf16* __restrict__ Vt, float* __restrict__ out, int N,
                                                                          int Npad, int H, const int* __restrict__ q_rows,
@@ -244,19 +246,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attention_split_kernel(cons
     };
     // 12 MFMAs: steps sa, sa + 1 into two independent accumulator chains (smallest terms first)
     auto qk_half = [&](const KFrag& f, int sa, f32x16& acc0, f32x16& acc1) {
-        acc0 = mma(f.m[0], qf[1][sa], acc0); acc1 = mma(f.m[1], qf[1][sa + 1], acc1);
-        acc0 = mma(f.l[0], qf[0][sa], acc0); acc1 = mma(f.l[1], qf[0][sa + 1], acc1);
-        acc0 = mma(f.h[0], qf[2][sa], acc0); acc1 = mma(f.h[1], qf[2][sa + 1], acc1);
-        acc0 = mma(f.m[0], qf[0][sa], acc0); acc1 = mma(f.m[1], qf[0][sa + 1], acc1);
-        acc0 = mma(f.h[0], qf[1][sa], acc0); acc1 = mma(f.h[1], qf[1][sa + 1], acc1);
+        if constexpr (EXACT) {
+            acc0 = mma(f.m[0], qf[1][sa], acc0); acc1 = mma(f.m[1], qf[1][sa + 1], acc1);
+            acc0 = mma(f.l[0], qf[0][sa], acc0); acc1 = mma(f.l[1], qf[0][sa + 1], acc1);
+            acc0 = mma(f.h[0], qf[2][sa], acc0); acc1 = mma(f.h[1], qf[2][sa + 1], acc1);
+            acc0 = mma(f.m[0], qf[0][sa], acc0); acc1 = mma(f.m[1], qf[0][sa + 1], acc1);
+            acc0 = mma(f.h[0], qf[1][sa], acc0); acc1 = mma(f.h[1], qf[1][sa + 1], acc1);
+        }
         acc0 = mma(f.h[0], qf[0][sa], acc0); acc1 = mma(f.h[1], qf[0][sa + 1], acc1);
     };
     auto pv_step = [&](const VFrag& f, const bf16x8& Ph, const bf16x8& Pm, const bf16x8& Pl) {
-        o_lo = mma(f.m[0], Pm, o_lo); o_hi = mma(f.m[1], Pm, o_hi);
-        o_lo = mma(f.l[0], Ph, o_lo); o_hi = mma(f.l[1], Ph, o_hi);
-        o_lo = mma(f.h[0], Pl, o_lo); o_hi = mma(f.h[1], Pl, o_hi);
-        o_lo = mma(f.m[0], Ph, o_lo); o_hi = mma(f.m[1], Ph, o_hi);
-        o_lo = mma(f.h[0], Pm, o_lo); o_hi = mma(f.h[1], Pm, o_hi);
+        if constexpr (EXACT) {
+            o_lo = mma(f.m[0], Pm, o_lo); o_hi = mma(f.m[1], Pm, o_hi);
+            o_lo = mma(f.l[0], Ph, o_lo); o_hi = mma(f.l[1], Ph, o_hi);
+            o_lo = mma(f.h[0], Pl, o_lo); o_hi = mma(f.h[1], Pl, o_hi);
+            o_lo = mma(f.m[0], Ph, o_lo); o_hi = mma(f.m[1], Ph, o_hi);
+            o_lo = mma(f.h[0], Pm, o_lo); o_hi = mma(f.h[1], Pm, o_hi);
+        }
         o_lo = mma(f.h[0], Ph, o_lo); o_hi = mma(f.h[1], Ph, o_hi);
     };
     auto qk_tile = [&](int kbuf) {
@@ -380,8 +386,8 @@ extern "C" size_t scp_vit_attention_split_workspace(int B, int N, int H) {
 }
 
 extern "C" int scp_vit_attention_split_forward(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale,
-                                               const int* q_rows, const int* q_count, void* workspace, size_t workspace_bytes,
-                                               void* stream) {
+                                               const int* q_rows, const int* q_count, int exact, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
     if (B <= 0 || N <= 0 || H <= 0) return scp::fail(hipErrorInvalidValue, "vit_attention_split: empty problem");
     if (head_dim != HD) return scp::fail(hipErrorInvalidValue, "vit_attention_split: head_dim must be 64");
     if (!qkv || !out || !workspace || (q_rows == nullptr) != (q_count == nullptr))
@@ -400,7 +406,8 @@ extern "C" int scp_vit_attention_split_forward(const float* qkv, float* out, int
     // four wavefronts per workgroup, two workgroups per CU = two wavefronts per SIMD (three per workgroup fit 1025 tokens without
     // an idle wavefront, but leave every other SIMD with a single wavefront and nothing to cover its stalls: 400 vs 368 us)
     const int qtiles = (N + 31) / 32;
-    hipLaunchKernelGGL(vit_attention_split_kernel<4>, dim3((qtiles + 3) / 4, B * H), dim3(256), 0, st, Qp, Kp, Vt, out, N, npad, H, q_rows,
-                       q_count);
+    const dim3 grid((qtiles + 3) / 4, B * H);
+    if (exact) hipLaunchKernelGGL((vit_attention_split_kernel<4, true>), grid, dim3(256), 0, st, Qp, Kp, Vt, out, N, npad, H, q_rows, q_count);
+    else hipLaunchKernelGGL((vit_attention_split_kernel<4, false>), grid, dim3(256), 0, st, Qp, Kp, Vt, out, N, npad, H, q_rows, q_count);
     return scp::check_launch("vit_attention_split");
 }

@@ -52,6 +52,9 @@ using QtrCfg = scp::GemmCfg<1, 2, 2, 2, 2, 2>;      //  64 x 128
 // SCP_GEMM_W_SPLIT3, W then points to the three bf16 planes of the weight (scp_split_bf16x3)
 using BigSplit = scp::SplitCfg<4, 2, 2, 2, 2>;      // 256 x 128, 2-stage ring = 56 KiB
 using QtrSplit = scp::SplitCfg<1, 2, 2, 2, 2>;      //  64 x 128
+// ... and with operands rounded to bf16, one product (SCP_GEMM_W_BF16: BASELINE configs[4] precision; W = one bf16 plane)
+using BigBf16 = scp::SplitCfg<4, 2, 2, 2, 2, 1>;
+using QtrBf16 = scp::SplitCfg<1, 2, 2, 2, 2, 1>;
 constexpr int THREADS = 256;
 constexpr int BN = 128, QM = 64;                    // column block; row quarter
 static_assert(BigCfg::BN == BN && QtrCfg::BN == BN && BigCfg::BM == 4 * QM && QtrCfg::BM == QM, "tile shapes");
@@ -181,12 +184,13 @@ __device__ __forceinline__ void run_tile(const GemmArgs& g, float* lds, int M, i
     }
 }
 
-template <int EPI, bool INDEXED, bool SPLIT>
+// CORE: 0 = fp32 matrix cores, 1 = bf16 cores on exactly split operands, 2 = bf16 cores on rounded operands
+template <int EPI, bool INDEXED, int CORE>
 __global__ __launch_bounds__(THREADS, 2) void vit_gemm_kernel(const GemmArgs g) {
-    using Big = std::conditional_t<SPLIT, BigSplit, BigCfg>;
-    using Qtr = std::conditional_t<SPLIT, QtrSplit, QtrCfg>;
-    using BigCore = std::conditional_t<SPLIT, scp::SplitGemmCore<BigSplit>, scp::GemmCore<BigCfg>>;
-    using QtrCore = std::conditional_t<SPLIT, scp::SplitGemmCore<QtrSplit>, scp::GemmCore<QtrCfg>>;
+    using Big = std::conditional_t<CORE == 1, BigSplit, std::conditional_t<CORE == 2, BigBf16, BigCfg>>;
+    using Qtr = std::conditional_t<CORE == 1, QtrSplit, std::conditional_t<CORE == 2, QtrBf16, QtrCfg>>;
+    using BigCore = std::conditional_t<CORE == 0, scp::GemmCore<BigCfg>, scp::SplitGemmCore<Big>>;
+    using QtrCore = std::conditional_t<CORE == 0, scp::GemmCore<QtrCfg>, scp::SplitGemmCore<Qtr>>;
     __shared__ __attribute__((aligned(16))) float lds[Big::LDS_BYTES / 4];
     // row count: host value, or read from the device (rows selected by an earlier kernel, no host round trip)
     int M = g.M;
@@ -342,7 +346,7 @@ int device_slots() {
     return slots;
 }
 
-template <int EPI, bool SPLIT>
+template <int EPI, int SPLIT>
 void launch(const GemmArgs& g, hipStream_t st) {
     const Plan p = make_plan(g.M, g.nblk_n, g.slots);
     // with a device-side row count the kernel redoes the plan: its big segment is never longer than the host's (nbig is
@@ -356,7 +360,7 @@ void launch(const GemmArgs& g, hipStream_t st) {
 }  // namespace
 
 namespace {
-template <bool SPLIT>
+template <int SPLIT>
 int dispatch(const GemmArgs& g, int epilogue, hipStream_t st) {
     switch (epilogue) {
         case SCP_GEMM_BIAS: launch<SCP_GEMM_BIAS, SPLIT>(g, st); break;
@@ -374,8 +378,9 @@ int vit_linear_impl(const float* A, const void* W, const float* vec0, const floa
     if (K % (BigCfg::NSTAGE * BigCfg::BK) != 0) return scp::fail(hipErrorInvalidValue, "vit_linear: K must be a multiple of 32");
     if ((size_t)M * (size_t)K >= (1ull << 30) || (size_t)N * (size_t)K >= (1ull << 30))
         return scp::fail(hipErrorInvalidValue, "vit_linear: operand larger than 2^30 elements");
-    const bool split = (epilogue & SCP_GEMM_W_SPLIT3) != 0;
-    epilogue &= ~SCP_GEMM_W_SPLIT3;
+    const bool split = (epilogue & SCP_GEMM_W_SPLIT3) != 0, bf16 = (epilogue & SCP_GEMM_W_BF16) != 0;
+    epilogue &= ~(SCP_GEMM_W_SPLIT3 | SCP_GEMM_W_BF16);
+    if (split && bf16) return scp::fail(hipErrorInvalidValue, "vit_linear: SCP_GEMM_W_SPLIT3 and SCP_GEMM_W_BF16 exclude each other");
     if (split && 3 * (size_t)N * (size_t)K >= (1ull << 31)) return scp::fail(hipErrorInvalidValue, "vit_linear: split weight larger than 2^32 bytes");
     const bool ln = epilogue == SCP_GEMM_LN || epilogue == SCP_GEMM_LN_GELU;
     if (!vec0 || (ln && (!vec1 || !rowstat)) || (epilogue == SCP_GEMM_BIAS_RESIDUAL && !resid))
@@ -387,7 +392,7 @@ int vit_linear_impl(const float* A, const void* W, const float* vec0, const floa
     g.slots = device_slots();
     g.clock = (g_clock_slots && g_clock_i < g_clock_n) ? g_clock_slots + 2 * (g_clock_i++) : nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int bad = split ? dispatch<true>(g, epilogue, st) : dispatch<false>(g, epilogue, st);
+    const int bad = split ? dispatch<1>(g, epilogue, st) : bf16 ? dispatch<2>(g, epilogue, st) : dispatch<0>(g, epilogue, st);
     if (bad) return bad;
     return scp::check_launch("vit_linear");
 }

@@ -34,6 +34,9 @@ ALLOW_RANDOM_INIT = False
 # BASELINE configs[4] (mixed bf16): the six linear layers of every block run on the bf16 matrix cores (fp32
 # accumulate); residual stream, LayerNorm, attention scores / softmax / P.V stay fp32.  Set from opts.mixed_bf16.
 MIXED_BF16 = False
+# under MIXED_BF16: the ViT through the build's own GEMM / attention kernels with bf16-rounded operands ("1"), or through
+# hipBLASLt bf16 GEMMs + csrc/vit_attn_bf16.hip with bf16 activations ("0")
+MIXED_OWN_KERNELS = os.environ.get("SCP_MIXED_OWN_KERNELS", "1") == "1"
 
 
 def _linear(layer_or_w, x, bias=None):
@@ -87,6 +90,15 @@ class _Attention(nn.Module):
 ATTN_MODE = os.environ.get("SCP_VIT_ATTN", "split")
 
 
+def attn_mode():
+    """the attention kernel of this call: BASELINE configs[4] ("mixed bf16") rounds the operands to bf16, one product"""
+    return "bf16" if MIXED_BF16 else ATTN_MODE
+
+
+def gemm_mode():
+    return "bf16" if MIXED_BF16 else GEMM_MODE
+
+
 def fused_attention(qkv, b, n, heads, head_dim, scale, q_rows=None, q_count=None, mode=None):
     """HIP flash-style attention on the matrix cores (csrc/vit_attn_split.hip / csrc/vit_attn.hip, see ATTN_MODE): qkv
     [b,n,3*heads*head_dim] as produced by the qkv Linear -> [b, n, heads*head_dim].  Forward only (the DINO ViT is frozen and
@@ -99,20 +111,21 @@ def fused_attention(qkv, b, n, heads, head_dim, scale, q_rows=None, q_count=None
         raise RuntimeError("scp_amd.dino.fused_attention is forward-only (frozen ViT)")
     qkv = qkv.contiguous()
     out = torch.empty(b, n, heads * head_dim, dtype=torch.float32, device=qkv.device)
-    mode = ATTN_MODE if mode is None else mode
-    if mode not in ("split", "fp32"):
+    mode = attn_mode() if mode is None else mode
+    if mode not in ("split", "fp32", "bf16"):
         raise RuntimeError("fused_attention: unknown mode %r" % (mode,))
     if q_rows is not None:
         for t, name, numel in ((q_rows, "q_rows", b * n), (q_count, "q_count", b)):
             if not (t is not None and t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and t.numel() == numel):
                 raise RuntimeError("fused_attention: %s must be a contiguous int32 device tensor of %d entries" % (name, numel))
-    if mode == "split":
+    if mode in ("split", "bf16"):
         L = capi.lib()
         ws_bytes = L.scp_vit_attention_split_workspace(b, n, heads)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device)
         ip = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
         capi.check(L.scp_vit_attention_split_forward(capi.dev_ptr(qkv, "qkv"), capi.dev_ptr(out, "out"), b, n, heads, head_dim,
-                                                     float(scale), ip(q_rows), ip(q_count), ctypes.c_void_p(ws.data_ptr()), ws_bytes,
+                                                     float(scale), ip(q_rows), ip(q_count), int(mode == "split"),
+                                                     ctypes.c_void_p(ws.data_ptr()), ws_bytes,
                                                      capi.current_stream()), "scp_vit_attention_split_forward")
         return out
     if q_rows is None:
@@ -162,7 +175,7 @@ def add_layernorm(x, branch, norm):
 GEMM_BIAS, GEMM_BIAS_RESIDUAL, GEMM_LN, GEMM_LN_GELU = 0, 1, 2, 3      # include/scp_hip.h SCP_GEMM_*
 
 
-GEMM_W_SPLIT3 = 0x100                                                    # include/scp_hip.h SCP_GEMM_W_SPLIT3
+GEMM_W_SPLIT3, GEMM_W_BF16 = 0x100, 0x200                                # include/scp_hip.h SCP_GEMM_W_SPLIT3 / _BF16
 # "split": products on the bf16 matrix cores with exactly split operands (fp32 = h + m + l in bf16, six partial products, fp32
 # accumulation -- csrc/gemm_core_split.h; as close to float64 as the fp32 matrix cores, ~1.5x their rate).
 # "fp32": v_mfma_f32_32x32x2_f32.  SCP_VIT_GEMM=fp32 in the environment selects the latter for a whole process.
@@ -197,8 +210,16 @@ def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilog
     if out is None:
         out = torch.empty(m, n, dtype=torch.float32, device=a.device)
     L = capi.lib()
-    mode = GEMM_MODE if mode is None else mode
-    if mode == "split":
+    mode = gemm_mode() if mode is None else mode
+    if mode == "bf16":
+        # configs[4] precision: W rounded to bf16 (one plane), A rounded in registers, one product, fp32 accumulate / output
+        if w_split is None:
+            w_split = w.detach().to(torch.bfloat16).contiguous()
+        if not (w_split.is_cuda and w_split.dtype == torch.bfloat16 and w_split.is_contiguous() and tuple(w_split.shape) == (n, k)):
+            raise RuntimeError("vit_linear: in bf16 mode w_split must be the contiguous [%d,%d] bfloat16 weight" % (n, k))
+        w_ptr = ctypes.c_void_p(w_split.data_ptr())
+        epilogue = epilogue | GEMM_W_BF16
+    elif mode == "split":
         if w_split is None:
             w_split = split_weight(w)
         if not (w_split.is_cuda and w_split.dtype == torch.bfloat16 and w_split.is_contiguous() and tuple(w_split.shape) == (3, n, k)):
@@ -269,16 +290,20 @@ class _Block(nn.Module):
         the bf16 planes of the five weight matrices the fused path multiplies with are rebuilt with them (self._planes)"""
         src = (self.norm1.weight, self.norm1.bias, self.attn.qkv.weight, self.attn.qkv.bias,
                self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias, self.attn.proj.weight, self.mlp.fc2.weight)
-        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in src) + (GEMM_MODE,)
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in src) + (gemm_mode(),)
         if getattr(self, "_fold_key", None) != key:
             with torch.no_grad():
                 self._fold = (fold_layernorm(self.norm1, self.attn.qkv.weight, self.attn.qkv.bias),
                               fold_layernorm(self.norm2, self.mlp.fc1.weight, self.mlp.fc1.bias))
                 c = self.norm1.weight.shape[0]
                 wq, w1 = self._fold[0][0], self._fold[1][0]
-                if GEMM_MODE == "split" and wq.is_cuda:
+                if gemm_mode() == "split" and wq.is_cuda:
                     self._planes = dict(qkv=split_weight(wq), k=split_weight(wq[c:2 * c]), fc1=split_weight(w1),
                                         proj=split_weight(self.attn.proj.weight), fc2=split_weight(self.mlp.fc2.weight))
+                elif gemm_mode() == "bf16" and wq.is_cuda:
+                    rnd = lambda t: t.detach().to(torch.bfloat16).contiguous()
+                    self._planes = dict(qkv=rnd(wq), k=rnd(wq[c:2 * c]), fc1=rnd(w1), proj=rnd(self.attn.proj.weight),
+                                        fc2=rnd(self.mlp.fc2.weight))
                 else:
                     self._planes = dict(qkv=None, k=None, fc1=None, proj=None, fc2=None)
             self._fold_key = key
@@ -398,8 +423,8 @@ class VisionTransformer(nn.Module):
     def key_features(self, x, layer=9, keep=None):
         """keys of block `layer`: [b, heads, tokens, d].  `keep` (bool [b, tokens - 1], patch tokens): only these tokens' keys
         are needed -- the others come back as zeros (fused GPU path; ignored elsewhere, where all keys are computed)"""
-        if x.is_cuda and not MIXED_BF16:
-            tok = self.prepare_tokens(x).contiguous()
+        if x.is_cuda and (MIXED_OWN_KERNELS or not MIXED_BF16):   # fused path; under MIXED_BF16 the same kernels, operands rounded to bf16
+            tok = self.prepare_tokens(x).float().contiguous()
             b, n, c = tok.shape
             x2d = tok.view(b * n, c)
             if keep is not None and layer >= 1:

@@ -291,3 +291,29 @@ def test_dino_features_of_kept_tokens_equal_the_full_pass(attn_mode):
     # query that shares its wavefront with different neighbours may round differently in the last bits
     torch.testing.assert_close(part[km], full[km], rtol=1e-5, atol=2e-6 * full.abs().max().item())
     assert bool((part[~km] == 0).all())
+
+
+@pytest.mark.gpu
+def test_configs4_bf16_modes_of_the_own_kernels():
+    """BASELINE configs[4] ("mixed bf16"): the same GEMM / attention kernels with operands ROUNDED to bf16, one product, fp32
+    accumulation.  Reference: float64 on the bf16-rounded operands (what the matrix cores are given), so the comparison isolates the
+    kernel from the rounding it is asked to do; the attention also rounds P, hence its looser bound."""
+    from scp_amd import dino
+    g = torch.Generator().manual_seed(23)
+    M, K, N = 1025 + 70, 384, 1152
+    a = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).cuda()
+    b = (torch.randn(N, generator=g) * 0.1).cuda()
+    got = dino.vit_linear(a, w, b, mode="bf16")
+    ref = a.bfloat16().double() @ w.bfloat16().double().t() + b.double()
+    err = (got.double() - ref).abs().max().item()
+    assert err <= 2e-5 * ref.abs().max().item(), err
+    full = a.double() @ w.double().t() + b.double()
+    assert (got.double() - full).abs().max().item() > 1e-4 * full.abs().max().item(), "bf16 mode must actually round its operands"
+    B, Nt, H = 2, 257, 3
+    qkv = (torch.randn(B, Nt, 3 * H * 64, generator=g) * 1.2).cuda()
+    out = dino.fused_attention(qkv, B, Nt, H, 64, 0.125, mode="bf16").cpu()
+    ref = oracle.attention_oracle(qkv.cpu(), H, 0.125)
+    rel = (out - ref).norm() / ref.norm()
+    assert rel <= 1e-2, rel                        # bf16 operands: ~3 significant digits
+    assert rel >= 1e-4, "bf16 mode must actually round its operands"
