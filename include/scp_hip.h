@@ -300,6 +300,11 @@ int scp_batchnorm_act_backward_bf16(const void* dy, const void* x, const void* y
  *   fixed order: deterministic); dbias (or NULL): [Cout] = sum over pixels of dy. */
 int scp_conv_nhwc_forward(const float* x, const float* w, const void* w_split, const float* bias, float* y, float* partials, int N,
                           int H, int W, int Cin, int Cout, int ksize, int stride, int leaky, float slope, void* stream);
+/* weight [Cout,Cin,k,k] fp32 with element strides (s_co, s_ci, s_ky, s_kx) -> the `w_split` planes of the forward call
+ * (planes_fwd: [3][Cout][k][k][Cin] bf16) and of the input-gradient call (planes_dgrad: [3][Cin][k][k][Cout] bf16, taps flipped;
+ * NULL = not wanted), one launch */
+int scp_conv_weight_planes(const float* w, long long s_co, long long s_ci, long long s_ky, long long s_kx, int Cout, int Cin, int ksize,
+                           void* planes_fwd, void* planes_dgrad, void* stream);
 int scp_conv_nhwc_partial_rows(int N, int H, int W, int Cout, int ksize, int stride, int split, int* tiles_m, int* rows_per_tile);
 /* convolution (no bias) + the batch statistics of the nn.BatchNorm2d that follows it (training mode), one launch: the per-tile
  * partial sums go to `workspace` (>= 2 * tiles_m * Cout floats), the last workgroup of the launch (ticket: a zeroed device word,

@@ -244,6 +244,31 @@ __global__ __launch_bounds__(FCFG::THREADS, 2) void conv_igemm_kernel(const Conv
     }
 }
 
+// weight [Cout, Cin, k, k] (any strides) -> the split operand planes of both directions in one pass:
+//   fwd   [3][Cout][k][k][Cin]   the W operand of the forward implicit GEMM,
+//   dgrad [3][Cin][k][k][Cout]   taps flipped: the W operand of the input gradient (NULL: not wanted)
+__global__ void conv_weight_planes_kernel(const float* __restrict__ w, long s_co, long s_ci, long s_ky, long s_kx, int Cout, int Cin,
+                                          int k, __bf16* __restrict__ fwd, __bf16* __restrict__ dgrad) {
+    const long n = (long)Cout * Cin * k * k;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // fwd order: ((co k + ky) k + kx) Cin + ci
+    if (i >= n) return;
+    const int ci = (int)(i % Cin);
+    long r = i / Cin;
+    const int kx = (int)(r % k);
+    r /= k;
+    const int ky = (int)(r % k), co = (int)(r / k);
+    const float v = w[co * s_co + ci * s_ci + ky * s_ky + kx * s_kx];
+    const __bf16 h = (__bf16)v;
+    const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);
+    fwd[i] = h; fwd[n + i] = m; fwd[2 * n + i] = l;
+    if (dgrad) {
+        const long j = (((long)ci * k + (k - 1 - ky)) * k + (k - 1 - kx)) * Cout + co;
+        dgrad[j] = h; dgrad[n + j] = m; dgrad[2 * n + j] = l;
+    }
+}
+
 using Cfg256x64 = scp::GemmCfg<2, 2, 4, 1, 2, 2>;     // 64-channel layers at 64 x 64 resolution
 using Cfg64x128 = scp::GemmCfg<1, 2, 2, 2, 2, 2>;
 using Cfg64x64 = scp::GemmCfg<1, 1, 2, 2, 2, 2>;
@@ -369,4 +394,14 @@ extern "C" int scp_conv_nhwc_forward_bn(const float* x, const float* w, const vo
     const scp_bn::FwdFinalize fin{0, gamma, beta, running_mean, running_var, batches_tracked, momentum, eps, save_mean, save_invstd,
                                   save_scale, save_shift};
     return conv_forward_impl(x, w, w_split, nullptr, y, static_cast<float*>(workspace), ticket, &fin, N, H, W, Cin, Cout, ksize, stride, 0, 0.f, stream);
+}
+
+extern "C" int scp_conv_weight_planes(const float* w, long long s_co, long long s_ci, long long s_ky, long long s_kx, int Cout, int Cin,
+                                      int ksize, void* planes_fwd, void* planes_dgrad, void* stream) {
+    if (!w || !planes_fwd || Cout <= 0 || Cin <= 0 || ksize <= 0) return scp::fail(hipErrorInvalidValue, "conv_weight_planes: bad argument");
+    const long n = (long)Cout * Cin * ksize * ksize;
+    hipLaunchKernelGGL(conv_weight_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                       (long)s_co, (long)s_ci, (long)s_ky, (long)s_kx, Cout, Cin, ksize, static_cast<__bf16*>(planes_fwd),
+                       static_cast<__bf16*>(planes_dgrad));
+    return scp::check_launch("conv_weight_planes");
 }

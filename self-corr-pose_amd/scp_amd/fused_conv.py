@@ -84,11 +84,16 @@ def weight_planes(conv, with_dgrad):
     cache = conv.__dict__.get("_scp_planes")
     if cache is None or cache["key"] != key:
         cache = conv.__dict__["_scp_planes"] = {"key": key}
-    with torch.no_grad():
-        if "fwd" not in cache:
-            cache["fwd"] = split_planes(w.detach().permute(0, 2, 3, 1).contiguous())
-        if with_dgrad and "dgrad" not in cache:
-            cache["dgrad"] = split_planes(w.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous())
+    if "fwd" not in cache or (with_dgrad and "dgrad" not in cache):
+        cout, cin, k, _ = w.shape
+        fwd = torch.empty(3, cout, k, k, cin, dtype=torch.bfloat16, device=w.device)
+        dgrad = torch.empty(3, cin, k, k, cout, dtype=torch.bfloat16, device=w.device) if with_dgrad else None
+        wd = w.detach()
+        capi.check(capi.lib().scp_conv_weight_planes(ctypes.c_void_p(wd.data_ptr()), wd.stride(0), wd.stride(1), wd.stride(2), wd.stride(3),
+                                                     cout, cin, k, _ptr(fwd), _ptr(dgrad), capi.current_stream()), "conv_weight_planes")
+        cache["fwd"] = fwd
+        if with_dgrad:
+            cache["dgrad"] = dgrad
     return cache
 
 

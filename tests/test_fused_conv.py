@@ -165,3 +165,24 @@ def test_encoder_with_own_convolutions_is_as_accurate_as_the_stock_path(monkeypa
     print("parameters beyond the tight bound (behind a flipped ReLU): %d of %d, worst %.2e" % (
         len(flipped), len(grads_c), max([f[1] for f in flipped], default=0.0)))
     print("encoder gradients, worst parameter %s: own %.2e, stock %.2e (relative L2 vs float64)" % (worst[2], worst[0], worst[1]))
+
+
+def test_weight_planes_kernel_equals_the_torch_composition():
+    """scp_conv_weight_planes: both operand-plane sets of a convolution weight in one launch == split_planes of the
+    channels_last weight (forward) and of the flipped / transposed weight (input gradient), for contiguous and channels_last
+    parameter storage; and the planes sum back to the weight exactly"""
+    from scp_amd import fused_conv
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        conv = nn.Conv2d(64, 96, 3, padding=1, bias=False).cuda().to(memory_format=fmt)
+        with torch.no_grad():
+            conv.weight.mul_(torch.exp2(torch.randint(-8, 9, conv.weight.shape, device="cuda").float()))
+        old, fused_conv.CONV_MODE = fused_conv.CONV_MODE, "split"
+        try:
+            cache = fused_conv.weight_planes(conv, True)
+        finally:
+            fused_conv.CONV_MODE = old
+        w = conv.weight.detach()
+        ref_f = fused_conv.split_planes(w.permute(0, 2, 3, 1).contiguous())
+        ref_d = fused_conv.split_planes(w.flip(2, 3).permute(1, 2, 3, 0).contiguous())
+        assert torch.equal(cache["fwd"], ref_f) and torch.equal(cache["dgrad"], ref_d)
+        assert torch.equal(cache["fwd"].double().sum(0), w.permute(0, 2, 3, 1).double())
