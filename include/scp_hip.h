@@ -299,13 +299,19 @@ int scp_batchnorm_act_backward_bf16(const void* dy, const void* x, const void* y
  *   dy [N,Ho,Wo,Cout]; workspace >= scp_conv_nhwc_weight_grad_workspace(...) bytes (partial sums of the pixel split, folded in a
  *   fixed order: deterministic); dbias (or NULL): [Cout] = sum over pixels of dy. */
 int scp_conv_nhwc_forward(const float* x, const float* w, const void* w_split, const float* bias, float* y, float* partials, int N,
-                          int H, int W, int Cin, int Cout, int ksize, int stride, int leaky, float slope, void* stream);
+                          int H, int W, int Cin, int Cout, int ksize, int stride, int leaky, float slope, void* splitk_ws,
+                          size_t splitk_bytes, void* stream);
+/* With w_split the deep layers (few pixels, long K) run split-K: 2 / 4 / 8 workgroups per 128 x 128 tile write raw partial tiles
+ * into `splitk_ws` and a fold kernel adds them and applies the epilogue / statistics.  The caller passes a buffer of
+ * scp_conv_nhwc_splitk_workspace(...) bytes (0: this layer does not split; the buffer may then be NULL). */
+size_t scp_conv_nhwc_splitk_workspace(int N, int H, int W, int Cin, int Cout, int ksize, int stride, int split);
 /* weight [Cout,Cin,k,k] fp32 with element strides (s_co, s_ci, s_ky, s_kx) -> the `w_split` planes of the forward call
  * (planes_fwd: [3][Cout][k][k][Cin] bf16) and of the input-gradient call (planes_dgrad: [3][Cin][k][k][Cout] bf16, taps flipped;
  * NULL = not wanted), one launch */
 int scp_conv_weight_planes(const float* w, long long s_co, long long s_ci, long long s_ky, long long s_kx, int Cout, int Cin, int ksize,
                            void* planes_fwd, void* planes_dgrad, void* stream);
-int scp_conv_nhwc_partial_rows(int N, int H, int W, int Cout, int ksize, int stride, int split, int* tiles_m, int* rows_per_tile);
+int scp_conv_nhwc_partial_rows(int N, int H, int W, int Cin, int Cout, int ksize, int stride, int split, int* tiles_m,
+                               int* rows_per_tile);
 /* convolution (no bias) + the batch statistics of the nn.BatchNorm2d that follows it (training mode), one launch: the per-tile
  * partial sums go to `workspace` (>= 2 * tiles_m * Cout floats), the last workgroup of the launch (ticket: a zeroed device word,
  * re-armed by the kernel) folds them in fp64 in tile order and writes save_mean / save_invstd / save_scale (= gamma invstd) /
@@ -315,7 +321,7 @@ int scp_conv_nhwc_forward_bn(const float* x, const float* w, const void* w_split
                              const float* gamma, const float* beta, float* running_mean, float* running_var,
                              long long* batches_tracked, float momentum, float eps, float* save_mean, float* save_invstd,
                              float* save_scale, float* save_shift, void* workspace, size_t workspace_bytes, unsigned* ticket,
-                             void* stream);
+                             void* splitk_ws, size_t splitk_bytes, void* stream);
 int scp_batchnorm_apply(const float* x, const float* skip, const float* scale, const float* shift, long R, int C, int relu, float* y,
                         void* stream);
 size_t scp_conv_nhwc_weight_grad_workspace(int N, int H, int W, int Cin, int Cout, int ksize, int stride);

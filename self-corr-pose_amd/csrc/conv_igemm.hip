@@ -40,11 +40,14 @@ struct ConvArgs {
     const float* bias;     // [Cout] or nullptr
     float* y;              // [N, Ho, Wo, Cout]
     float* partials;       // [2][tiles_m][Cout] (sums, then sums of squares) or nullptr
+    float* ypart;          // split-K: [ksplit][M][Cout] raw partial outputs (folded by conv_splitk_fold_kernel)
+    int ksplit, nk_split;  // split-K: workgroups per tile, chunks per workgroup
     unsigned* ticket;      // with partials: the last workgroup folds them and finalises the BatchNorm statistics (fin)
     scp_bn::FwdFinalize fin;
     int H, W, Ho, Wo, Cin, Cout, M, K;
     int stride, lg_cpt;    // chunks per tap = Cin / 16 = 1 << lg_cpt
-    int nblk_n, tiles_m;
+    int nblk_n, tiles_m;   // tiles_m: row tiles of the statistics partials (= the kernel's, or the fold kernel's with split-K)
+    int tiles_m_kernel;    // row tiles of the convolution kernel's grid
     unsigned x_bytes;
     float slope;
 };
@@ -163,25 +166,34 @@ __global__ __launch_bounds__(FCFG::THREADS, 2) void conv_igemm_kernel(const Conv
     using Core = std::conditional_t<SPLIT, scp::SplitGemmCore<SplitOf<FCFG>, ConvASource<SplitOf<FCFG>, TAPS>>,
                                     scp::GemmCore<FCFG, ConvSource<FCFG, TAPS>>>;
     // tile order: workgroup t runs on XCD t % 8; consecutive tiles of one XCD walk the column blocks of one pixel panel
-    const int total = g.tiles_m * g.nblk_n;
+    // split-K (split main loop, deep layers): ksplit consecutive workgroups share a tile, each its own range of K chunks; they
+    // write raw partial tiles, conv_splitk_fold_kernel adds them and applies the epilogue / statistics
+    const int ksplit = SPLIT ? g.ksplit : 1;
+    const int total = g.tiles_m_kernel * g.nblk_n * ksplit;
     const int per_xcd = (total + 7) >> 3;
-    const int lid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (lid >= total) {
+    const int lid0 = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lid0 >= total) {
         // a padding workgroup still takes its ticket (the last arrival is counted over the whole grid); it can be the last
         if (STATS && g.ticket && scp_bn::last_block_arrived(g.ticket)) finalize_statistics(g, lds);
         return;
     }
+    const int lid = lid0 / ksplit, ks = lid0 - lid * ksplit;
     const int bm = lid / g.nblk_n, bn = lid - bm * g.nblk_n;
     const int m0 = bm * CFG::BM, n0 = bn * CFG::BN;
     Core core(lds);
+    float* yout = g.y;
     if constexpr (SPLIT) {
         core.asrc.set(g, m0, core.wave, core.lane);
         core.set_w_rows(g.w_split, g.Cout, g.K, [&](int r) { return min(n0 + r, g.Cout - 1); });
+        if (ksplit > 1) {
+            core.kc0 = ks * g.nk_split;
+            yout = g.ypart + (size_t)ks * g.M * g.Cout;
+        }
     } else {
         core.src.set(g, m0, n0, core.wave, core.lane);
     }
     typename Core::Acc acc;
-    core.run(acc, g.K / CFG::BK);
+    core.run(acc, (SPLIT && ksplit > 1) ? g.nk_split : g.K / CFG::BK);
 
     const int half = core.lane >> 5, l31 = core.lane & 31;
     float csum[CFG::WN], csq[CFG::WN];
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(FCFG::THREADS, 2) void conv_igemm_kernel(const Conv
                     v += b;
                     v = v > 0.f ? v : v * g.slope;
                 }
-                if (live) g.y[(size_t)m * g.Cout + n] = v;
+                if (live) yout[(size_t)m * g.Cout + n] = v;
             }
         }
     }
@@ -277,8 +289,8 @@ using Cfg128x128 = scp::GemmCfg<2, 2, 2, 2, 2, 2>;    // split main loop only: i
 template <class CFG, int TAPS>
 void launch_cfg(ConvArgs& g, bool leaky, bool stats, hipStream_t st) {
     g.nblk_n = (g.Cout + CFG::BN - 1) / CFG::BN;
-    g.tiles_m = (g.M + CFG::BM - 1) / CFG::BM;
-    const int total = g.tiles_m * g.nblk_n;
+    g.tiles_m = g.tiles_m_kernel = (g.M + CFG::BM - 1) / CFG::BM;
+    const int total = g.tiles_m * g.nblk_n * (g.w_split && g.ksplit > 1 ? g.ksplit : 1);
     const dim3 grid(((total + 7) >> 3) << 3), block(CFG::THREADS);
     if (g.w_split) {
         if (leaky) {
@@ -299,39 +311,126 @@ void launch_cfg(ConvArgs& g, bool leaky, bool stats, hipStream_t st) {
     }
 }
 
-// tile shape of a layer: the widest tile that still gives the machine >= 256 workgroups
-int pick_cfg(long M, int Cout, bool split) {
-    if (Cout <= 64) return 0;                                                      // 256 x 64
+// y[m][n] = epilogue(sum over the K splits of ypart[s][m][n]); with STATS also the column sums / sums of squares of the RAW output
+// per tile of 128 rows (the partials protocol of the convolution kernel's own epilogue), the last workgroup finalises the batch
+// statistics.  grid = row tiles x ceil(Cout / 256); thread = 4 columns x one of 4 row lanes.
+template <int EPI, bool STATS>
+__global__ __launch_bounds__(256) void conv_splitk_fold_kernel(const ConvArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[2048];
+    const int colblocks = (g.Cout + 255) / 256;
+    const int bm = blockIdx.x / colblocks, cb = blockIdx.x - bm * colblocks;
+    const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = cb * 256 + 4 * cq;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < g.Cout) {
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (EPI == EPI_BIAS_LEAKY) {
+            const float4 t = *reinterpret_cast<const float4*>(g.bias + n);
+            b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
+        }
+        const size_t split_stride = (size_t)g.M * g.Cout;
+        for (int r = rl; r < 128; r += 4) {
+            const int m = bm * 128 + r;
+            if (m >= g.M) break;
+            const float* src = g.ypart + (size_t)m * g.Cout + n;
+            float4 a = *reinterpret_cast<const float4*>(src);
+            for (int sidx = 1; sidx < g.ksplit; sidx++) {
+                const float4 t = *reinterpret_cast<const float4*>(src + sidx * split_stride);
+                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+            }
+            float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (STATS) {
+                    cs[i] += v[i];
+                    cq2[i] += v[i] * v[i];
+                }
+                if (EPI == EPI_BIAS_LEAKY) {
+                    v[i] += b[i];
+                    v[i] = v[i] > 0.f ? v[i] : v[i] * g.slope;
+                }
+            }
+            *reinterpret_cast<float4*>(g.y + (size_t)m * g.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    if (STATS) {
+        float* red = lds;                                   // [4 row lanes][64 column quads][8]
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            red[(rl * 64 + cq) * 8 + i] = cs[i];
+            red[(rl * 64 + cq) * 8 + 4 + i] = cq2[i];
+        }
+        __syncthreads();
+        if (rl == 0 && n < g.Cout) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int l = 0; l < 4; l++) {
+                    a += red[(l * 64 + cq) * 8 + i];
+                    q += red[(l * 64 + cq) * 8 + 4 + i];
+                }
+                __hip_atomic_store(g.partials + ((size_t)0 * g.tiles_m + bm) * g.Cout + n + i, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g.partials + ((size_t)1 * g.tiles_m + bm) * g.Cout + n + i, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (g.ticket && scp_bn::last_block_arrived(g.ticket)) finalize_statistics(g, lds);
+    }
+}
+
+// How a layer is run: tile shape (0: 256 x 64, 1: 64 x 128, 2: 64 x 64, 3: 128 x 128) and K splits.
+struct ConvPlan { int cfg, ksplit; };
+ConvPlan plan_conv(long M, int Cout, int K, bool split) {
+    if (Cout <= 64) return {0, 1};                                                 // 256 x 64
     const long t128 = ((M + 63) / 64) * ((Cout + 127) / 128);
     if (split) {
         // the split main loop does 2.7x less matrix-pipe work per chunk while its barriers, DMA waits and operand splits stay:
-        // the largest tile that still gives every CU a workgroup
-        // (measured per layer, tools/conv_bench.py: 128 x 128 on half the CUs and 64 x 128 are both slower than 64 x 64 there)
-        if (((M + 127) / 128) * ((Cout + 127) / 128) >= 256) return 3;             // 128 x 128
+        // 128 x 128 (24 MFMAs per wavefront and chunk) wherever that gives every CU a workgroup ...
+        const long t = ((M + 127) / 128) * ((Cout + 127) / 128);
+        if (t >= 256) return {3, 1};
+        // ... and where it does not (the 16 x 16 / 8 x 8 layers: few pixels, K = 9 Cin up to 4608), the same tile with the K range
+        // cut over 2 / 4 / 8 workgroups and a fold pass: one 128 x 128 workgroup per CU runs at ~0.7 TFLOP/s, 64 x 64 tiles that
+        // fill the machine at half that per flop (tools/conv_bench.py)
+        const int nk = K / 16;
+        if (t >= 32 && nk >= 128 && Cout % 4 == 0) {
+            // every split keeps >= 64 chunks (a shorter main loop is dominated by its prologue / epilogue: the stride-2 layers,
+            // K = 1152 / 2304, stay on 64 x 64 tiles), and the launch must reach ~one workgroup per CU
+            int ks = 1;
+            while (ks < 8 && t * ks < 256 && nk % (4 * ks) == 0 && nk / (2 * ks) >= 64) ks *= 2;
+            if (ks > 1 && t * ks >= 192) return {3, ks};
+        }
     }
     // 64 x 128 while that still gives >= 384 workgroups, else 64 x 64 (measured inside the step: filling the machine with the
     // smaller tile beats the larger tile on half the CUs, 39.8 vs 40.4 ms)
-    return t128 >= 384 ? 1 : 2;
+    return {t128 >= 384 ? 1 : 2, 1};
 }
 int tile_rows(int cfg) { return cfg == 0 ? Cfg256x64::BM : cfg == 3 ? Cfg128x128::BM : 64; }
 
 }  // namespace
 
-extern "C" int scp_conv_nhwc_partial_rows(int N, int H, int W, int Cout, int ksize, int stride, int split, int* tiles_m,
+extern "C" int scp_conv_nhwc_partial_rows(int N, int H, int W, int Cin, int Cout, int ksize, int stride, int split, int* tiles_m,
                                           int* rows_per_tile) {
     const int pad = ksize / 2;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const long M = (long)N * Ho * Wo;
-    const int rows = tile_rows(pick_cfg(M, Cout, split != 0));
+    const int rows = tile_rows(plan_conv(M, Cout, ksize * ksize * Cin, split != 0).cfg);
     if (tiles_m) *tiles_m = (int)((M + rows - 1) / rows);
     if (rows_per_tile) *rows_per_tile = rows;
     return 0;
 }
 
+extern "C" size_t scp_conv_nhwc_splitk_workspace(int N, int H, int W, int Cin, int Cout, int ksize, int stride, int split) {
+    const int pad = ksize / 2;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const long M = (long)N * Ho * Wo;
+    const ConvPlan pl = plan_conv(M, Cout, ksize * ksize * Cin, split != 0);
+    return pl.ksplit > 1 ? (size_t)pl.ksplit * M * Cout * sizeof(float) : 0;
+}
+
 namespace {
 int conv_forward_impl(const float* x, const float* w, const void* w_split, const float* bias, float* y, float* partials, unsigned* ticket,
                       const scp_bn::FwdFinalize* fin, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int leaky,
-                      float slope, void* stream) {
+                      float slope, void* splitk_ws, size_t splitk_bytes, void* stream) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return scp::fail(hipErrorInvalidValue, "conv_nhwc: empty problem");
     if (!x || (!w && !w_split) || !y || (leaky && !bias)) return scp::fail(hipErrorInvalidValue, "conv_nhwc: null argument");
     if (ksize != 1 && ksize != 3) return scp::fail(hipErrorInvalidValue, "conv_nhwc: kernel size must be 1 or 3");
@@ -358,8 +457,29 @@ int conv_forward_impl(const float* x, const float* w, const void* w_split, const
         g.fin.R = M;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int cfg = pick_cfg(M, Cout, w_split != nullptr);
+    const ConvPlan pl = plan_conv(M, Cout, g.K, w_split != nullptr);
+    const int cfg = pl.cfg;
     const bool stats = partials != nullptr;
+    g.ksplit = pl.ksplit;
+    if (pl.ksplit > 1) {
+        // raw partial tiles by the convolution kernel, epilogue / statistics by the fold kernel
+        if (!splitk_ws || splitk_bytes < (size_t)pl.ksplit * M * Cout * sizeof(float))
+            return scp::fail(hipErrorInvalidValue, "conv_nhwc: this layer runs split-K, pass scp_conv_nhwc_splitk_workspace() bytes");
+        g.ypart = static_cast<float*>(splitk_ws);
+        g.nk_split = (g.K / 16) / pl.ksplit;
+        if (ksize == 3) launch_cfg<Cfg128x128, 9>(g, false, false, st);
+        else launch_cfg<Cfg128x128, 1>(g, false, false, st);
+        g.tiles_m = (g.M + 127) / 128;
+        const dim3 grid(g.tiles_m * ((Cout + 255) / 256)), block(256);
+        if (leaky) {
+            if (stats) hipLaunchKernelGGL((conv_splitk_fold_kernel<EPI_BIAS_LEAKY, true>), grid, block, 0, st, g);
+            else hipLaunchKernelGGL((conv_splitk_fold_kernel<EPI_BIAS_LEAKY, false>), grid, block, 0, st, g);
+        } else {
+            if (stats) hipLaunchKernelGGL((conv_splitk_fold_kernel<EPI_RAW, true>), grid, block, 0, st, g);
+            else hipLaunchKernelGGL((conv_splitk_fold_kernel<EPI_RAW, false>), grid, block, 0, st, g);
+        }
+        return scp::check_launch("conv_nhwc_forward (split-K)");
+    }
     if (ksize == 3) {
         if (cfg == 0) launch_cfg<Cfg256x64, 9>(g, leaky, stats, st);
         else if (cfg == 1) launch_cfg<Cfg64x128, 9>(g, leaky, stats, st);
@@ -377,23 +497,25 @@ int conv_forward_impl(const float* x, const float* w, const void* w_split, const
 
 extern "C" int scp_conv_nhwc_forward(const float* x, const float* w, const void* w_split, const float* bias, float* y, float* partials,
                                      int N, int H, int W, int Cin, int Cout, int ksize, int stride, int leaky, float slope,
-                                     void* stream) {
-    return conv_forward_impl(x, w, w_split, bias, y, partials, nullptr, nullptr, N, H, W, Cin, Cout, ksize, stride, leaky, slope, stream);
+                                     void* splitk_ws, size_t splitk_bytes, void* stream) {
+    return conv_forward_impl(x, w, w_split, bias, y, partials, nullptr, nullptr, N, H, W, Cin, Cout, ksize, stride, leaky, slope, splitk_ws,
+                             splitk_bytes, stream);
 }
 
 extern "C" int scp_conv_nhwc_forward_bn(const float* x, const float* w, const void* w_split, float* y, int N, int H, int W, int Cin, int Cout, int ksize,
                                         int stride, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                         long long* batches_tracked, float momentum, float eps, float* save_mean, float* save_invstd,
                                         float* save_scale, float* save_shift, void* workspace, size_t workspace_bytes, unsigned* ticket,
-                                        void* stream) {
+                                        void* splitk_ws, size_t splitk_bytes, void* stream) {
     if (!save_mean || !save_invstd || !save_scale || !save_shift || !workspace || !ticket)
         return scp::fail(hipErrorInvalidValue, "conv_nhwc_forward_bn: null argument");
     int tiles_m = 0;
-    scp_conv_nhwc_partial_rows(N, H, W, Cout, ksize, stride, w_split != nullptr, &tiles_m, nullptr);
+    scp_conv_nhwc_partial_rows(N, H, W, Cin, Cout, ksize, stride, w_split != nullptr, &tiles_m, nullptr);
     if (workspace_bytes < (size_t)2 * tiles_m * Cout * sizeof(float)) return scp::fail(hipErrorInvalidValue, "conv_nhwc_forward_bn: workspace too small");
     const scp_bn::FwdFinalize fin{0, gamma, beta, running_mean, running_var, batches_tracked, momentum, eps, save_mean, save_invstd,
                                   save_scale, save_shift};
-    return conv_forward_impl(x, w, w_split, nullptr, y, static_cast<float*>(workspace), ticket, &fin, N, H, W, Cin, Cout, ksize, stride, 0, 0.f, stream);
+    return conv_forward_impl(x, w, w_split, nullptr, y, static_cast<float*>(workspace), ticket, &fin, N, H, W, Cin, Cout, ksize, stride, 0, 0.f,
+                             splitk_ws, splitk_bytes, stream);
 }
 
 extern "C" int scp_conv_weight_planes(const float* w, long long s_co, long long s_ci, long long s_ky, long long s_kx, int Cout, int Cin,

@@ -110,6 +110,7 @@ struct SplitGemmCore {
     unsigned lds0;                 // its LDS byte address (DMA destinations)
     unsigned a_rd[2], w_rd;        // lane's fragment byte offsets inside a stage (tile 0)
     int wave, lane;
+    int kc0 = 0;                   // first chunk of this workgroup's K range (split-K callers set it before run())
 
     __device__ __forceinline__ SplitGemmCore(float* lds_) {
         lds = reinterpret_cast<char*>(lds_);
@@ -149,6 +150,7 @@ struct SplitGemmCore {
 
     __device__ __forceinline__ void issue(int kc, int stage) const {
         const unsigned dst = lds0 + stage * CFG::STAGE_BYTES;
+        kc += kc0;
         static_for<0, CFG::A_PER>([&](auto i) { asrc.template issue<decltype(i)::value>(kc, dst, wave); });
         static_for<0, CFG::W_PER>([&](auto i) {
             constexpr int I = decltype(i)::value;

@@ -83,13 +83,14 @@ SYMBOLS = {
     "scp_bias_leaky_relu_forward_bf16": (ctypes.c_int, [_P, _P, _F, ctypes.c_long, _I, _P]),
     "scp_bias_leaky_relu_backward": (ctypes.c_int, [_P, _P, _F, ctypes.c_long, _I, _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "scp_bias_leaky_relu_backward_bf16": (ctypes.c_int, [_P, _P, _F, ctypes.c_long, _I, _P, _P, _P, ctypes.c_size_t, _P, _P]),
-    "scp_conv_nhwc_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "scp_conv_nhwc_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, ctypes.c_size_t, _P]),
+    "scp_conv_nhwc_splitk_workspace": (ctypes.c_size_t, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "scp_conv_nhwc_forward_bn": (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P,
-                                                ctypes.c_size_t, _P, _P]),
+                                                ctypes.c_size_t, _P, _P, ctypes.c_size_t, _P]),
     "scp_batchnorm_apply": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_long, _I, _I, _P, _P]),
     "scp_conv_weight_planes": (ctypes.c_int, [_P, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _I, _I, _I,
                                               _P, _P, _P]),
-    "scp_conv_nhwc_partial_rows": (ctypes.c_int, [_I, _I, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "scp_conv_nhwc_partial_rows": (ctypes.c_int, [_I, _I, _I, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "scp_conv_nhwc_weight_grad_workspace": (ctypes.c_size_t, [_I, _I, _I, _I, _I, _I, _I]),
     "scp_conv_nhwc_weight_grad": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _I, _I, _I, _I, _I, _I, _I, _P]),
     "scp_posefit_workspace": (ctypes.c_size_t, [_I, _I, _I]),

@@ -105,14 +105,24 @@ def _planes_arg(conv, x, stride):
     return weight_planes(conv, need_dx)
 
 
+def _splitk(n, h, w, cin, cout, k, stride, split, device):
+    """(buffer, bytes) for the split-K partial tiles of this layer (include/scp_hip.h: scp_conv_nhwc_splitk_workspace); (None, 0)
+    when the layer does not split"""
+    nbytes = capi.lib().scp_conv_nhwc_splitk_workspace(n, h, w, cin, cout, k, stride, int(split))
+    if not nbytes:
+        return None, 0
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device), nbytes
+
+
 def _conv_forward(x, weight, bias, stride, leaky, slope, planes=None):
     """raw own forward: x, weight channels_last; returns a channels_last tensor"""
     L = capi.lib()
     n, cin, h, w = x.shape
     cout, k = weight.shape[0], weight.shape[2]
     y = torch.empty(_conv_out_shape(x, weight, stride), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    sk, sk_bytes = _splitk(n, h, w, cin, cout, k, stride, planes is not None, x.device)
     capi.check(L.scp_conv_nhwc_forward(_ptr(x), _ptr(None if planes else weight), _ptr(planes["fwd"] if planes else None), _ptr(bias),
-                                       _ptr(y), _ptr(None), n, h, w, cin, cout, k, stride, int(leaky), float(slope),
+                                       _ptr(y), _ptr(None), n, h, w, cin, cout, k, stride, int(leaky), float(slope), _ptr(sk), sk_bytes,
                                        capi.current_stream()), "conv_nhwc_forward")
     return y
 
@@ -130,8 +140,9 @@ def _conv_backward(x, weight, g, stride, need_dx, need_dw, planes=None):
         wt3 = planes.get("dgrad") if planes else None
         wt = None if wt3 is not None else weight.flip(2, 3).permute(1, 2, 3, 0).contiguous()
         dx = torch.empty(x.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        sk, sk_bytes = _splitk(n, h, w, cout, cin, k, 1, wt3 is not None, x.device)
         capi.check(L.scp_conv_nhwc_forward(_ptr(g), _ptr(wt), _ptr(wt3), _ptr(None), _ptr(dx), _ptr(None), n, h, w, cout, cin, k, 1, 0,
-                                           0.0, capi.current_stream()), "conv_nhwc_forward (input gradient)")
+                                           0.0, _ptr(sk), sk_bytes, capi.current_stream()), "conv_nhwc_forward (input gradient)")
     if own_dw:
         ws_bytes = L.scp_conv_nhwc_weight_grad_workspace(n, h, w, cin, cout, 3, 1)
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
@@ -162,15 +173,16 @@ class _ConvBNAct(Function):
         rows = conv.shape[0] * conv.shape[2] * conv.shape[3]
         stats = torch.empty(4, cout, dtype=torch.float32, device=x.device)
         tiles = ctypes.c_int()
-        L.scp_conv_nhwc_partial_rows(n, h, w, cout, k, stride, int(planes is not None), ctypes.byref(tiles), None)
+        L.scp_conv_nhwc_partial_rows(n, h, w, cin, cout, k, stride, int(planes is not None), ctypes.byref(tiles), None)
         ws = torch.empty(2 * tiles.value * cout, dtype=torch.float32, device=x.device)
         momentum = 0.1 if bn.momentum is None else bn.momentum
+        sk, sk_bytes = _splitk(n, h, w, cin, cout, k, stride, planes is not None, x.device)
         capi.check(L.scp_conv_nhwc_forward_bn(
             _ptr(x), _ptr(None if planes else weight), _ptr(planes["fwd"] if planes else None), _ptr(conv), n, h, w, cin, cout, k,
             stride, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean),
             _ptr(bn.running_var), _ptr(bn.num_batches_tracked if bn.track_running_stats else None), float(momentum), float(bn.eps),
             _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(ws), ws.numel() * 4, capi.ticket(x.device),
-            capi.current_stream()), "conv_nhwc_forward_bn")
+            _ptr(sk), sk_bytes, capi.current_stream()), "conv_nhwc_forward_bn")
         if skip is not None:
             skip = _nhwc(skip)
         y = torch.empty_like(conv)

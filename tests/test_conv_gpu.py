@@ -40,17 +40,21 @@ def _conv(x_nhwc, w_khwc, bias=None, stride=1, leaky=False, slope=0.1, partials=
     part = None
     if partials:
         tm, rows = ctypes.c_int(), ctypes.c_int()
-        L.scp_conv_nhwc_partial_rows(n, h, w, cout, k, stride, int(CORE == "split"), ctypes.byref(tm), ctypes.byref(rows))
+        L.scp_conv_nhwc_partial_rows(n, h, w, cin, cout, k, stride, int(CORE == "split"), ctypes.byref(tm), ctypes.byref(rows))
         part = torch.full((2, tm.value, cout), float("nan"), device="cuda")
+    sk_bytes = L.scp_conv_nhwc_splitk_workspace(n, h, w, cin, cout, k, stride, int(CORE == "split"))
+    sk = torch.empty(sk_bytes // 4, device="cuda") if sk_bytes else None
     capi.check(L.scp_conv_nhwc_forward(P(x_nhwc), P(None if w3 is not None else w_khwc), P(w3), P(bias), P(y), P(part), n, h, w, cin, cout,
-                                       k, stride, int(leaky), slope, capi.current_stream()), "conv_nhwc_forward")
+                                       k, stride, int(leaky), slope, P(sk), sk_bytes, capi.current_stream()), "conv_nhwc_forward")
     return (y, part, rows.value) if partials else y
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w,k,stride", [
     (2, 64, 64, 8, 8, 3, 1), (4, 32, 128, 16, 8, 3, 1), (2, 128, 200, 8, 16, 3, 1), (3, 64, 48, 16, 8, 3, 1),
     (2, 64, 128, 16, 16, 3, 2), (2, 128, 256, 8, 8, 3, 2), (2, 64, 128, 16, 16, 1, 2), (2, 64, 64, 16, 16, 1, 1),
-    (32, 128, 128, 32, 32, 3, 1), (8, 64, 64, 64, 64, 3, 1), (4, 512, 512, 8, 8, 3, 1), (1, 256, 512, 4, 4, 3, 1)])
+    (32, 128, 128, 32, 32, 3, 1), (8, 64, 64, 64, 64, 3, 1), (4, 512, 512, 8, 8, 3, 1), (1, 256, 512, 4, 4, 3, 1),
+    # the split main loop runs these split-K (2 / 4 / 8 workgroups per 128 x 128 tile + fold pass):
+    (32, 256, 256, 16, 16, 3, 1), (32, 512, 512, 8, 8, 3, 1), (32, 128, 256, 32, 32, 3, 2), (9, 512, 256, 16, 16, 3, 1)])
 def test_conv_forward_and_input_gradient_vs_float64(n, cin, cout, h, w, k, stride):
     g = torch.Generator().manual_seed(cin + cout + h + k + stride)
     x = torch.randn(n, cin, h, w, generator=g).cuda()
@@ -70,7 +74,8 @@ def test_conv_forward_and_input_gradient_vs_float64(n, cin, cout, h, w, k, strid
         assert err <= 1e-5 * dx_ref.abs().max().item(), err
 
 
-@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 16, 16), (3, 128, 128, 8, 8), (2, 64, 256, 8, 8), (32, 64, 64, 64, 64)])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 16, 16), (3, 128, 128, 8, 8), (2, 64, 256, 8, 8), (32, 64, 64, 64, 64),
+                                           (32, 256, 256, 16, 16), (31, 512, 512, 8, 8)])   # the last two: split-K + fold epilogue
 def test_conv_epilogues(n, cin, cout, h, w):
     """bias + LeakyReLU(0.1) of the decoder's conv units, and the per-tile column sums a BatchNorm folds into its statistics
     (always of the RAW convolution output)"""
@@ -120,6 +125,6 @@ def test_conv_rejects_shapes_it_does_not_cover():
     x = torch.randn(1, 4, 4, 24, device="cuda")      # Cin not a power of two >= 32
     wt = torch.randn(8, 3, 3, 24, device="cuda")
     y = torch.empty(1, 4, 4, 8, device="cuda")
-    assert L.scp_conv_nhwc_forward(P(x), P(wt), P(None), P(None), P(y), P(None), 1, 4, 4, 24, 8, 3, 1, 0, 0.0, capi.current_stream()) != 0
-    assert L.scp_conv_nhwc_forward(P(x), P(wt), P(None), P(None), P(y), P(None), 1, 4, 4, 32, 8, 7, 2, 0, 0.0, capi.current_stream()) != 0   # the 7x7 stem stays on MIOpen
+    assert L.scp_conv_nhwc_forward(P(x), P(wt), P(None), P(None), P(y), P(None), 1, 4, 4, 24, 8, 3, 1, 0, 0.0, P(None), 0, capi.current_stream()) != 0
+    assert L.scp_conv_nhwc_forward(P(x), P(wt), P(None), P(None), P(y), P(None), 1, 4, 4, 32, 8, 7, 2, 0, 0.0, P(None), 0, capi.current_stream()) != 0   # the 7x7 stem stays on MIOpen
     assert L.scp_conv_nhwc_weight_grad_workspace(2, 12, 12, 64, 64, 3, 1) == 0                                                 # not a power-of-two map
