@@ -11,8 +11,9 @@ model/module/network/image_encoder.py:119-139.  ONE autograd op:
 (net_blocks.py:336-359 with_bn=False); bias and activation live in the convolution's epilogue.
 
 What the own kernels do not cover goes to MIOpen through ATen, layer by layer and direction by direction, never silently for a
-whole network: the 7x7 stem (Cin = 3), the backward of the three stride-2 3x3 layers and of the 1x1 stride-2 projections
-(`aten.convolution_backward`).  CPU tensors, eval-mode BatchNorm, SyncBatchNorm and non-fp32 activations (configs[4] bf16
+whole network: the 7x7 stem (Cin = 3) and the backward of the three stride-2 3x3 layers (`aten.convolution_backward`); the 1x1
+stride-2 projections' backward is an own 1x1 product scattered to the even pixels (input gradient) and one gather + library GEMM
+(weight gradient).  CPU tensors, eval-mode BatchNorm, SyncBatchNorm and non-fp32 activations (configs[4] bf16
 autocast) take the stock composition, which is also what the tests compare with."""
 import ctypes
 
@@ -44,8 +45,10 @@ def own_forward_ok(x, weight, stride):
 
 
 def _own_dgrad_ok(weight, stride):
+    """stride 1, or the 1x1 stride-2 projections of the ResNet trunk (their input gradient is a 1x1 convolution of dy scattered to
+    the even pixels)"""
     cout, k = weight.shape[0], weight.shape[2]
-    return stride == 1 and cout >= 32 and _pow2(cout)
+    return (stride == 1 or (stride == 2 and k == 1)) and cout >= 32 and _pow2(cout)
 
 
 def _own_wgrad_ok(x_shape, weight, stride):
@@ -139,16 +142,30 @@ def _conv_backward(x, weight, g, stride, need_dx, need_dw, planes=None):
         # the forward kernel on dy with the weights as [Cin, k, k, Cout], taps flipped
         wt3 = planes.get("dgrad") if planes else None
         wt = None if wt3 is not None else weight.flip(2, 3).permute(1, 2, 3, 0).contiguous()
-        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-        sk, sk_bytes = _splitk(n, h, w, cout, cin, k, 1, wt3 is not None, x.device)
-        capi.check(L.scp_conv_nhwc_forward(_ptr(g), _ptr(wt), _ptr(wt3), _ptr(None), _ptr(dx), _ptr(None), n, h, w, cout, cin, k, 1, 0,
-                                           0.0, _ptr(sk), sk_bytes, capi.current_stream()), "conv_nhwc_forward (input gradient)")
+        ho, wo = g.shape[2], g.shape[3]
+        # stride 2 (1x1 only): the same product at the output resolution, then scattered to the even pixels of a zero gradient
+        dense = torch.empty((n, cin, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        sk, sk_bytes = _splitk(n, ho, wo, cout, cin, k, 1, wt3 is not None, x.device)
+        capi.check(L.scp_conv_nhwc_forward(_ptr(g), _ptr(wt), _ptr(wt3), _ptr(None), _ptr(dense), _ptr(None), n, ho, wo, cout, cin, k, 1,
+                                           0, 0.0, _ptr(sk), sk_bytes, capi.current_stream()), "conv_nhwc_forward (input gradient)")
+        if stride == 1:
+            dx = dense
+        else:
+            dx = torch.empty(x.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last).zero_()
+            dx[:, :, ::2, ::2] = dense
     if own_dw:
         ws_bytes = L.scp_conv_nhwc_weight_grad_workspace(n, h, w, cin, cout, 3, 1)
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
         dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         capi.check(L.scp_conv_nhwc_weight_grad(_ptr(x), _ptr(g), _ptr(dw), _ptr(None), _ptr(ws), ws_bytes, n, h, w, cin, cout, 3, 1,
                                                capi.current_stream()), "conv_nhwc_weight_grad")
+    if need_dw and not own_dw and k == 1 and stride == 2:
+        # weight gradient of a 1x1 stride-2 projection = dy^T (Cout x pixels) @ x at the even pixels (pixels x Cin): one gather + one
+        # library GEMM instead of MIOpen's 50-60 us kernels for 0.5 GFLOP
+        xs = x.permute(0, 2, 3, 1)[:, ::2, ::2, :].reshape(-1, cin)
+        g2 = g.permute(0, 2, 3, 1).reshape(-1, cout)
+        dw = torch.mm(g2.t(), xs).reshape(cout, cin, 1, 1)
+        own_dw = True
     miss_dx, miss_dw = need_dx and not own_dx, need_dw and not own_dw
     if miss_dx or miss_dw:
         p = weight.shape[2] // 2

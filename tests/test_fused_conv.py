@@ -42,7 +42,7 @@ def _close_grad(got, ref, tol, what):
 
 @pytest.mark.parametrize("n,cin,cout,h,k,stride,skip,relu", [
     (4, 64, 64, 16, 3, 1, False, True), (4, 64, 64, 16, 3, 1, True, True), (2, 64, 128, 16, 3, 2, False, True),
-    (2, 64, 128, 16, 1, 2, False, False), (2, 128, 128, 8, 3, 1, True, True), (2, 256, 512, 8, 3, 2, False, True),
+    (2, 64, 128, 16, 1, 2, False, False), (3, 128, 256, 16, 1, 2, False, False), (2, 128, 128, 8, 3, 1, True, True), (2, 256, 512, 8, 3, 2, False, True),
     (32, 64, 64, 64, 3, 1, True, True)])
 def test_conv_bn_act_vs_float64(n, cin, cout, h, k, stride, skip, relu):
     from scp_amd import fused_conv

@@ -8,7 +8,7 @@ import csv
 import json
 import sys
 
-FAMILIES = {"vit_gemm": "vit_gemm_kernel", "vit_attention": "vit_attention_kernel", "raster_backward": "raster_backward_kernel<1, 1>",
+FAMILIES = {"vit_gemm": "vit_gemm_kernel", "vit_attention": "vit_attention_", "vit_qkv_split": "qkv_split_kernel", "conv_splitk_fold": "conv_splitk_fold_kernel", "raster_backward": "raster_backward_kernel<1, 1>",
             "raster_forward": "raster_forward_kernel", "corr_fused": "fvm_", "conv_igemm": "conv_igemm_kernel",
             "conv_wgrad": "conv_wgrad_kernel", "wgrad_fold": "wgrad_fold_kernel"}
 
