@@ -12,6 +12,10 @@ laptop_wild6d flag set, synthetic batch (scp_amd/synthetic.py), random-init weig
 ImageNet / DINO checkpoints).  Weak scaling: every rank processes its own 32 images; `value` counts
 32-image iterations completed by all ranks per second.
 
+A step is `Trainer.step(batch, next_data=batch)`: like `Trainer.train()`, the bench hands every step the following batch, whose
+frozen-DINO pass is then enqueued on the side stream before the current step's backward (one ViT pass per step either way, DESIGN
+section 5; `config.vit_lookahead` reports the unpipelined time of the same run, `--no-lookahead` times only that).
+
 Extra JSON objects (tier contract):
   roofline      the dominant hand-written kernel family of the step = vit_gemm_kernel (csrc/vit_gemm.hip: the 37 linear
                 layers of the DINO ViT with LayerNorm / GELU / residual fused).  Default main loop: fp32 products on the bf16
@@ -422,6 +426,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lookahead", action="store_true",
+                    help="do not hand step() the following batch: the frozen-DINO features of batch i+1 are then computed at the start "
+                         "of step i+1 instead of on the side stream during step i's backward (Trainer.train() always looks ahead)")
     ap.add_argument("--no-isolated", action="store_true",
                     help="skip the isolated-kernel reference figures (profiling runs: keeps extra launches out of the trace)")
     ap.add_argument("--mixed-bf16", action="store_true",
@@ -476,21 +483,37 @@ def main():
         # initialisation, not measurement: the first iterations run MIOpen's solver search (cudnn.benchmark, once per
         # convolution shape and process) and fill the caching allocator -- the counterpart of a compile step.  Done
         # before the W warm-up steps so that a small --warmup still times steady-state iterations.
+        # The training loop (scp_amd/trainer.py: Trainer.train, one batch of look-ahead like any input pipeline) hands step() the
+        # FOLLOWING batch: its frozen-DINO features depend on nothing but the images, so that ViT pass is enqueued on the side stream
+        # before this step's backward.  Per-step work is unchanged -- every step of the timed region enqueues exactly one ViT pass
+        # (for the batch after it) besides its own forward / backward / optimizer -- but the pass no longer heads the critical path
+        # of the step that consumes it.  The synthetic "next batch" is the same resident batch.  --no-lookahead: the unpipelined step.
+        nxt = None if args.no_lookahead else data
         for _ in range(INIT_STEPS):
             tr.step(data)
         sync()
         for _ in range(args.warmup):
-            tr.step(data)
+            tr.step(data, next_data=nxt)
         sync()
         kt.enabled = at.enabled = gt.enabled = True
         kc.start()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            tr.step(data)
+            tr.step(data, next_data=nxt)
         sync()
         elapsed = time.perf_counter() - t0
         kt.enabled = at.enabled = gt.enabled = False
         kc.stop()
+        # the same K steps without the look-ahead, after the timed region (reported beside the headline, not instead of it)
+        unpipelined = None
+        if nxt is not None:
+            tr.step(data)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                tr.step(data)
+            sync()
+            unpipelined = time.perf_counter() - t1
         gemm_clock = kc.result()
         kernel_ms = kt.mean_ms()
         attn_ms = at.mean_ms()
@@ -615,6 +638,11 @@ def main():
                        "images_per_sec": world * args.steps * B / elapsed, "parallelism": "dp%d" % world,
                        "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else 0,
                        "gradient_buckets": len(tr.grads.buckets), "buckets_launched_inside_backward": tr.grads.launched_in_backward,
+                       "vit_lookahead": {"enabled": not args.no_lookahead,
+                                         "what": "step(data, next_data): the frozen-DINO ViT pass of the NEXT batch runs on the side stream "
+                                                 "during this step's backward, as in Trainer.train(); one ViT pass per timed step either way",
+                                         "unpipelined_ms_per_step": None if unpipelined is None else 1000.0 * unpipelined / args.steps,
+                                         "unpipelined_iters_per_sec": None if unpipelined is None else world * args.steps / unpipelined},
                        "matrix_cores": {"vit_linear": dino_mod.GEMM_MODE, "encoder_conv_fwd_dgrad": fused_conv_mode(),
                                         "note": "split = bf16 MFMA on exactly split fp32 operands, fp32 accumulate (fp32-accurate); "
                                                 "fp32 = v_mfma_f32_32x32x2_f32; attention, weight gradients and the 7x7 stem run "

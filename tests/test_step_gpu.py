@@ -209,6 +209,49 @@ def test_every_wild6d_category_preset_steps(category):
     assert not torch.equal(before, tr.model.mesh.mean_v)
 
 
+def test_lookahead_of_the_frozen_vit_changes_nothing_but_the_schedule():
+    """Trainer.step(data, next_data): the DINO pass of the following batch is enqueued on the side stream before this step's
+    backward (Trainer.train() and bench.py do that).  Same batches, same seeds, with and without the look-ahead: every step's
+    losses and the parameters after four steps must agree as closely as two runs WITHOUT the look-ahead agree with each other
+    (the step is not bitwise reproducible: atomics in the rasteriser's backward, and the sigma = 1e-4 depth term amplifies
+    that) -- the features are the same numbers computed earlier.  The following batch is a DIFFERENT tensor than the current one,
+    so features taken from the wrong batch would show as an O(1) change of the DINO cycle loss."""
+    import copy
+    import scp_amd.dino as dino
+    from scp_amd.flags import Options
+    from scp_amd.trainer import Trainer
+    import scenes
+    import synth
+    dino.ALLOW_RANDOM_INIT = True
+    batches = [synth.make_batch(2, 2, 256, seed=10 + i, device="cuda") for i in range(4)]
+    runs, state = {}, None
+    for look in (False, "again", True):
+        opts = Options("laptop_wild6d", batch_size=2, repeat=2, train=True, total_iters=100)
+        torch.manual_seed(0)
+        tr = Trainer(opts, prior=scenes.bottle_like(3), device="cuda")
+        if state is None:
+            state = copy.deepcopy(tr.model.state_dict())
+        tr.model.load_state_dict(state)
+        tr.model.rotation_angle = 90.0
+        torch.manual_seed(1)
+        hist = []
+        for i, data in enumerate(batches):
+            nxt = batches[i + 1] if (look is True and i + 1 < len(batches)) else None
+            total, aux, grad = tr.step(data, next_data=nxt)
+            hist.append({k: float(v.detach()) for k, v in aux.items()})
+        runs[look] = (hist, [p.detach().clone() for p in tr.model.parameters()])
+    for a, b, c in zip(*[runs[k][0] for k in (False, "again", True)]):
+        for k in a:
+            # run-to-run floor (one sample of it) + the conditioning band of the sigma = gamma = 1e-4 terms (tests/step_case.py);
+            # the DINO cycle loss -- the only consumer of the prefetched features -- is held tight
+            floor = abs(a[k] - b[k])
+            band = 1e-4 if k == "cycle_loss_pretrain" else 2e-3
+            assert abs(c[k] - a[k]) <= 4 * floor + band * abs(a[k]) + 1e-9, (k, a[k], b[k], c[k])
+    for p, q, r in zip(runs[False][1], runs["again"][1], runs[True][1]):
+        floor = (p - q).abs().max().item()
+        assert (r - p).abs().max().item() <= 4 * floor + 1e-4 * p.abs().max().item() + 1e-9
+
+
 def test_mixed_bf16_step_tracks_fp32():
     """BASELINE configs[4] precision (opts.mixed_bf16: bf16 convolutions and ViT linears, fp32 everywhere else): the
     same model / batch in both precisions.  bf16 carries 8 mantissa bits, so this is a sanity band, not parity: every
