@@ -295,7 +295,8 @@ int scp_batchnorm_act_backward_bf16(const void* dy, const void* x, const void* y
  * The input gradient of a stride-1 convolution is the same call with dy as x, Cin <-> Cout and w transposed + flipped
  * ([Cin,k,k,Cout], tap (k-1-ky, k-1-kx)).  Requires Cin a power of two >= 32, k in {1, 3}, stride in {1, 2}
  * (else hipErrorInvalidValue: the caller keeps its library convolution -- the 7x7 stem does).
- * scp_conv_nhwc_weight_grad: dw [Cout,k,k,Cin] = sum over output pixels of dy[p][co] x[p + tap][ci]; x [N,H,W,Cin],
+ * scp_conv_nhwc_weight_grad (split != 0: on the bf16 matrix cores with exactly split operands, both operands split in registers;
+ *   else fp32 matrix cores): dw [Cout,k,k,Cin] = sum over output pixels of dy[p][co] x[p + tap][ci]; x [N,H,W,Cin],
  *   dy [N,Ho,Wo,Cout]; workspace >= scp_conv_nhwc_weight_grad_workspace(...) bytes (partial sums of the pixel split, folded in a
  *   fixed order: deterministic); dbias (or NULL): [Cout] = sum over pixels of dy. */
 int scp_conv_nhwc_forward(const float* x, const float* w, const void* w_split, const float* bias, float* y, float* partials, int N,
@@ -326,7 +327,7 @@ int scp_batchnorm_apply(const float* x, const float* skip, const float* scale, c
                         void* stream);
 size_t scp_conv_nhwc_weight_grad_workspace(int N, int H, int W, int Cin, int Cout, int ksize, int stride);
 int scp_conv_nhwc_weight_grad(const float* x, const float* dy, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
-                              int N, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
+                              int N, int H, int W, int Cin, int Cout, int ksize, int stride, int split, void* stream);
 
 /* ---- stem max pooling ------------------------------------------------------------------------------------------
  * nn.MaxPool2d(3, 2, 1) of torchvision's resnet18 stem (image_encoder.py:119-139), NHWC, even H and W, C % 4 == 0:

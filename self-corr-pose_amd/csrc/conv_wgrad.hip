@@ -21,6 +21,8 @@
 // Roofline: bound = fp32 MFMA; algorithmic flops 2 M Cout 9 Cin; algorithmic bytes 4 (M Cin + M Cout + 9 Cin Cout).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "gemm_core.h"
 #include "scp_common.h"
 #include "scp_hip.h"
@@ -186,7 +188,116 @@ struct WgradCore {
     }
 };
 
+// ---- the same contraction on the bf16 matrix cores with exactly split operands (csrc/gemm_core_split.h) ---------------------------
+// Both operands are activations and the contraction index is the pixel, so a lane's MFMA operand (8 consecutive k = 8 pixels of
+// ONE channel) is 8 separate LDS words; they are split in registers.  Per chunk of 16 pixels (= one k-step of
+// v_mfma_f32_32x32x16_bf16) and wavefront: 8 words of dy and 3 x 10 words of the halo block (a halo row serves its three kx taps:
+// the tap's 8 pixels are words kx .. kx + 7 of the row's 10) are read with ds_read_b32, split by TRUNCATION
+//   h = x & 0xffff0000, r = x - h, m = r & 0xffff0000, l = r - m          (x = h + m + l exactly; 4 VALU per value)
+// and packed pairwise with v_perm_b32; 9 taps x 6 partial products = 54 MFMAs of 32 cycles against 72 of 64 cycles on the fp32
+// cores.  DMA, ring and halo layout are WgradCore's; MFMAs, splits and reads are left to the compiler's scheduler.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 template <int CW>
+struct WgradSplitCore : WgradCore<CW> {
+    using Base = WgradCore<CW>;
+    using Acc = typename Base::Acc;
+    const float* ldsf;
+    int a_lane, b_lane;            // float offsets inside a stage of this lane's first dy word / first halo word
+
+    __device__ __forceinline__ WgradSplitCore(const WgradArgs& args, float* lds, int cob, int cib, int first_chunk)
+        : Base(args, lds, cob, cib, first_chunk), ldsf(lds) {
+        const int half = this->lane >> 5, l31 = this->lane & 31;
+        const int wm = this->wave >> 1, wn = this->wave & 1;
+        a_lane = 8 * half * BC + wm * 32 + l31;                                   // pixel 8 half + i -> dy row
+        // pixel p = 8 half + i sits at halo (row p / CW, column p % CW); the tap adds (ky, kx)
+        const int pr = CW == 16 ? 0 : half, pc0 = CW == 16 ? 8 * half : 0;
+        b_lane = DY_BYTES / 4 + (pr * Base::HC + pc0) * BC + wn * 32 + l31;
+    }
+
+    struct Split { float h, m, l; };
+    static __device__ __forceinline__ Split split(float x) {
+        Split s;
+        s.h = __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+        const float r = x - s.h;
+        s.m = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
+        s.l = r - s.m;
+        return s;
+    }
+    // bf16 pair (element 0 = lo, element 1 = hi) from two floats whose low 16 bits are zero (or ignored)
+    static __device__ __forceinline__ unsigned pack(float lo, float hi) {
+        return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+    }
+
+    template <int S>
+    __device__ __forceinline__ void compute(Acc& acc) const {
+        const float* st = ldsf + S * (STAGE_BYTES / 4);
+        u32x4 ah, am, al;
+        {
+            Split a[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) a[i] = split(st[a_lane + i * BC]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                ah[j] = pack(a[2 * j].h, a[2 * j + 1].h);
+                am[j] = pack(a[2 * j].m, a[2 * j + 1].m);
+                al[j] = pack(a[2 * j].l, a[2 * j + 1].l);
+            }
+        }
+        const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Am = __builtin_bit_cast(bf16x8, am), Al = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+            Split x[10];
+#pragma unroll
+            for (int j = 0; j < 10; j++) x[j] = split(st[b_lane + (ky * Base::HC + j) * BC]);
+            bf16x8 Bh[3], Bm[3], Bl[3];
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                u32x4 h, m, l;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    h[j] = pack(x[kx + 2 * j].h, x[kx + 2 * j + 1].h);
+                    m[j] = pack(x[kx + 2 * j].m, x[kx + 2 * j + 1].m);
+                    l[j] = pack(x[kx + 2 * j].l, x[kx + 2 * j + 1].l);
+                }
+                Bh[kx] = __builtin_bit_cast(bf16x8, h); Bm[kx] = __builtin_bit_cast(bf16x8, m); Bl[kx] = __builtin_bit_cast(bf16x8, l);
+            }
+            // smallest terms first; the three taps of the row alternate so that consecutive MFMAs are independent
+            auto mac = [&](const bf16x8& av, const bf16x8 (&bv)[3]) {
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++)
+                    acc.t[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[kx], acc.t[ky * 3 + kx], 0, 0, 0);
+            };
+            mac(Am, Bm);
+            mac(Al, Bh);
+            mac(Ah, Bl);
+            mac(Am, Bh);
+            mac(Ah, Bm);
+            mac(Ah, Bh);
+        }
+    }
+
+    // nk chunks (even, >= 2)
+    __device__ __forceinline__ void run(Acc& acc, int nk) {
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc.t[t][r] = 0.f;
+        this->issue(0, 0);
+        for (int c = 0; c < nk; c += 2) {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            this->issue(c + 1, 1);
+            compute<0>(acc);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (c + 2 < nk) this->issue(c + 2, 0);
+            compute<1>(acc);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+};
+
+template <int CW, bool SPLIT>
 __global__ __launch_bounds__(THREADS, 2) void conv_wgrad_kernel(const WgradArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE_BYTES / 4];
     // workgroup b runs on XCD b % 8 and takes a contiguous share of the (split, co block, ci block) list, split slowest: the
@@ -200,7 +311,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_wgrad_kernel(const WgradArgs 
     const int cob = blk / g.ncib, cib = blk - cob * g.ncib;
     const int first = split * g.chunks_per_split;
     const int nk = min(g.chunks_per_split, g.total_chunks - first);
-    using Core = WgradCore<CW>;
+    using Core = std::conditional_t<SPLIT, WgradSplitCore<CW>, WgradCore<CW>>;
     Core core(g, lds, cob, cib, first);
     typename Core::Acc acc;
     core.run(acc, nk);
@@ -282,7 +393,7 @@ extern "C" size_t scp_conv_nhwc_weight_grad_workspace(int N, int H, int W, int C
 
 extern "C" int scp_conv_nhwc_weight_grad(const float* x, const float* dy, float* dw, float* dbias, void* workspace,
                                          size_t workspace_bytes, int N, int H, int W, int Cin, int Cout, int ksize, int stride,
-                                         void* stream) {
+                                         int split, void* stream) {
     if (!x || !dy || !dw || !workspace) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: null argument");
     if (ksize != 3 || stride != 1) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: 3x3 / stride 1 only");
     if (dbias) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: the bias gradient comes from scp_bias_leaky_relu_backward");
@@ -300,8 +411,13 @@ extern "C" int scp_conv_nhwc_weight_grad(const float* x, const float* dy, float*
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int total = p.splits * p.ncob * p.ncib;
     const dim3 grid(((total + 7) >> 3) << 3);
-    if (W >= 16) hipLaunchKernelGGL(conv_wgrad_kernel<16>, grid, dim3(THREADS), 0, st, g);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<8>, grid, dim3(THREADS), 0, st, g);
+    if (split) {
+        if (W >= 16) hipLaunchKernelGGL((conv_wgrad_kernel<16, true>), grid, dim3(THREADS), 0, st, g);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<8, true>), grid, dim3(THREADS), 0, st, g);
+    } else {
+        if (W >= 16) hipLaunchKernelGGL((conv_wgrad_kernel<16, false>), grid, dim3(THREADS), 0, st, g);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<8, false>), grid, dim3(THREADS), 0, st, g);
+    }
     const int n4 = Cout * 9 * Cin / 4;
     hipLaunchKernelGGL(wgrad_fold_kernel, dim3((n4 + 15) / 16), dim3(256), 0, st, static_cast<const float*>(workspace), dw, n4, p.splits);
     return scp::check_launch("conv_weight_grad");

@@ -92,7 +92,7 @@ SYMBOLS = {
                                               _P, _P, _P]),
     "scp_conv_nhwc_partial_rows": (ctypes.c_int, [_I, _I, _I, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "scp_conv_nhwc_weight_grad_workspace": (ctypes.c_size_t, [_I, _I, _I, _I, _I, _I, _I]),
-    "scp_conv_nhwc_weight_grad": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "scp_conv_nhwc_weight_grad": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "scp_posefit_workspace": (ctypes.c_size_t, [_I, _I, _I]),
     "scp_ransac_hypotheses": (ctypes.c_int, [_P, _P, _I, _I, _P, _I, _P, _P]),
     "scp_ransac_score": (ctypes.c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P, ctypes.c_size_t, _P]),

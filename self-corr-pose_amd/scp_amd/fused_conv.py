@@ -68,6 +68,8 @@ def _conv_out_shape(x, weight, stride):
 # part's power limit).  "fp32": v_mfma_f32_32x32x2_f32.  SCP_CONV_GEMM=fp32 in the environment selects the latter.
 import os
 CONV_MODE = os.environ.get("SCP_CONV_GEMM", "split")
+# the weight gradient's own switch (csrc/conv_wgrad.hip: both operands are activations, split in registers): "split" | "fp32"
+WGRAD_MODE = os.environ.get("SCP_CONV_WGRAD", CONV_MODE)
 
 
 def split_planes(t):
@@ -158,7 +160,7 @@ def _conv_backward(x, weight, g, stride, need_dx, need_dw, planes=None):
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
         dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         capi.check(L.scp_conv_nhwc_weight_grad(_ptr(x), _ptr(g), _ptr(dw), _ptr(None), _ptr(ws), ws_bytes, n, h, w, cin, cout, 3, 1,
-                                               capi.current_stream()), "conv_nhwc_weight_grad")
+                                               int(WGRAD_MODE == "split"), capi.current_stream()), "conv_nhwc_weight_grad")
     if need_dw and not own_dw and k == 1 and stride == 2:
         # weight gradient of a 1x1 stride-2 projection = dy^T (Cout x pixels) @ x at the even pixels (pixels x Cin): one gather + one
         # library GEMM instead of MIOpen's 50-60 us kernels for 0.5 GFLOP

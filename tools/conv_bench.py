@@ -17,7 +17,8 @@ torch.backends.cudnn.benchmark = True
 L = capi.lib()
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-SPLIT = os.environ.get("SCP_CONV_GEMM", "split") == "split"     # own kernels: bf16 cores on split operands, or fp32 cores
+SPLIT = os.environ.get("SCP_CONV_GEMM", "split") == "split"
+WSPLIT = os.environ.get("SCP_CONV_WGRAD", "split" if SPLIT else "fp32") == "split"     # own kernels: bf16 cores on split operands, or fp32 cores
 # (name, Cin, Cout, k, stride, H_in, count per encoder pass)
 LAYERS = [("stem 7x7/2", 3, 64, 7, 2, 256, 1), ("layer1 3x3", 64, 64, 3, 1, 64, 4), ("layer2.0 3x3/2", 64, 128, 3, 2, 64, 1),
           ("layer2 3x3", 128, 128, 3, 1, 32, 3), ("layer2 down 1x1/2", 64, 128, 1, 2, 64, 1), ("layer3.0 3x3/2", 128, 256, 3, 2, 32, 1),
@@ -76,7 +77,7 @@ for name, cin, cout, k, s, h, cnt in LAYERS:
                     ws = torch.empty(ws_bytes // 4, device="cuda")
                     dw = torch.empty(cout, 3, 3, cin, device="cuda")
                     ow = t(lambda: capi.check(L.scp_conv_nhwc_weight_grad(P(xn), P(gn), P(dw), P(None), P(ws), ws_bytes, B, h, h, cin, cout,
-                                                                          3, 1, capi.current_stream()), "wgrad"))
+                                                                          3, 1, int(WSPLIT), capi.current_stream()), "wgrad"))
     for key, v in (("mf", mf), ("md", md), ("mw", mw), ("of", of), ("od", od), ("ow", ow)):
         # a layer the own kernels do not cover counts with MIOpen's time on both sides (that is what the encoder runs)
         alt = {"of": mf, "od": md, "ow": mw}.get(key)

@@ -1,7 +1,8 @@
 """tools/phase_timeline.py -- GPU timeline of the step's phases WITHOUT a profiler: HIP events recorded on the streams the phases
 run on (forward: around the wrapped calls; backward: from gradient hooks on the phases' inputs / outputs), read back after the run.
 rocprofv3's per-launch interception makes this workload host-bound (50 ms steps), so its timeline is not the free-running one; a few
-dozen events per step do not disturb anything.  Prints, per mark, the median time since the step's first event over the measured steps."""
+dozen events per step do not disturb anything.  Prints, per mark, the median time since the step's first event over the measured steps.  --lookahead: with the training loop's
+one batch of look-ahead for the frozen ViT (bench.py's default)."""
 import os
 import sys
 import time
@@ -19,6 +20,7 @@ model = tr.model
 data = synth.make_batch(opts.batch_size, opts.repeat, opts.img_size, seed=100, device="cuda:0")
 
 MARKS = None   # list of (label, event) for the current step
+LOOKAHEAD = "--lookahead" in sys.argv
 
 
 def mark(label):
@@ -75,6 +77,8 @@ for _ in range(12):
     tr.grads.prepare()
     total, aux = tr.model(data)
     mark("forward-enqueued")
+    if LOOKAHEAD:      # Trainer.step(data, next_data=data): the next batch's DINO pass goes to the side stream before the backward
+        tr.model.pretrain_corr_net.prefetch_features(data[0], data[1])
     total.mean().backward()
     mark("backward<")
     tr.collect_grad()
