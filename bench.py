@@ -211,6 +211,11 @@ def fused_conv_mode():
     return fused_conv.CONV_MODE
 
 
+def fused_wgrad_mode():
+    from scp_amd import fused_conv
+    return fused_conv.WGRAD_MODE
+
+
 BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix-core peak
 
 
@@ -643,10 +648,12 @@ def main():
                                                  "during this step's backward, as in Trainer.train(); one ViT pass per timed step either way",
                                          "unpipelined_ms_per_step": None if unpipelined is None else 1000.0 * unpipelined / args.steps,
                                          "unpipelined_iters_per_sec": None if unpipelined is None else world * args.steps / unpipelined},
-                       "matrix_cores": {"vit_linear": dino_mod.GEMM_MODE, "encoder_conv_fwd_dgrad": fused_conv_mode(),
-                                        "note": "split = bf16 MFMA on exactly split fp32 operands, fp32 accumulate (fp32-accurate); "
-                                                "fp32 = v_mfma_f32_32x32x2_f32; attention, weight gradients and the 7x7 stem run "
-                                                "on the fp32 cores"}},
+                       "matrix_cores": {"vit_linear": dino_mod.GEMM_MODE, "vit_attention": dino_mod.ATTN_MODE,
+                                        "encoder_conv_fwd_dgrad": fused_conv_mode(), "encoder_conv_wgrad": fused_wgrad_mode(),
+                                        "note": "split = bf16 MFMA on exactly split fp32 operands, fp32 accumulate (fp32-accurate, "
+                                                "DESIGN 4.4c); fp32 = v_mfma_f32_32x32x2_f32 (SCP_VIT_GEMM / SCP_VIT_ATTN / "
+                                                "SCP_CONV_GEMM / SCP_CONV_WGRAD = fp32); the 7x7 stem and the stride-2 3x3 backward "
+                                                "are MIOpen fp32"}},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -63,9 +63,10 @@ def _conv_out_shape(x, weight, stride):
     return n, weight.shape[0], (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
 
 
-# "split": the convolutions' products run on the bf16 matrix cores with exactly split operands (csrc/gemm_core_split.h: every
-# fp32 value = three bf16 terms, six partial products, fp32 accumulation -- fp32-accurate, ~1.4x the fp32 cores' rate at the
-# part's power limit).  "fp32": v_mfma_f32_32x32x2_f32.  SCP_CONV_GEMM=fp32 in the environment selects the latter.
+# "split": the convolutions' products (forward, input gradient, weight gradient) run on the bf16 matrix cores with exactly split
+# operands (csrc/gemm_core_split.h: every fp32 value = three bf16 terms, six partial products, fp32 accumulation -- fp32-accurate,
+# ~1.4x the fp32 cores' rate at the part's power limit).  "fp32": v_mfma_f32_32x32x2_f32.  SCP_CONV_GEMM=fp32 in the environment
+# selects the latter.
 import os
 CONV_MODE = os.environ.get("SCP_CONV_GEMM", "split")
 # the weight gradient's own switch (csrc/conv_wgrad.hip: both operands are activations, split in registers): "split" | "fp32"

@@ -211,11 +211,10 @@ def test_every_wild6d_category_preset_steps(category):
 
 def test_lookahead_of_the_frozen_vit_changes_nothing_but_the_schedule():
     """Trainer.step(data, next_data): the DINO pass of the following batch is enqueued on the side stream before this step's
-    backward (Trainer.train() and bench.py do that).  Same batches, same seeds, with and without the look-ahead: every step's
-    losses and the parameters after four steps must agree as closely as two runs WITHOUT the look-ahead agree with each other
-    (the step is not bitwise reproducible: atomics in the rasteriser's backward, and the sigma = 1e-4 depth term amplifies
-    that) -- the features are the same numbers computed earlier.  The following batch is a DIFFERENT tensor than the current one,
-    so features taken from the wrong batch would show as an O(1) change of the DINO cycle loss."""
+    backward (Trainer.train() and bench.py do that).  (1) What the look-ahead leaves for the next step -- features and pair
+    matching of the NEXT batch, a different tensor than the current one -- is bit-identical to computing them when the step starts;
+    (2) four steps on four different batches with and without it end in the same losses and parameters, up to the run-to-run
+    spread of the step itself (atomics in the rasteriser's backward, amplified by the sigma = 1e-4 depth term and by training)."""
     import copy
     import scp_amd.dino as dino
     from scp_amd.flags import Options
@@ -239,17 +238,26 @@ def test_lookahead_of_the_frozen_vit_changes_nothing_but_the_schedule():
             nxt = batches[i + 1] if (look is True and i + 1 < len(batches)) else None
             total, aux, grad = tr.step(data, next_data=nxt)
             hist.append({k: float(v.detach()) for k, v in aux.items()})
+            if nxt is not None and i == 1:
+                # (1) the prefetched state for batch i + 1 against a synchronous evaluation of the same thing
+                pc = tr.model.pretrain_corr_net
+                img, feats, matched = pc._prefetched
+                assert img is nxt[0]
+                torch.cuda.synchronize()
+                with torch.no_grad():
+                    direct = pc.net(nxt[0], pc._keep_tokens(nxt[1]))
+                    direct_matched = pc._match_pairs(direct, nxt[1])
+                assert torch.equal(feats, direct)
+                for u, v in zip(matched, direct_matched):
+                    assert torch.equal(u, v)
         runs[look] = (hist, [p.detach().clone() for p in tr.model.parameters()])
     for a, b, c in zip(*[runs[k][0] for k in (False, "again", True)]):
         for k in a:
-            # run-to-run floor (one sample of it) + the conditioning band of the sigma = gamma = 1e-4 terms (tests/step_case.py);
-            # the DINO cycle loss -- the only consumer of the prefetched features -- is held tight
             floor = abs(a[k] - b[k])
-            band = 1e-4 if k == "cycle_loss_pretrain" else 2e-3
-            assert abs(c[k] - a[k]) <= 4 * floor + band * abs(a[k]) + 1e-9, (k, a[k], b[k], c[k])
+            assert abs(c[k] - a[k]) <= 6 * floor + 5e-3 * abs(a[k]) + 1e-9, (k, a[k], b[k], c[k])
     for p, q, r in zip(runs[False][1], runs["again"][1], runs[True][1]):
         floor = (p - q).abs().max().item()
-        assert (r - p).abs().max().item() <= 4 * floor + 1e-4 * p.abs().max().item() + 1e-9
+        assert (r - p).abs().max().item() <= 6 * floor + 1e-3 * p.abs().max().item() + 1e-9
 
 
 def test_mixed_bf16_step_tracks_fp32():
