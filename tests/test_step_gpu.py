@@ -136,8 +136,10 @@ def test_full_step_b8_laptop_vs_oracle_backend(monkeypatch):
         rel = abs(got_aux[k] - ref) / max(abs(ref), 1e-6)
         print("%-22s cpu-oracle %.9g gpu %.9g rel %.2e" % (k, ref, got_aux[k], rel))
         assert rel <= band.get(k, 1e-4), "%s: %.9g vs %.9g (rel %.2e)" % (k, got_aux[k], ref, rel)
-    np.testing.assert_allclose(got_pose[0], ref_pose[0], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(got_pose[1], ref_pose[1], rtol=1e-4, atol=1e-5)
+    # poses: 1e-4 relative to the quantity's scale -- a rotation matrix has unit rows (entries near zero cannot be compared
+    # relatively; observed: <= 2.3e-5 absolute in the full-suite process, ~1e-5 alone), translations are O(1)
+    np.testing.assert_allclose(got_pose[0], ref_pose[0], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(got_pose[1], ref_pose[1], rtol=1e-4, atol=5e-5)
     for k in probes:
         g, r = got_grad[k], ref_grad[k]
         rel = np.linalg.norm(g - r) / np.linalg.norm(r)
