@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "self-corr-pose_amd"))
-from scp_amd import capi  # noqa: E402
+from scp_amd import capi, dino  # noqa: E402
 
 L = capi.lib()
 if os.environ.get("GEMM_LIB"):          # an ablation build of csrc/vit_gemm.hip (tools/probes), timing only
@@ -32,8 +32,17 @@ def timeit(fn, iters=30):
     return e0.elapsed_time(e1) / iters
 
 
+SPLIT = os.environ.get("SCP_VIT_GEMM", "split") == "split"      # main loop: bf16 cores on exactly split operands, or fp32 cores
+_PLANES = {}
+
+
 def run(A, W, v0, v1, st, resid, C, epi):
-    capi.check(L.scp_vit_linear(P(A), P(W), P(v0), P(v1), P(st), P(resid), P(C), A.shape[0], W.shape[0], A.shape[1], epi,
+    wp = W
+    if SPLIT:
+        if id(W) not in _PLANES:
+            _PLANES[id(W)] = (W, dino.split_weight(W))
+        wp, epi = _PLANES[id(W)][1], epi | dino.GEMM_W_SPLIT3
+    capi.check(L.scp_vit_linear(P(A), P(wp), P(v0), P(v1), P(st), P(resid), P(C), A.shape[0], W.shape[0], A.shape[1], epi,
                                 capi.current_stream()), "vit_linear")
 
 
