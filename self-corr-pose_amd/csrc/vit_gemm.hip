@@ -99,12 +99,12 @@ __host__ __device__ inline Plan make_plan(int M, int nblk_n, int slots) {
     p.panels = quarters / 4;
     const int total_big = p.panels * nblk_n;
     const int rem = total_big % slots;
-    // whole rounds as big tiles; a last round that is more than 3/4 full stays big as well (cutting it would not shorten it)
-    p.nbig = total_big - (4 * rem > 3 * slots ? 0 : rem);
-    // less than one round (proj / fc2: 387 tiles on 512 slots): two slots share a CU's matrix pipes, so 131 CUs with two big
-    // tiles finish twice as late as 125 with one.  One big tile per CU (half a round), the rest as quarters: every CU ends up
-    // with ~1.5 tiles of work whichever way the dispatcher deals them
-    if (total_big < slots && 2 * total_big > slots) p.nbig = slots / 2;
+    // Whole rounds as big tiles.  The last, partial round: two slots share a CU's matrix pipes, so a CU that gets two big tiles
+    // of it finishes twice as late as one that gets one (proj / fc2 are LESS than one round, 387 tiles on 512 slots: 131 CUs
+    // with two tiles, 125 with one -- 97 / 108 TFLOP/s; with the rule below 126 / 152).  So at most one big tile per CU (half a
+    // round) of the partial round stays big, the rest is cut into quarters, which the dispatcher's greedy list scheduling spreads
+    // evenly.
+    p.nbig = total_big - rem + (2 * rem > slots ? slots / 2 : 0);
     p.nq = 4 * (total_big - p.nbig) + (quarters % 4) * nblk_n;
     p.big_pad = (p.nbig + 7) & ~7;
     p.q_pad = (p.nq + 7) & ~7;
