@@ -140,7 +140,7 @@ template <int WAVES, bool EXACT>
 __global__ __launch_bounds__(WAVES * 64, 2) void vit_attention_split_kernel(const __bf16* __restrict__ Qp, const __bf16* __restrict__ Kp,
                                                                          const __bf16* __restrict__ Vt, float* __restrict__ out, int N,
                                                                          int Npad, int H, const int* __restrict__ q_rows,
-                                                                         const int* __restrict__ q_count) {
+                                                                         const int* __restrict__ q_count, int n_main) {
     // per buffer: K planes 3 x [32 keys][64 d] bf16 (128 B rows), V^T planes 3 x [64 d][32 keys] bf16 (64 B rows)
     __shared__ __attribute__((aligned(16))) char k_lds[2][3 * 4096];
     __shared__ __attribute__((aligned(16))) char v_lds[2][3 * 4096];
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attention_split_kernel(cons
     }
     const int b = bh / H, h = bh - b * H;
     const int q0 = (qg * WAVES + wave) * 32;
-    const int n_query = q_count ? min(q_count[b], N) : N;
+    const int n_query = q_count ? min(q_count[b], N) : n_main;    // n_main < N: the last few queries run in the tail kernel
     if (qg * WAVES * 32 >= n_query) return;          // workgroup-uniform
     const size_t plane = (size_t)gridDim.y * Npad * HD;      // elements per plane (gridDim.y = B H also in the remapped order)
     const __bf16* kbase = Kp + (size_t)bh * Npad * HD;
@@ -378,11 +378,100 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attention_split_kernel(cons
     }
 }
 
+
+// ---- 3. the few queries beyond the last full tile of 32 ---------------------------------------------------------------------------
+// N = 1025 = 32 x 32 + 1: a 33rd query tile holds ONE query (the class token) per (image, head), and a workgroup that streams all
+// keys and values for it costs as much as one that serves 128 queries -- a ninth of the launch.  Those r = N % 32 <= 8 queries
+// run here instead, in plain fp32 FMA arithmetic on the qkv tensor itself (25 MFLOP in all), flash-decoding style so that the
+// launch fills the machine: TAIL_CHUNKS workgroups per (query, image, head) each take a range of <= 256 keys -- thread = key for
+// the scores and the chunk's softmax statistics, thread = (4 dims, 1 of 16 key parts) for sum_j p_j v_j -- and leave
+// (max, sum, partial output[64]); a second tiny kernel merges the chunks.
+constexpr int TAIL_CHUNKS = 8, TAIL_REC = 2 + HD;
+
+__global__ __launch_bounds__(256) void attention_tail_partial_kernel(const float* __restrict__ qkv, float* __restrict__ partial, int N, int H,
+                                                                     float scale_log2e, int first_query, int chunk_keys) {
+    __shared__ __attribute__((aligned(16))) float p_lds[256];
+    __shared__ __attribute__((aligned(16))) float o_lds[16 * HD];
+    __shared__ float red[8];
+    const int c = blockIdx.x, qi = blockIdx.y, bh = blockIdx.z, b = bh / H, h = bh - b * H;
+    const int q = first_query + qi;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t row_stride = (size_t)3 * H * HD;
+    const float* base = qkv + (size_t)b * N * row_stride + (size_t)h * HD;
+    const int k0 = c * chunk_keys, nk = max(0, min(chunk_keys, N - k0));
+    float s = -INFINITY;
+    if (tid < nk) {
+        const float4* qp = reinterpret_cast<const float4*>(base + (size_t)q * row_stride);
+        const float4* kp = reinterpret_cast<const float4*>(base + (size_t)(k0 + tid) * row_stride + (size_t)H * HD);
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < HD / 4; i++) {
+            const float4 u = qp[i], t = kp[i];
+            a = fmaf(u.x * scale_log2e, t.x, a); a = fmaf(u.y * scale_log2e, t.y, a);
+            a = fmaf(u.z * scale_log2e, t.z, a); a = fmaf(u.w * scale_log2e, t.w, a);
+        }
+        s = a;
+    }
+    float m = s;
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) m = fmaxf(m, __shfl_xor(m, k));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float e = tid < nk ? __builtin_amdgcn_exp2f(s - m) : 0.f;
+    p_lds[tid] = e;
+    float l = e;
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) l += __shfl_xor(l, k);
+    if (lane == 0) red[4 + wave] = l;
+    __syncthreads();
+    l = (red[4] + red[5]) + (red[6] + red[7]);
+    const int d4 = tid & 15, part = tid >> 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* vbase = base + (size_t)2 * H * HD + 4 * d4;
+    for (int j = part; j < nk; j += 16) {
+        const float pj = p_lds[j];
+        const float4 v = *reinterpret_cast<const float4*>(vbase + (size_t)(k0 + j) * row_stride);
+        acc.x = fmaf(pj, v.x, acc.x); acc.y = fmaf(pj, v.y, acc.y); acc.z = fmaf(pj, v.z, acc.z); acc.w = fmaf(pj, v.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(o_lds + part * HD + 4 * d4) = acc;
+    __syncthreads();
+    float* rec = partial + (((size_t)bh * gridDim.y + qi) * TAIL_CHUNKS + c) * TAIL_REC;
+    if (tid < HD) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) t += o_lds[k * HD + tid];
+        rec[2 + tid] = t;
+    }
+    if (tid == 0) {
+        rec[0] = nk > 0 ? m : -INFINITY;
+        rec[1] = nk > 0 ? l : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(HD) void attention_tail_merge_kernel(const float* __restrict__ partial, float* __restrict__ out, int N, int H,
+                                                                  int first_query) {
+    const int qi = blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh - b * H, d = threadIdx.x;
+    const float* rec = partial + ((size_t)bh * gridDim.x + qi) * TAIL_CHUNKS * TAIL_REC;
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < TAIL_CHUNKS; c++) m = fmaxf(m, rec[c * TAIL_REC]);
+    float l = 0.f, o = 0.f;
+#pragma unroll
+    for (int c = 0; c < TAIL_CHUNKS; c++) {
+        const float w = __builtin_amdgcn_exp2f(rec[c * TAIL_REC] - m);      // exp2(-inf) = 0 for an empty chunk
+        l = fmaf(rec[c * TAIL_REC + 1], w, l);
+        o = fmaf(rec[c * TAIL_REC + 2 + d], w, o);
+    }
+    out[((size_t)b * N + first_query + qi) * (H * HD) + (size_t)h * HD + d] = o / l;
+}
+
 }  // namespace
 
 extern "C" size_t scp_vit_attention_split_workspace(int B, int N, int H) {
     const size_t npad = (size_t)((N + KT - 1) / KT) * KT;
-    return (size_t)9 * B * H * npad * HD * sizeof(__bf16);
+    // operand planes + the tail queries' chunk records (<= 8 queries x TAIL_CHUNKS per (image, head))
+    return (size_t)9 * B * H * npad * HD * sizeof(__bf16) + (size_t)B * H * 8 * TAIL_CHUNKS * TAIL_REC * sizeof(float);
 }
 
 extern "C" int scp_vit_attention_split_forward(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale,
@@ -405,9 +494,23 @@ extern "C" int scp_vit_attention_split_forward(const float* qkv, float* out, int
     hipLaunchKernelGGL(qkv_split_kernel, dim3(npad / KT, B * H), dim3(256), 0, st, qkv, Qp, Kp, Vt, N, npad, H, sl);
     // four wavefronts per workgroup, two workgroups per CU = two wavefronts per SIMD (three per workgroup fit 1025 tokens without
     // an idle wavefront, but leave every other SIMD with a single wavefront and nothing to cover its stalls: 400 vs 368 us)
-    const int qtiles = (N + 31) / 32;
+    int qtiles = (N + 31) / 32;
+    const int tail = N % 32;
+    // the queries beyond the last full tile, when they are few, go to attention_tail_queries_kernel (see there): for N = 1025 the
+    // main launch is then exactly 3.0 rounds of 512 workgroups instead of 3.375
+    const int chunk_keys = (N + TAIL_CHUNKS - 1) / TAIL_CHUNKS;
+    const bool split_tail = !q_rows && exact && tail >= 1 && tail <= 8 && N >= 64 && chunk_keys <= 256;
+    if (split_tail) qtiles -= 1;
     const dim3 grid((qtiles + 3) / 4, B * H);
-    if (exact) hipLaunchKernelGGL((vit_attention_split_kernel<4, true>), grid, dim3(256), 0, st, Qp, Kp, Vt, out, N, npad, H, q_rows, q_count);
-    else hipLaunchKernelGGL((vit_attention_split_kernel<4, false>), grid, dim3(256), 0, st, Qp, Kp, Vt, out, N, npad, H, q_rows, q_count);
+    // n_query of the main kernel: with the tail split off only the full tiles' queries
+    const int n_main = split_tail ? N - tail : N;
+    if (exact) hipLaunchKernelGGL((vit_attention_split_kernel<4, true>), grid, dim3(256), 0, st, Qp, Kp, Vt, out, N, npad, H, q_rows, q_count, n_main);
+    else hipLaunchKernelGGL((vit_attention_split_kernel<4, false>), grid, dim3(256), 0, st, Qp, Kp, Vt, out, N, npad, H, q_rows, q_count, n_main);
+    if (split_tail) {
+        float* partial = reinterpret_cast<float*>(Vt + plane3);
+        hipLaunchKernelGGL(attention_tail_partial_kernel, dim3(TAIL_CHUNKS, tail, B * H), dim3(256), 0, st, qkv, partial, N, H, sl, N - tail,
+                           chunk_keys);
+        hipLaunchKernelGGL(attention_tail_merge_kernel, dim3(tail, B * H), dim3(HD), 0, st, partial, out, N, H, N - tail);
+    }
     return scp::check_launch("vit_attention_split");
 }

@@ -142,6 +142,8 @@ int main(int argc, char** argv) {
         run<S2, scp::SplitGemmCore<S2>, __bf16>("split bf16x6 128x128", A, W3, C, ref, M, s.N, s.K, h0);
         using S3 = scp::SplitCfg<2, 4, 2, 2, 2>;
         run<S3, scp::SplitGemmCore<S3>, __bf16>("split bf16x6 128x256", A, W3, C, ref, M, s.N, s.K, h0);
+        using S4 = scp::SplitCfg<2, 2, 4, 2, 2>;
+        run<S4, scp::SplitGemmCore<S4>, __bf16>("split bf16x6 256x128 8 wavefronts", A, W3, C, ref, M, s.N, s.K, h0);
     }
     return 0;
 }
