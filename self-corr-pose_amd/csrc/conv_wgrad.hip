@@ -370,6 +370,8 @@ Plan make_plan(int N, int H, int W, int Cin, int Cout) {
     const int blocks = p.ncob * p.ncib;
     // ~256 workgroups (one per CU), every split an even number of chunks >= 4.  512 (two per CU) was measured 3-5 % slower on
     // the 9.7-GFLOP layers and doubles the partial-sum traffic (2.7 GB written + read per step)
+    // (the split main loop: 512 workgroups are 8 % faster in isolation, 2.07 vs 2.25 ms per encoder pass, and 0.4 ms SLOWER inside
+    // the step)
     int splits = (256 + blocks - 1) / blocks;
     int cps = (p.total_chunks + splits - 1) / splits;
     cps = (cps + 1) & ~1;
