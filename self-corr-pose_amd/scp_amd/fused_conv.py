@@ -19,7 +19,6 @@ import ctypes
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 from torch.autograd import Function
 
 from . import capi

@@ -5,7 +5,6 @@ dozen events per step do not disturb anything.  Prints, per mark, the median tim
 one batch of look-ahead for the frozen ViT (bench.py's default)."""
 import os
 import sys
-import time
 
 import torch
 
