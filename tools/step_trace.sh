@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/trace_$tag
-rocprofv3 --kernel-trace -d /tmp/trace_$tag --output-format csv -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-isolated > $R/gpurun_out/${tag}_bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace -d /tmp/trace_$tag --output-format csv -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-isolated --no-lookahead > $R/gpurun_out/${tag}_bench_under_rocprof.json 2>/dev/null
 f=$(ls /tmp/trace_$tag/*/*kernel_trace.csv | head -1)
 cd $R
 # window = after the (INIT 3 + warmup 2 + 1)-th optimizer launch, i.e. the last 5 steps
