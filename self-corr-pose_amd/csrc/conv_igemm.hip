@@ -312,8 +312,11 @@ void launch_cfg(ConvArgs& g, bool leaky, bool stats, hipStream_t st) {
 }
 
 // y[m][n] = epilogue(sum over the K splits of ypart[s][m][n]); with STATS also the column sums / sums of squares of the RAW output
-// per tile of 128 rows (the partials protocol of the convolution kernel's own epilogue), the last workgroup finalises the batch
-// statistics.  grid = row tiles x ceil(Cout / 256); thread = 4 columns x one of 4 row lanes.
+// per tile of FOLD_ROWS rows (the partials protocol of the convolution kernel's own epilogue), the last workgroup finalises the batch
+// statistics.  grid = row tiles x ceil(Cout / 256); thread = 4 columns x one of 4 row lanes.  (32 rows per workgroup: the layers
+// that split K have 2 048 - 8 192 pixels, and with 128-row tiles the launch was 32 - 128 workgroups of a latency-bound loop: 27 us
+// each, 0.67 ms per step.)
+constexpr int FOLD_ROWS = 32;
 template <int EPI, bool STATS>
 __global__ __launch_bounds__(256) void conv_splitk_fold_kernel(const ConvArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[2048];
@@ -329,8 +332,8 @@ __global__ __launch_bounds__(256) void conv_splitk_fold_kernel(const ConvArgs g)
             b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
         }
         const size_t split_stride = (size_t)g.M * g.Cout;
-        for (int r = rl; r < 128; r += 4) {
-            const int m = bm * 128 + r;
+        for (int r = rl; r < FOLD_ROWS; r += 4) {
+            const int m = bm * FOLD_ROWS + r;
             if (m >= g.M) break;
             const float* src = g.ypart + (size_t)m * g.Cout + n;
             float4 a = *reinterpret_cast<const float4*>(src);
@@ -413,7 +416,8 @@ extern "C" int scp_conv_nhwc_partial_rows(int N, int H, int W, int Cin, int Cout
     const int pad = ksize / 2;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const long M = (long)N * Ho * Wo;
-    const int rows = tile_rows(plan_conv(M, Cout, ksize * ksize * Cin, split != 0).cfg);
+    const ConvPlan pl = plan_conv(M, Cout, ksize * ksize * Cin, split != 0);
+    const int rows = pl.ksplit > 1 ? FOLD_ROWS : tile_rows(pl.cfg);
     if (tiles_m) *tiles_m = (int)((M + rows - 1) / rows);
     if (rows_per_tile) *rows_per_tile = rows;
     return 0;
@@ -469,7 +473,7 @@ int conv_forward_impl(const float* x, const float* w, const void* w_split, const
         g.nk_split = (g.K / 16) / pl.ksplit;
         if (ksize == 3) launch_cfg<Cfg128x128, 9>(g, false, false, st);
         else launch_cfg<Cfg128x128, 1>(g, false, false, st);
-        g.tiles_m = (g.M + 127) / 128;
+        g.tiles_m = (g.M + FOLD_ROWS - 1) / FOLD_ROWS;
         const dim3 grid(g.tiles_m * ((Cout + 255) / 256)), block(256);
         if (leaky) {
             if (stats) hipLaunchKernelGGL((conv_splitk_fold_kernel<EPI_BIAS_LEAKY, true>), grid, block, 0, st, g);
