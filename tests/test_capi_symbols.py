@@ -87,3 +87,36 @@ def test_bench_and_entry_points_use_the_oracle_only_where_allowed():
             names = [a.name for a in node.names] + ([node.module] if isinstance(node, ast.ImportFrom) and node.module else [])
             assert not any(n.split(".")[0] in ("oracle", "tests", "scenes", "synth", "step_case") for n in names), names
     assert 'os.path.join(ROOT, "tests")' not in src and "'tests'" not in src
+
+
+def test_convolution_launch_plans_host_side():
+    """host logic behind the convolution entry points (no launch): which layers of the encoder at B = 32 split K on the split
+    main loop, the workspace that implies, and the row tile of the BatchNorm partial sums the caller has to size for"""
+    from scp_amd import capi
+    L = capi.lib()
+    tiles, rows = ctypes.c_int(), ctypes.c_int()
+
+    def plan(h, cin, cout, k=3, stride=1, split=1, n=32):
+        L.scp_conv_nhwc_partial_rows(n, h, h, cin, cout, k, stride, split, ctypes.byref(tiles), ctypes.byref(rows))
+        return L.scp_conv_nhwc_splitk_workspace(n, h, h, cin, cout, k, stride, split), tiles.value, rows.value
+
+    # layer1 (64 x 64, 64 ch): 256 x 64 tiles, no split; layer2 (32 x 32, 128 ch): 128 x 128 tiles fill the machine, no split
+    assert plan(64, 64, 64) == (0, 32 * 64 * 64 // 256, 256)
+    assert plan(32, 128, 128) == (0, 32 * 32 * 32 // 128, 128)
+    # layer3 (16 x 16, 256 ch, K = 2304): two workgroups per 128 x 128 tile; layer4 (8 x 8, 512 ch, K = 4608): four.  The partial
+    # tiles are ksplit x M x Cout floats and the statistics come from the fold kernel in 32-row tiles
+    m3, m4 = 32 * 16 * 16, 32 * 8 * 8
+    assert plan(16, 256, 256) == (2 * m3 * 256 * 4, m3 // 32, 32)
+    assert plan(8, 512, 512) == (4 * m4 * 512 * 4, m4 // 32, 32)
+    # the stride-2 layers' K (1152 / 2304) is too short to split (>= 64 chunks per workgroup), 1 x 1 projections never split
+    assert plan(32, 128, 256, stride=2)[0] == 0 and plan(16, 256, 512, stride=2)[0] == 0
+    assert plan(32, 128, 256, k=1, stride=2)[0] == 0
+    # the fp32 main loop never splits K
+    assert plan(8, 512, 512, split=0)[0] == 0 and plan(16, 256, 256, split=0)[2] == 64
+    # the weight-gradient workspace: ~256 workgroups' partial [Cout, 9, Cin] blocks
+    ws = L.scp_conv_nhwc_weight_grad_workspace(32, 64, 64, 64, 64, 3, 1)
+    assert ws > 0 and ws % (64 * 9 * 64 * 4) == 0 and 200 <= ws // (64 * 9 * 64 * 4) <= 256
+    assert L.scp_conv_nhwc_weight_grad_workspace(32, 64, 64, 64, 64, 3, 2) == 0          # stride 2: not covered
+    # the attention's operand planes + tail-query records
+    n_pad = 1056
+    assert L.scp_vit_attention_split_workspace(32, 1025, 6) == 9 * 32 * 6 * n_pad * 64 * 2 + 32 * 6 * 8 * 8 * 66 * 4
