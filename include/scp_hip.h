@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SCP_ABI_VERSION 1
+#define SCP_ABI_VERSION 2
 
 /* enum values = the integer ids the reference passes (functional/soft_rasterize.py:22-25) */
 enum { SCP_DIST_HARD = 0, SCP_DIST_BARYCENTRIC = 1, SCP_DIST_EUCLIDEAN = 2 };
@@ -398,6 +398,23 @@ int scp_crop_resize_batch(const void* staging, const scp_crop_desc* descs, int B
 size_t scp_mutual_argmax_workspace(int N, int Q);
 int scp_mutual_argmax(const float* scores, const float* rowmask, const float* colmask, int N, int P, int Q,
                       long long* col_index, long long* row_index, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- mutual nearest neighbours WITHOUT the score tensor: score GEMM + dual argmax in one kernel (round 4) --------------------
+ * Replaces pretrained_corr.py:85-89 end to end (`pointcorr = bmm(src_feat^T, tgt_feat)`, mask, `.max(1)`, `.max(2)`), and the
+ * per-pair gathers of the feature maps before it (pretrained_corr.py:59-74, loss_utils.py:326-345):
+ *   keys       [n_images, n_tok, C] fp32, token-major: the DINO key features as the ViT's K projection leaves them
+ *   key_planes [3][n_images * n_tok][C] bf16 = scp_split_bf16x3(keys): the products then run on the bf16 matrix cores with exactly
+ *              split operands (fp32-accurate, csrc/gemm_core_split.h); NULL: fp32 matrix cores on `keys` itself
+ *   tokens tok0 .. tok0 + P - 1 of an image take part (tok0 = 1 skips the class token); C % 32 == 0
+ *   src_img / tgt_img [N] int32: the images of pair n;  mask [n_images, P] fp32 or NULL: a score counts as -1e5 where the source
+ *              token's or the target token's mask is <= 0
+ *   tgt_of_src [N, P] int64 = argmax over target tokens for every source token  (reference `fw`  = pointcorr.max(2).indices)
+ *   src_of_tgt [N, P] int64 = argmax over source tokens for every target token  (reference `bw`  = pointcorr.max(1).indices)
+ *   lowest index on exact ties (torch.max on CPU); workspace >= scp_mutual_nn_fused_workspace(N, P) bytes. */
+size_t scp_mutual_nn_fused_workspace(int N, int P);
+int scp_mutual_nn_fused(const float* keys, const void* key_planes, int n_images, int n_tok, int tok0, int C, const int* src_img,
+                        const int* tgt_img, const float* mask, int N, int P, long long* tgt_of_src, long long* src_of_tgt,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- decoder upsampling backward ---------------------------------------------------------------------------
  * Backward of `F.interpolate(x, size=(2H,2W), mode="bilinear", align_corners=False)` as used by ResNet_Decoder

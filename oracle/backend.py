@@ -51,6 +51,13 @@ def mutual_nn(src_feat, tgt_feat, src_mask, tgt_mask):
     return bw, fw
 
 
+def mutual_nn_pairs(keys, src_img, tgt_img, mask_down, tok0=1):
+    """CPU stand-in of scp_mutual_nn_fused: gather the pairs' feature maps and run the reference formulation"""
+    feat = keys[:, tok0:, :].transpose(1, 2)                      # n_images, C, P
+    bw, fw, _ = oracle_corr.mutual_nn_oracle(feat[src_img], feat[tgt_img], mask_down[src_img], mask_down[tgt_img])
+    return bw, fw
+
+
 def install(monkeypatch):
     import scp_amd.dino as dino
     import scp_amd.mesh as mesh
@@ -61,6 +68,7 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, "feature_vertex_match", feature_vertex_match)
     monkeypatch.setattr(ops, "cols_softargmax", oracle_corr.cols_softargmax_oracle)
     monkeypatch.setattr(ops, "mutual_nn", mutual_nn)
+    monkeypatch.setattr(ops, "mutual_nn_pairs", mutual_nn_pairs)
     monkeypatch.setattr(dino, "fused_attention", fused_attention)
     monkeypatch.setattr(dino, "add_layernorm", add_layernorm)
     monkeypatch.setattr(mesh, "nearest_index", oracle_corr.nearest_index_oracle)

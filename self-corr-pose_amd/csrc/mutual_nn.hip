@@ -8,8 +8,18 @@
 // columns in registers and the strip's row maxima are reduced across the workgroup; column partials of the strips are
 // merged with a 64-bit atomicMax on (order-preserving float bits << 32 | ~row), row results are written directly.
 // Ties resolve to the LOWEST index in both directions (the CPU semantics of torch.max).  HBM-bound: one read of S.
+//
+// scp_mutual_nn_fused (round 4): the score matrix itself is never formed.  pretrained_corr.py:85-89 is `bmm` -> mask -> max(1) /
+// max(2): here one kernel per launch computes, for every (src image, tgt image) pair, 128 x 128 tiles of  S = K_src K_tgt^T
+// (K = the DINO key features of the pair's images, token-major [tokens, 384]) on the matrix cores -- default: the split main loop
+// of csrc/gemm_core_split.h (fp32 products as six bf16 MFMA products, fp32 accumulation), A operand = the fp32 keys split in
+// registers, W operand = their three bf16 planes -- and reduces each tile IN REGISTERS to its masked row maxima / column maxima
+// with the lowest index on ties, merged across tiles by 64-bit atomicMax on (order-preserving float bits << 32 | ~index).
+// 51.5 GFLOP per step at B = 32 and no 268 MB score tensor ("0 if fused with argmax").
 #include <hip/hip_runtime.h>
 
+#include "gemm_core.h"
+#include "gemm_core_split.h"
 #include "scp_common.h"
 #include "scp_hip.h"
 
@@ -97,6 +107,116 @@ __global__ void mutual_unpack_kernel(const unsigned long long* __restrict__ colb
     }
 }
 
+
+// ---- fused score GEMM + dual argmax -------------------------------------------------------------------------------------------
+struct FusedArgs {
+    const float* keys;            // [rows_total, C] fp32, token-major (A operand)
+    const void* w;                // W operand: planes [3][rows_total][C] bf16 (split core) or the same fp32 keys (fp32 core)
+    const int* src_img;           // [N] image of the pair's source / target side
+    const int* tgt_img;
+    const float* mask;            // [B, P] per-image mask at the key resolution (> 0 = inside), or nullptr
+    unsigned long long* rowbest;  // [N, P] packed (value, ~tgt index): best target per source token
+    unsigned long long* colbest;  // [N, P] packed (value, ~src index): best source per target token
+    int N, P, C, n_tok, tok0, rows_total;
+};
+
+using FusedSplitCfg = scp::SplitCfg<2, 2, 2, 2, 2>;        // 128 x 128 tile, 4 wavefronts of 64 x 64, 40 KiB ring
+using FusedFp32Cfg = scp::GemmCfg<2, 2, 2, 2, 2, 2>;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+// maximum over the 32 lanes of a half-wavefront, in every lane of it
+__device__ __forceinline__ float half_max(float x) {
+    x = fmaxf(x, dpp_f<0xB1>(x));        // lane ^ 1
+    x = fmaxf(x, dpp_f<0x4E>(x));        // lane ^ 2
+    x = fmaxf(x, dpp_f<0x141>(x));       // row_half_mirror: lane ^ 7
+    x = fmaxf(x, dpp_f<0x140>(x));       // row_mirror: lane ^ 15
+    return fmaxf(x, __shfl_xor(x, 16, 64));
+}
+__device__ __forceinline__ unsigned long long pack_key(float v, int idx) {
+    return ((unsigned long long)ordered(v) << 32) | (unsigned)(~(unsigned)idx);
+}
+
+template <class CFG, class Core>
+__global__ __launch_bounds__(CFG::THREADS, 2) void mutual_nn_fused_kernel(const FusedArgs g) {
+    static_assert(CFG::WM == 2 && CFG::WN == 2, "the epilogue's lane <-> row / column slots assume 64 x 64 per wavefront");
+    __shared__ __attribute__((aligned(16))) float lds[CFG::LDS_BYTES / 4];
+    // all tiles of a pair on one XCD (workgroup b runs on XCD b % 8): its 8 + 8 operand panels (3.9 MB) stay in that XCD's L2
+    const int tiles_1d = (g.P + CFG::BM - 1) / CFG::BM, tiles = tiles_1d * tiles_1d;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int pair = (local / tiles) * 8 + xcd, tile = local % tiles;
+    if (pair >= g.N) return;
+    const int m0 = (tile / tiles_1d) * CFG::BM, n0 = (tile % tiles_1d) * CFG::BN;
+    const int simg = g.src_img[pair], timg = g.tgt_img[pair];
+    const int srow = simg * g.n_tok + g.tok0, trow = timg * g.n_tok + g.tok0;
+    Core core(lds);
+    core.set_rows(g.keys, g.w, g.rows_total, g.C, [&](int r) { return srow + min(m0 + r, g.P - 1); },
+                  [&](int r) { return trow + min(n0 + r, g.P - 1); });
+    typename Core::Acc acc;
+    core.run(acc, g.C / CFG::BK);
+
+    // ---- epilogue: a lane holds S[m][n] for column n = nb + 32 j + l31 (j = 0, 1) and the 32 rows mb + 32 i + acc_row(r, half)
+    const int half = core.lane >> 5, l31 = core.lane & 31;
+    const int mb = m0 + core.row_base(), nb = n0 + core.col_base();
+    const float* smask = g.mask ? g.mask + (size_t)simg * g.P : nullptr;
+    const float* tmask = g.mask ? g.mask + (size_t)timg * g.P : nullptr;
+    bool ck[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int n = nb + 32 * j + l31;
+        ck[j] = n < g.P && (!tmask || tmask[min(n, g.P - 1)] > 0);
+    }
+    float cv[2] = {-INFINITY, -INFINITY};
+    int cr[2] = {0, 0};
+    unsigned long long rowkey = 0ull;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = mb + 32 * i + scp::acc_row(r, half);
+            const bool m_in = m < g.P;
+            const bool rk = m_in && (!smask || smask[min(m, g.P - 1)] > 0);
+            // masked entries count as -1e5 (pretrained_corr.py:86); rows / columns past the matrix never win
+            const float v0 = (nb + l31 < g.P) ? ((rk && ck[0]) ? acc.t[2 * i][r] : -1e5f) : -INFINITY;
+            const float v1 = (nb + 32 + l31 < g.P) ? ((rk && ck[1]) ? acc.t[2 * i + 1][r] : -1e5f) : -INFINITY;
+            // columns: rows are visited in increasing order, strictly greater keeps the lowest row
+            if (m_in && v0 > cv[0]) { cv[0] = v0; cr[0] = m; }
+            if (m_in && v1 > cv[1]) { cv[1] = v1; cr[1] = m; }
+            // row m: maximum over this wavefront's 64 columns, then the LOWEST column that attains it
+            const float mx = half_max(fmaxf(v0, v1));
+            const unsigned long long b0 = __ballot(v0 == mx), b1 = __ballot(v1 == mx);
+            const unsigned h0 = (unsigned)(b0 >> (32 * half)), h1 = (unsigned)(b1 >> (32 * half));
+            const int col = h0 ? __builtin_ctz(h0) : 32 + __builtin_ctz(h1 | 0x80000000u);
+            if (l31 == 16 * i + r) rowkey = m_in ? pack_key(mx, nb + col) : 0ull;
+        }
+    }
+    // row slots: lane l31 of half h owns row mb + 32 (l31 >> 4) + acc_row(l31 & 15, h)
+    {
+        const int m = mb + 32 * (l31 >> 4) + scp::acc_row(l31 & 15, half);
+        if (m < g.P && rowkey) atomicMax(g.rowbest + (size_t)pair * g.P + m, rowkey);
+    }
+    // column slots: combine the two halves (they hold different rows of the same columns), then half h writes column block j = h
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        unsigned long long k = cv[j] > -INFINITY ? pack_key(cv[j], cr[j]) : 0ull;
+        const unsigned long long o = __shfl_xor(k, 32, 64);
+        k = o > k ? o : k;
+        const int n = nb + 32 * j + l31;
+        if (half == j && n < g.P && k) atomicMax(g.colbest + (size_t)pair * g.P + n, k);
+    }
+}
+
+__global__ void unpack_keys_kernel(const unsigned long long* __restrict__ keys, long long* __restrict__ a, long long* __restrict__ b,
+                                   long n_each) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * n_each) return;
+    const long long idx = (long long)(unsigned)(~(unsigned)(keys[i] & 0xFFFFFFFFull));
+    if (i < n_each) a[i] = idx;
+    else b[i - n_each] = idx;
+}
+
 }  // namespace
 
 extern "C" size_t scp_mutual_argmax_workspace(int N, int Q) { return (size_t)N * Q * sizeof(unsigned long long); }
@@ -121,4 +241,37 @@ extern "C" int scp_mutual_argmax(const float* scores, const float* rowmask, cons
     hipLaunchKernelGGL(mutual_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, colbest, tc, col_index,
                        row_index, tr);
     return scp::check_launch("mutual_argmax unpack");
+}
+
+extern "C" size_t scp_mutual_nn_fused_workspace(int N, int P) { return 2 * (size_t)N * P * sizeof(unsigned long long); }
+
+extern "C" int scp_mutual_nn_fused(const float* keys, const void* key_planes, int n_images, int n_tok, int tok0, int C,
+                                   const int* src_img, const int* tgt_img, const float* mask, int N, int P, long long* tgt_of_src,
+                                   long long* src_of_tgt, void* workspace, size_t workspace_bytes, void* stream) {
+    if (N <= 0 || P <= 0 || n_images <= 0) return scp::fail(hipErrorInvalidValue, "mutual_nn_fused: empty problem");
+    if (!keys || !src_img || !tgt_img || !tgt_of_src || !src_of_tgt) return scp::fail(hipErrorInvalidValue, "mutual_nn_fused: null argument");
+    if (C <= 0 || C % 32 != 0) return scp::fail(hipErrorInvalidValue, "mutual_nn_fused: C must be a multiple of 32");
+    if (tok0 < 0 || tok0 + P > n_tok) return scp::fail(hipErrorInvalidValue, "mutual_nn_fused: tok0 + P exceeds the tokens per image");
+    if ((size_t)n_images * n_tok * C >= (1ull << 30)) return scp::fail(hipErrorInvalidValue, "mutual_nn_fused: keys larger than 2^30 elements");
+    if (!workspace || workspace_bytes < scp_mutual_nn_fused_workspace(N, P))
+        return scp::fail(hipErrorInvalidValue, "mutual_nn_fused: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned long long* best = static_cast<unsigned long long*>(workspace);
+    if (hipMemsetAsync(best, 0, scp_mutual_nn_fused_workspace(N, P), st) != hipSuccess) return scp::check_launch("mutual_nn_fused memset");
+    FusedArgs g{};
+    g.keys = keys; g.w = key_planes ? key_planes : static_cast<const void*>(keys);
+    g.src_img = src_img; g.tgt_img = tgt_img; g.mask = mask;
+    g.rowbest = best; g.colbest = best + (size_t)N * P;
+    g.N = N; g.P = P; g.C = C; g.n_tok = n_tok; g.tok0 = tok0; g.rows_total = n_images * n_tok;
+    const int tiles_1d = (P + FusedSplitCfg::BM - 1) / FusedSplitCfg::BM;
+    const unsigned grid = (unsigned)(((N + 7) / 8) * tiles_1d * tiles_1d * 8);
+    if (key_planes)
+        hipLaunchKernelGGL((mutual_nn_fused_kernel<FusedSplitCfg, scp::SplitGemmCore<FusedSplitCfg>>), dim3(grid), dim3(FusedSplitCfg::THREADS),
+                           0, st, g);
+    else
+        hipLaunchKernelGGL((mutual_nn_fused_kernel<FusedFp32Cfg, scp::GemmCore<FusedFp32Cfg>>), dim3(grid), dim3(FusedFp32Cfg::THREADS), 0, st, g);
+    if (int e = scp::check_launch("mutual_nn_fused")) return e;
+    const long n_each = (long)N * P;
+    hipLaunchKernelGGL(unpack_keys_kernel, dim3((unsigned)((2 * n_each + 255) / 256)), dim3(256), 0, st, best, tgt_of_src, src_of_tgt, n_each);
+    return scp::check_launch("mutual_nn_fused unpack");
 }

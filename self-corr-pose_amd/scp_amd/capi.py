@@ -12,7 +12,7 @@ import torch
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # SCP_HIP_LIB: an alternative build of the same library (A/B of kernel variants from tools/); the default is the in-tree build
 LIB_PATH = os.environ.get("SCP_HIP_LIB") or os.path.join(_PKG, "lib", "libscp_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class RasterParams(ctypes.Structure):
@@ -100,6 +100,8 @@ SYMBOLS = {
     "scp_crop_resize_batch": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _P, _P]),
     "scp_mutual_argmax_workspace": (ctypes.c_size_t, [_I, _I]),
     "scp_mutual_argmax": (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, ctypes.c_size_t, _P]),
+    "scp_mutual_nn_fused_workspace": (ctypes.c_size_t, [_I, _I]),
+    "scp_mutual_nn_fused": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, ctypes.c_size_t, _P]),
     "scp_upsample2x_bilinear_backward": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "scp_upsample2x_bilinear_forward": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "scp_upsample2x_bilinear_forward_bf16": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _P]),

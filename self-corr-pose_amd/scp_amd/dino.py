@@ -358,16 +358,15 @@ class _Block(nn.Module):
         k = torch.zeros(m, c, dtype=torch.float32, device=x2d.device)
         vit_linear(x2d, kq[c:2 * c], ks[c:2 * c], kt[c:2 * c], row_mean_rstd(x2d, key_block.norm1.eps), out=k, epilogue=GEMM_LN,
                    a_rows=idx, c_rows=idx, w_split=key_block._planes["k"], **sel)
-        heads = key_block.attn.num_heads
-        return k.view(b, n, heads, c // heads).permute(0, 2, 1, 3)
+        return k.view(b, n, c)
 
     def keys_fused(self, x2d, b, n):
-        """K third of qkv(LN1(x)): [b, heads, n, d]  (the only part of block 9 the DINO features need)"""
+        """K third of qkv(LN1(x)), token-major [b, n, heads * d]  (the only part of block 9 the DINO features need)"""
         (wq, sq, tq), _ = self._folded()
         c = x2d.shape[1]
         k = vit_linear(x2d, wq[c:2 * c], sq[c:2 * c], tq[c:2 * c], row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN,
                        w_split=self._planes["k"])
-        return k.view(b, n, self.attn.num_heads, c // self.attn.num_heads).permute(0, 2, 1, 3)
+        return k.view(b, n, c)
 
 
 class _PatchEmbed(nn.Module):
@@ -421,8 +420,16 @@ class VisionTransformer(nn.Module):
         return tok + self.interpolate_pos_encoding(tok.shape[1] - 1, w, h)
 
     def key_features(self, x, layer=9, keep=None):
-        """keys of block `layer`: [b, heads, tokens, d].  `keep` (bool [b, tokens - 1], patch tokens): only these tokens' keys
-        are needed -- the others come back as zeros (fused GPU path; ignored elsewhere, where all keys are computed)"""
+        """keys of block `layer`: [b, heads, tokens, d] (a view of key_tokens)"""
+        k = self.key_tokens(x, layer, keep)
+        b, n, c = k.shape
+        heads = self.blocks[layer].attn.num_heads
+        return k.view(b, n, heads, c // heads).permute(0, 2, 1, 3)
+
+    def key_tokens(self, x, layer=9, keep=None):
+        """keys of block `layer`, token-major as the K projection leaves them: [b, tokens, heads * d] contiguous, channel =
+        head * 64 + d (dino.py:102-108).  `keep` (bool [b, tokens - 1], patch tokens): only these tokens' keys are needed -- the
+        others come back as zeros (fused GPU path; ignored elsewhere, where all keys are computed)"""
         if x.is_cuda and (MIXED_OWN_KERNELS or not MIXED_BF16):   # fused path; under MIXED_BF16 the same kernels, operands rounded to bf16
             tok = self.prepare_tokens(x).float().contiguous()
             b, n, c = tok.shape
@@ -440,7 +447,8 @@ class VisionTransformer(nn.Module):
             tok, pending = blk(tok, pending)
         blk = self.blocks[layer]
         tok, y = add_layernorm(tok, pending, blk.norm1)
-        return blk.attn.keys(y)
+        k = blk.attn.keys(y)                                   # b,h,n,d
+        return k.permute(0, 2, 1, 3).reshape(k.shape[0], k.shape[2], -1)
 
     @torch.no_grad()
     def forward(self, x):
@@ -471,10 +479,17 @@ class DINO(nn.Module):
         return super().train(False)  # frozen feature extractor, always eval (pretrained_corr.py:21)
 
     @torch.no_grad()
+    def key_tokens(self, img, keep=None):
+        """the block-9 keys token-major, class token included at row 0: [b, 1 + side*side, 384] contiguous.  This is the layout the
+        mutual-nearest-neighbour matching consumes (scp_mutual_nn_fused: a token's key is one K-contiguous GEMM row); forward()
+        is its channel-major view for callers that want the reference's [b, 384, side, side] map."""
+        return self.model.key_tokens(img, self.feat_layer, keep)
+
+    @torch.no_grad()
     def forward(self, img, keep=None):
         """`keep` (bool [b, side*side] or [b, side, side]): the patch tokens whose features will be read; the others may come
-        back as zeros (VisionTransformer.key_features)"""
-        k = self.model.key_features(img, self.feat_layer, keep)[:, :, 1:, :]     # drop cls: b,h,t,d
-        b, nh, t, d = k.shape
+        back as zeros (VisionTransformer.key_tokens)"""
+        k = self.key_tokens(img, keep)[:, 1:, :]                                 # drop cls: b,t,c
+        b, t, c = k.shape
         side = int(math.sqrt(t))
-        return k.permute(0, 1, 3, 2).reshape(b, nh * d, side, side)
+        return k.transpose(1, 2).reshape(b, c, side, side)

@@ -9,7 +9,7 @@ compositions of stock PyTorch ops (library GEMMs, argmax, gather) and run on any
 
 Reference call sites: model/module/correspondence.py:42-53 (feature_vertex_match), :58-60
 (nearest_vertex), :105-110 (pixel_pixel_softargmax); model/module/pretrained_corr.py:85-102
-(mutual_nn), :120-137 (pool2x2_scores, vertex_bridge_match).
+(mutual_nn, mutual_nn_pairs), :120-137 (pool2x2_scores, vertex_bridge_match).
 """
 import torch
 
@@ -72,6 +72,17 @@ def mutual_nn(src_feat, tgt_feat, src_mask, tgt_mask):
     _require_gpu(src_feat, "mutual_nn")
     pc = src_feat.transpose(1, 2).bmm(tgt_feat)
     return corr_ops.mutual_argmax(pc, src_mask, tgt_mask)
+
+
+def mutual_nn_pairs(keys, src_img, tgt_img, mask_down, tok0=1):
+    """The training path's form of mutual_nn (pretrained_corr.py:59-89 in one kernel, csrc/mutual_nn.hip scp_mutual_nn_fused): keys
+    [n_images, n_tok, C] token-major DINO keys (class token at row 0 .. tok0 - 1), src_img / tgt_img [N] the images of each pair,
+    mask_down [n_images, P] per image  ->  (bw [N,P], fw [N,P]) as mutual_nn; neither the gathered per-pair feature maps nor the
+    [N,P,P] score tensor exist.  The products run on the matrix cores the ViT's linear layers use (scp_amd.dino.GEMM_MODE)."""
+    _require_gpu(keys, "mutual_nn_pairs")
+    from . import dino
+    mode = dino.gemm_mode()
+    return corr_ops.mutual_nn_fused(keys, src_img, tgt_img, mask_down, tok0, "fp32" if mode == "fp32" else "split")
 
 
 def pool2x2_scores(pc, hf, wf):

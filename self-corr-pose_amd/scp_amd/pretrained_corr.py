@@ -6,9 +6,10 @@ pixels), compute_cycle_loss :107-140 (soft pixel->pixel map bridged through the 
 the DINO matches).  Batch re-pairing: model/util/loss_utils.py:326-345.
 
 MI355X-first differences, value-preserving: DINO runs once per unique image and the src/tgt lists
-are gathers of feature maps (the reference pushes 4B images through the ViT for B
-unique ones); `pointcorr` is pooled once per image before pairing; the bridge `corr` matrix is only
-formed for the k gathered target columns.
+are INDEX lists into its token-major keys (the reference pushes 4B images through the ViT
+for B unique ones); the [2B,1024,1024] score matrix of :85 is never formed -- score GEMM and both
+argmax reductions are one kernel (scp_mutual_nn_fused); `pointcorr` is pooled once per image before
+pairing; the bridge `corr` matrix is only formed for the k gathered target columns.
 """
 import torch
 import torch.nn as nn
@@ -54,16 +55,32 @@ class PretrainedCorrespondence(nn.Module):
     # -- reference signature: images in, DINO inside --------------------------------------------
     def match(self, src_img, tgt_img, src_mask, tgt_mask, grid):
         bsz = src_img.shape[0]
-        feats = self.net(torch.cat((src_img, tgt_img), 0))
-        return self.match_features(feats[:bsz], feats[bsz:], src_mask, tgt_mask, grid)
+        keys = self.net.key_tokens(torch.cat((src_img, tgt_img), 0))
+        idx = torch.arange(bsz, device=keys.device)
+        return self._match_keys(keys, torch.cat((src_mask, tgt_mask), 0), idx, idx + bsz, grid)
 
     def match_features(self, src_feat, tgt_feat, src_mask, tgt_mask, grid):
+        """the matching given per-pair feature maps [N, C, fs, fs] (pretrained_corr.py:76-104); scores through ops.mutual_nn"""
         bsz = src_feat.shape[0]
         fs = self.feat_size
         src_feat, tgt_feat = src_feat.reshape(bsz, src_feat.shape[1], -1), tgt_feat.reshape(bsz, tgt_feat.shape[1], -1)
         src_mask_down = F.interpolate(src_mask[:, None], (fs, fs), mode="nearest").reshape(bsz, -1)
         tgt_mask_down = F.interpolate(tgt_mask[:, None], (fs, fs), mode="nearest").reshape(bsz, -1)
         bw, fw = ops.mutual_nn(src_feat, tgt_feat, src_mask_down, tgt_mask_down)
+        return self._select(bw, fw, tgt_mask_down, grid)
+
+    def _match_keys(self, keys, mask, src_idx, tgt_idx, grid):
+        """the same from the token-major keys of the unique images [n_images, 1 + fs*fs, C] and the pair lists: score GEMM and both
+        argmax reductions in one kernel (ops.mutual_nn_pairs), no per-pair feature gathers, no score tensor"""
+        fs = self.feat_size
+        mask_down = F.interpolate(mask[:, None].float(), (fs, fs), mode="nearest").reshape(mask.shape[0], -1)
+        bw, fw = ops.mutual_nn_pairs(keys, src_idx, tgt_idx, mask_down, tok0=keys.shape[1] - fs * fs)
+        return self._select(bw, fw, mask_down[tgt_idx], grid)
+
+    def _select(self, bw, fw, tgt_mask_down, grid):
+        """cycle distance of every target pixel through its mutual nearest neighbours, the k most consistent ones
+        (pretrained_corr.py:88-104)"""
+        bsz = bw.shape[0]
         self.last_nn = (bw, fw)
         if self.nn_override is not None:
             bw, fw = self.nn_override
@@ -86,7 +103,7 @@ class PretrainedCorrespondence(nn.Module):
         return match, grid_k, indices_match, indices, match_mask
 
     def _keep_tokens(self, mask):
-        """the patch tokens inside the object mask at the DINO resolution: match_features masks every other token out of the
+        """the patch tokens inside the object mask at the DINO resolution: the matching masks every other token out of the
         mutual-nearest-neighbour search (pretrained_corr.py:85-89), so their features are never read"""
         fs = self.feat_size
         return F.interpolate(mask[:, None].float(), (fs, fs), mode="nearest").reshape(mask.shape[0], -1) > 0
@@ -104,35 +121,36 @@ class PretrainedCorrespondence(nn.Module):
             self._side_stream = torch.cuda.Stream(device=img.device)
         self._side_stream.wait_stream(torch.cuda.current_stream(img.device))
         with torch.cuda.stream(self._side_stream):
-            feats = self.net(img, None if mask is None else self._keep_tokens(mask))
-            # the mutual-nearest-neighbour matching of the re-paired batch (score GEMM, dual argmax, top-k) needs nothing but
-            # the features and the masks either: it stays on the side stream instead of the main stream's critical path
-            matched = self._match_pairs(feats, mask) if mask is not None else None
+            keys = self.net.key_tokens(img, None if mask is None else self._keep_tokens(mask))
+            # the mutual-nearest-neighbour matching of the re-paired batch (fused score GEMM + dual argmax, top-k) needs nothing
+            # but the keys and the masks either: it stays on the side stream instead of the main stream's critical path
+            matched = self._match_pairs(keys, mask) if mask is not None else None
         img.record_stream(self._side_stream)
         if mask is not None:
             mask.record_stream(self._side_stream)
-        self._prefetched = (img, feats, matched)
+        self._prefetched = (img, keys, matched)
 
-    def _match_pairs(self, feats, mask):
-        src_idx, tgt_idx = pair_indices(self.divide_kind, self.opts.batch_size, self.opts.repeat, feats.device)
-        return self.match_features(feats[src_idx], feats[tgt_idx], mask[src_idx], mask[tgt_idx], self.half_grid(src_idx.shape[0]))
+    def _match_pairs(self, keys, mask):
+        src_idx, tgt_idx = pair_indices(self.divide_kind, self.opts.batch_size, self.opts.repeat, keys.device)
+        return self._match_keys(keys, mask, src_idx, tgt_idx, self.half_grid(src_idx.shape[0]))
 
     def _features(self, img, mask=None):
-        """(DINO features once per unique image, their pair matching) -- from the side stream if prefetch_features started them"""
+        """(DINO keys once per unique image, token-major; their pair matching) -- from the side stream if prefetch_features
+        started them"""
         pre = getattr(self, "_prefetched", None)
         self._prefetched = None
         if pre is not None and pre[0] is img:
             main = torch.cuda.current_stream(img.device)
             main.wait_stream(self._side_stream)
-            feats, matched = pre[1], pre[2]
+            keys, matched = pre[1], pre[2]
             if matched is None:
-                matched = self._match_pairs(feats, mask)
+                matched = self._match_pairs(keys, mask)
             else:
                 for t in matched:
                     t.record_stream(main)
-            return feats, matched
-        feats = self.net(img, None if mask is None else self._keep_tokens(mask))
-        return feats, self._match_pairs(feats, mask)
+            return keys, matched
+        keys = self.net.key_tokens(img, None if mask is None else self._keep_tokens(mask))
+        return keys, self._match_pairs(keys, mask)
 
     def compute_cycle_loss(self, img, mask, depth_weight, pointcorr):
         num_verts = pointcorr.shape[-1]

@@ -276,6 +276,68 @@ def test_hip_mutual_argmax_vs_oracle(N, C, P, Q):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["split", "fp32"])
+@pytest.mark.parametrize("B,n_tok,C,tok0", [(4, 1025, 384, 1), (3, 201, 64, 1), (2, 4097, 384, 1), (2, 128, 32, 0)])
+def test_hip_mutual_nn_fused_vs_float64(B, n_tok, C, tok0, mode):
+    """scp_mutual_nn_fused (score GEMM + dual argmax in one kernel, no score tensor) against pretrained_corr.py:85-89 evaluated in
+    float64 on the same keys: every selected index is THE argmax, or differs from it only at a near-tie of the float64 scores
+    (top-2 gap < 1e-5 relative: SURVEY F16); exact ties (bitwise duplicated tokens) resolve to the lowest index in both
+    directions; an image that is fully masked, pairs that repeat an image, P not a multiple of the 128-wide tile."""
+    from scp_amd import corr_ops
+    g = torch.Generator().manual_seed(B * 7 + n_tok)
+    P = n_tok - tok0
+    keys = torch.randn(B, n_tok, C, generator=g) * 1.7
+    keys[:, tok0 + 3] = keys[:, tok0 + 1]                    # exact ties: token 3 duplicates token 1 in every image
+    keys[:, tok0 + P - 1] = keys[:, tok0 + 2]
+    mask = (torch.rand(B, P, generator=g) > 0.35).float()
+    mask[:, 1] = mask[:, 3] = 1.
+    mask[B - 1] = 0.                                         # an image with nothing to match
+    src = torch.tensor([0, 1, 0, B - 1, 1][:max(2, B + 1)])
+    tgt = torch.tensor([1, 0, 0, 0, B - 1][:max(2, B + 1)])
+    bw, fw = corr_ops.mutual_nn_fused(keys.cuda(), src, tgt, mask.cuda(), tok0, mode)
+    bw, fw = bw.cpu(), fw.cpu()
+    k64 = keys[:, tok0:].double()
+    for n in range(src.numel()):
+        s, t = int(src[n]), int(tgt[n])
+        pc = k64[s] @ k64[t].t()
+        keep = (mask[s][:, None] > 0) & (mask[t][None, :] > 0)
+        pc = torch.where(keep, pc, torch.full_like(pc, -1e5))
+        for name, got, ref_v, ref_i, dim in (("bw", bw[n], pc.max(0).values, pc.max(0).indices, 0), ("fw", fw[n], pc.max(1).values, pc.max(1).indices, 1)):
+            chosen = pc.gather(dim, got[None] if dim == 0 else got[:, None]).reshape(-1)
+            gap = ref_v - chosen
+            assert bool((gap >= 0).all())
+            flips = got != ref_i
+            assert bool((gap[flips] <= 1e-5 * ref_v[flips].abs()).all()), (name, n, gap[flips].max())
+            assert flips.float().mean() <= 0.02, (name, n, flips.float().mean())
+            # exact ties resolve to the lowest index: the duplicates (3 of 1, P-1 of 2) are never selected
+            assert not bool((got == 3).any()) and not bool((got == P - 1).any()), (name, n)
+        if mask[s].sum() == 0 or mask[t].sum() == 0:         # all entries -1e5: lowest index everywhere
+            assert bool((bw[n] == 0).all()) and bool((fw[n] == 0).all())
+    # no mask: plain argmax
+    bw2, fw2 = corr_ops.mutual_nn_fused(keys.cuda(), src[:1], tgt[:1], None, tok0, mode)
+    pc = k64[int(src[0])] @ k64[int(tgt[0])].t()
+    assert (bw2[0].cpu() != pc.max(0).indices).float().mean() <= 0.02 and (fw2[0].cpu() != pc.max(1).indices).float().mean() <= 0.02
+
+
+@pytest.mark.gpu
+def test_hip_mutual_nn_fused_equals_two_step_path():
+    """the fused kernel against the build's own two-step path (score tensor by a library GEMM of the same keys, then
+    scp_mutual_argmax) at the training shape: identical wherever the two GEMMs' scores do not near-tie"""
+    from scp_amd import corr_ops
+    g = torch.Generator().manual_seed(3)
+    B, n_tok, C = 8, 1025, 384
+    keys = (torch.randn(B, n_tok, C, generator=g) * 1.5).cuda()
+    mask = (torch.rand(B, 1024, generator=g) > 0.4).float().cuda()
+    src = torch.arange(B).repeat(2)
+    tgt = torch.cat((torch.arange(B).roll(1), torch.arange(B).roll(3)))
+    bw, fw = corr_ops.mutual_nn_fused(keys, src, tgt, mask, 1, "split")
+    feat = keys[:, 1:].transpose(1, 2)
+    pc = feat[src].transpose(1, 2).bmm(feat[tgt])
+    bw_ref, fw_ref = corr_ops.mutual_argmax(pc, mask[src], mask[tgt])
+    assert (bw != bw_ref).float().mean() <= 1e-3 and (fw != fw_ref).float().mean() <= 1e-3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,hf,V", [(2, 64, 642), (3, 8, 37), (1, 16, 995), (2, 4, 64)])
 def test_fused_feature_vertex_match_vs_oracle(B, hf, V):
     """csrc/corr_fused.hip (scores never stored) against the materialised oracle: pooled scores, match, imatch and the

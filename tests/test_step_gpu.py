@@ -250,7 +250,7 @@ def test_lookahead_of_the_frozen_vit_changes_nothing_but_the_schedule():
                 assert img is nxt[0]
                 torch.cuda.synchronize()
                 with torch.no_grad():
-                    direct = pc.net(nxt[0], pc._keep_tokens(nxt[1]))
+                    direct = pc.net.key_tokens(nxt[0], pc._keep_tokens(nxt[1]))
                     direct_matched = pc._match_pairs(direct, nxt[1])
                 assert torch.equal(feats, direct)
                 for u, v in zip(matched, direct_matched):

@@ -207,7 +207,7 @@ def test_fused_block_matches_oracle(B, N, gemm_mode):
         prm64 = {k: v.double().cpu() for k, v in prm64.items()}
         ref = oracle.block_oracle(x.double().cpu(), prm64, 6)
         ref_k = oracle.block_keys_oracle(x.double().cpu(), prm64, 6)
-        got_k = blk.keys_fused(x.view(B * N, 384).clone(), B, N).cpu().double()
+        got_k = blk.keys_fused(x.view(B * N, 384).clone(), B, N).view(B, N, 6, 64).permute(0, 2, 1, 3).cpu().double()
         got = blk.forward_fused(x.view(B * N, 384).clone(), B, N).view(B, N, 384).cpu().double()
     for name, g_, r_ in (("block", got, ref), ("keys", got_k, ref_k)):
         err, scale = (g_ - r_).abs().max().item(), r_.abs().max().item()
