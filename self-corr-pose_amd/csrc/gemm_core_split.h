@@ -34,9 +34,13 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 // NPLANES = 3: the exact split (six products).  NPLANES = 1: operands ROUNDED to bf16 (W given as one bf16 plane, A converted in
 // registers), one product -- plain bf16 matrix-core precision with fp32 accumulation, BASELINE configs[4] ("mixed bf16").
-template <int WM_, int WN_, int NWM_, int NWN_, int MINBLK_, int NPLANES_ = 3>
+// ZSTART: the six partial products of a chunk are summed in a chunk-local accumulator that starts at zero and is added to the
+// running accumulator by the VALU (see compute()); needs 16 WN more VGPRs, which the 4 x 2-tile wavefronts of the ViT's 256 x 128
+// tile do not have while their A operand is still split in registers.
+template <int WM_, int WN_, int NWM_, int NWN_, int MINBLK_, int NPLANES_ = 3, bool ZSTART_ = (WM_ * WN_ <= 4)>
 struct SplitCfg {
     static constexpr int NPLANES = NPLANES_;
+    static constexpr bool ZSTART = ZSTART_;
     static constexpr int WM = WM_, WN = WN_, NWM = NWM_, NWN = NWN_, NSTAGE = 2, MINBLK = MINBLK_;
     static constexpr int BM = 32 * WM * NWM, BN = 32 * WN * NWN, BK = 16;
     static constexpr int NW = NWM * NWN, THREADS = 64 * NW;
@@ -180,19 +184,47 @@ struct SplitGemmCore {
                 continue;
             }
             const Split3 a = split3(x);
-            // smallest terms first; six products per accumulator tile, tiles interleaved so that consecutive MFMAs are independent
-            auto mac = [&](const bf16x8& av, int p) {
+            if constexpr (CFG::NPLANES == 3 && !CFG::ZSTART) {
+                // smallest terms first; six products per accumulator tile, tiles interleaved so that consecutive MFMAs are independent
+                auto mac = [&](const bf16x8& av, int p) {
 #pragma unroll
-                for (int j = 0; j < CFG::WN; j++)
-                    acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wf[p][j], acc.t[i * CFG::WN + j], 0, 0, 0);
-            };
-            if constexpr (CFG::NPLANES == 3) {
+                    for (int j = 0; j < CFG::WN; j++)
+                        acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wf[p][j], acc.t[i * CFG::WN + j], 0, 0, 0);
+                };
                 mac(a.m, 1);
                 mac(a.l, 0);
                 mac(a.h, 2);
                 mac(a.m, 0);
                 mac(a.h, 1);
                 mac(a.h, 0);
+            }
+            if constexpr (CFG::NPLANES == 3 && CFG::ZSTART) {
+                // All six partial products of a chunk are summed by the matrix core in an accumulator that starts at ZERO in every
+                // chunk (smallest terms first), and only the chunk's sum is added -- VALU, round to nearest -- to the running
+                // accumulator.  Measured (tools/split_bias_probe.py, round 4): chained onto the running accumulator, every small-term
+                // MFMA aligns its 16 products to the accumulator's exponent and FLOORS what falls below the matrix core's guard
+                // bits: a relative bias of -1.1e-7 at K = 4608 on same-sign data (the fp32 cores: -4e-9), and the small terms were
+                // rounded away one MFMA at a time.  Against a chunk-local accumulator nothing falls below the window.
+                f32x16 c[CFG::WN];
+#pragma unroll
+                for (int j = 0; j < CFG::WN; j++) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) z[r] = 0.f;
+                    c[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, wf[1][j], z, 0, 0, 0);
+                }
+                auto mac = [&](const bf16x8& av, int p) {
+#pragma unroll
+                    for (int j = 0; j < CFG::WN; j++) c[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wf[p][j], c[j], 0, 0, 0);
+                };
+                mac(a.l, 0);
+                mac(a.h, 2);
+                mac(a.m, 0);
+                mac(a.h, 1);
+                mac(a.h, 0);
+#pragma unroll
+                for (int j = 0; j < CFG::WN; j++) acc.t[i * CFG::WN + j] += c[j];
+                __builtin_amdgcn_sched_barrier(0);      // one row tile at a time: the chunk accumulators of two tiles never coexist
             }
         }
     }

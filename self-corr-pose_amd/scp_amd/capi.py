@@ -157,6 +157,11 @@ def current_stream():
 
 _TICKETS = {}
 _TICKET_WORDS = 8192
+# set by scp_amd.graphed while a HIP graph is being captured: launches recorded into a graph keep their ticket word for every
+# replay, so they get words of their own that the round-robin pool never hands out again
+CAPTURING = False
+_GRAPH_TICKETS = {}
+_GRAPH_TICKET_WORDS = 65536
 
 
 def ticket(device):
@@ -165,6 +170,15 @@ def ticket(device):
     later launches have been enqueued."""
     import torch
     key = device.index if device.index is not None else torch.cuda.current_device()
+    if CAPTURING:
+        pool = _GRAPH_TICKETS.get(key)
+        if pool is None:
+            raise RuntimeError("scp_amd.capi: reserve_graph_tickets(device) must run before a capture (it allocates and synchronises)")
+        i = pool[1]
+        if i >= _GRAPH_TICKET_WORDS:
+            raise RuntimeError("scp_amd.capi: graph ticket words exhausted")
+        pool[1] = i + 1
+        return ctypes.c_void_p(pool[0].data_ptr() + 4 * i)
     pool = _TICKETS.get(key)
     if pool is None:
         buf = torch.zeros(_TICKET_WORDS, dtype=torch.int32, device=device)
@@ -173,6 +187,16 @@ def ticket(device):
     i = pool[1]
     pool[1] = (i + 1) % _TICKET_WORDS
     return ctypes.c_void_p(pool[0].data_ptr() + 4 * i)
+
+
+def reserve_graph_tickets(device):
+    """the zeroed ticket words of launches that get captured into HIP graphs (see CAPTURING); call before the first capture"""
+    import torch
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _GRAPH_TICKETS:
+        buf = torch.zeros(_GRAPH_TICKET_WORDS, dtype=torch.int32, device=device)
+        torch.cuda.current_stream(device).synchronize()
+        _GRAPH_TICKETS[key] = [buf, 0]
 
 
 def dev_ptr(t, name):

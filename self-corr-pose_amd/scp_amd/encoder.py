@@ -26,24 +26,60 @@ class Encoder(nn.Module):
         self.shape_predictor = ShapePredictor(opts)
         self.pose_predictor = PosePredictor(opts, 512)
 
-    def encode_img(self, img, half_res=False):
-        """half_res: features at the even pixels of the feature map only (nets.ResNet_Decoder.forward)"""
+    # ---- HIP-graph replay of the two passes (scp_amd/graphed.py) ------------------------------------------------------------------
+    # Trainer switches this on (use_graphs = True) for fp32 training on the GPU: everything after the colour jitter -- whose random
+    # draw is a host-side kernel argument -- has static shapes and runs on one stream, ~100 launches forward and ~330 backward
+    # per pass.  The full pass (trunk + decoder + heads) and the rotated images' half-resolution pass are separate segments.
+    use_graphs = False
+
+    def _segment(self, name, fn):
+        segs = self.__dict__.setdefault("_graph_segments", {})
+        if name not in segs:
+            from .graphed import GraphedSegment
+            segs[name] = GraphedSegment(fn, [p for p in self.parameters() if p.requires_grad], warmup=2, name=name)
+        return segs[name]
+
+    def _graphable(self, x):
+        return (self.use_graphs and x.is_cuda and self.training and torch.is_grad_enabled()
+                and not bool(getattr(self.opts, "mixed_bf16", False)))
+
+    def _normalized(self, img):
         x = imgops.jitter_normalize(img, self.random_jitter, self.resnet_transform)
         if x.is_cuda:
             # NHWC end to end: MIOpen's fp32 implicit-GEMM kernels and PyTorch's NHWC bilinear
             # upsampling are ~2x faster on gfx950 than the NCHW paths for these shapes (measured,
             # tools/conv_diag.py); values are layout independent
             x = x.contiguous(memory_format=torch.channels_last)
+        return x
+
+    def _features(self, x, half_res=False):
+        """normalised NHWC image -> (img_code [B,512], unit-norm features [B,C,P])"""
         # BASELINE configs[4]: convolutions on the bf16 matrix cores, everything after them in fp32
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(getattr(self.opts, "mixed_bf16", False)) and x.is_cuda):
             c2, c3, c4, c5 = self.backbone(x)
             feat = self.featnet(c2, c3, c4, c5, half_res=half_res)
         img_code = c5.float().mean((2, 3))
-        feat = feat.float().contiguous().reshape(img.shape[0], self.opts.n_corr_feat, -1)
+        feat = feat.float().contiguous().reshape(x.shape[0], self.opts.n_corr_feat, -1)
         return img_code, F.normalize(feat, 2, 1)
 
+    def _features_half(self, x):
+        return self._features(x, half_res=True)
+
+    def encode_img(self, img, half_res=False):
+        """half_res: features at the even pixels of the feature map only (nets.ResNet_Decoder.forward)"""
+        x = self._normalized(img)
+        if self._graphable(x):
+            return self._segment("half" if half_res else "img", self._features_half if half_res else self._features)(x)
+        return self._features(x, half_res)
+
     def forward(self, img, mean_v, pp_crop, foc_crop):
-        img_code, img_feat = self.encode_img(img)
+        x = self._normalized(img)
+        if self._graphable(x):
+            return self._segment("full", self._heads_from_normalized)(x, mean_v, pp_crop, foc_crop)
+        return self._heads_from_normalized(x, mean_v, pp_crop, foc_crop)
+
+    def _heads_from_normalized(self, x, mean_v, pp_crop, foc_crop):
+        img_code, img_feat = self._features(x)
         pred_v = self.shape_predictor(mean_v, self.shape_code_predictor(img_code))
         mesh_feat = F.normalize(self.featnet_mesh(pred_v.detach()), 2, -1)
         rotation, trans, scale = self.pose_predictor(img_code)

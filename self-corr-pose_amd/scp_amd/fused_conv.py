@@ -82,24 +82,47 @@ def split_planes(t):
 def weight_planes(conv, with_dgrad):
     """The split operands of a convolution's weight for this weight version, kept on the module: "fwd" = planes of
     [Cout, k, k, Cin], "dgrad" = planes of the flipped / transposed [Cin, k, k, Cout] the input gradient multiplies with.
-    Both encoder passes of a step (and their backward passes) share them; they are rebuilt when the optimizer has stepped.
-    Built on the stream of the first forward of the step (the main stream, which every side stream has waited for)."""
+    Both encoder passes of a step (and their backward passes) share them.  The buffers are PERSISTENT (their addresses are baked into
+    the HIP graphs of scp_amd.graphed) and rebuilt IN PLACE when the weight has changed: lazily here, keyed by (storage, tensor
+    version, WEIGHT_EPOCH), or eagerly by refresh_planes(), which Trainer.step calls once per step on the main stream before any side
+    stream starts (updates made through `.data` -- optimizer-free loading, broadcasts -- do not bump the tensor version: callers of
+    such updates bump WEIGHT_EPOCH).  Under graph capture a stale cache is an error, not a launch."""
     w = conv.weight
-    key = (w.data_ptr(), w._version, str(w.device))
+    key = (w.data_ptr(), w._version, str(w.device), WEIGHT_EPOCH[0])
     cache = conv.__dict__.get("_scp_planes")
-    if cache is None or cache["key"] != key:
-        cache = conv.__dict__["_scp_planes"] = {"key": key}
-    if "fwd" not in cache or (with_dgrad and "dgrad" not in cache):
+    if cache is None:
+        cache = conv.__dict__["_scp_planes"] = {"key": None}
+    stale = cache["key"] != key
+    if stale or (with_dgrad and "dgrad" not in cache):
+        if capi.CAPTURING:
+            raise RuntimeError("scp_amd.fused_conv: weight planes are stale under graph capture -- call refresh_planes() first")
         cout, cin, k, _ = w.shape
-        fwd = torch.empty(3, cout, k, k, cin, dtype=torch.bfloat16, device=w.device)
-        dgrad = torch.empty(3, cin, k, k, cout, dtype=torch.bfloat16, device=w.device) if with_dgrad else None
+        if "fwd" not in cache:
+            cache["fwd"] = torch.empty(3, cout, k, k, cin, dtype=torch.bfloat16, device=w.device)
+        build_dgrad = with_dgrad or "dgrad" in cache
+        if build_dgrad and "dgrad" not in cache:
+            cache["dgrad"] = torch.empty(3, cin, k, k, cout, dtype=torch.bfloat16, device=w.device)
         wd = w.detach()
+        # one launch fills both plane sets (a "fwd" set that is current is rewritten with the values it already holds)
         capi.check(capi.lib().scp_conv_weight_planes(ctypes.c_void_p(wd.data_ptr()), wd.stride(0), wd.stride(1), wd.stride(2), wd.stride(3),
-                                                     cout, cin, k, _ptr(fwd), _ptr(dgrad), capi.current_stream()), "conv_weight_planes")
-        cache["fwd"] = fwd
-        if with_dgrad:
-            cache["dgrad"] = dgrad
+                                                     cout, cin, k, _ptr(cache["fwd"]), _ptr(cache["dgrad"] if build_dgrad else None),
+                                                     capi.current_stream()), "conv_weight_planes")
+        cache["key"] = key
     return cache
+
+
+# bumped by whoever changes weights without going through an optimizer step on the tensor itself (load_state_dict / broadcast via .data)
+WEIGHT_EPOCH = [0]
+
+
+def refresh_planes(convs):
+    """rebuild the split planes of every convolution in `convs` whose weight changed since they were built (Trainer.step: once per
+    step, main stream, before the forward)"""
+    if CONV_MODE != "split":
+        return
+    for conv in convs:
+        if conv.weight.is_cuda:
+            weight_planes(conv, with_dgrad=conv.weight.requires_grad or "dgrad" in conv.__dict__.get("_scp_planes", {}))
 
 
 def _planes_arg(conv, x, stride):

@@ -150,7 +150,9 @@ class MeshNet(nn.Module):
         if opts.camera_loss:
             aux_output["cam_loss"] = cam_loss
         self.last_pose = (rotation.detach(), translation.detach())
-        self.last_geometry = (pred_v.detach(), rotation.detach(), translation.detach())   # the encoder's geometric outputs (parity runs pin them)
+        # the encoder's outputs of this step (parity runs pin them on the other side; references, no copies)
+        self.last_geometry = (pred_v.detach(), rotation.detach(), translation.detach())
+        self.last_features = (img_feat.detach(), mesh_feat.detach())
         return total_loss, aux_output
 
     def _texture_loss(self, pred_v, faces, tex, cam, img, mask, occ):

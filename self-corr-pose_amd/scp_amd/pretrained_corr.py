@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import dino, ops
 from .correspondence import make_meshgrid
 from .dino import DINO
 from .losses import pair_indices
@@ -121,14 +121,29 @@ class PretrainedCorrespondence(nn.Module):
             self._side_stream = torch.cuda.Stream(device=img.device)
         self._side_stream.wait_stream(torch.cuda.current_stream(img.device))
         with torch.cuda.stream(self._side_stream):
-            keys = self.net.key_tokens(img, None if mask is None else self._keep_tokens(mask))
-            # the mutual-nearest-neighbour matching of the re-paired batch (fused score GEMM + dual argmax, top-k) needs nothing
-            # but the keys and the masks either: it stays on the side stream instead of the main stream's critical path
-            matched = self._match_pairs(keys, mask) if mask is not None else None
+            if self.use_graphs and mask is not None and self.nn_override is None and self.topk_override is None and not dino.MIXED_BF16:
+                # the whole frozen pass (ViT + matching, ~150 launches) as one HIP-graph replay (scp_amd/graphed.py)
+                if getattr(self, "_vit_graph", None) is None:
+                    from .graphed import GraphedInference
+                    self._vit_graph = GraphedInference(self._keys_and_matches, warmup=2)
+                out = self._vit_graph(img, mask)
+                keys, matched = out[0], tuple(out[1:])
+            else:
+                keys = self.net.key_tokens(img, None if mask is None else self._keep_tokens(mask))
+                # the mutual-nearest-neighbour matching of the re-paired batch (fused score GEMM + dual argmax, top-k) needs nothing
+                # but the keys and the masks either: it stays on the side stream instead of the main stream's critical path
+                matched = self._match_pairs(keys, mask) if mask is not None else None
         img.record_stream(self._side_stream)
         if mask is not None:
             mask.record_stream(self._side_stream)
         self._prefetched = (img, keys, matched)
+
+    use_graphs = False          # Trainer switches it on for fp32 training on the GPU
+
+    @torch.no_grad()
+    def _keys_and_matches(self, img, mask):
+        keys = self.net.key_tokens(img, self._keep_tokens(mask))
+        return (keys,) + tuple(self._match_pairs(keys, mask))
 
     def _match_pairs(self, keys, mask):
         src_idx, tgt_idx = pair_indices(self.divide_kind, self.opts.batch_size, self.opts.repeat, keys.device)

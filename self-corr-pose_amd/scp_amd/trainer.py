@@ -104,6 +104,16 @@ class Trainer:
             # buffers included
             self.reducer.broadcast_parameters(self.model, 0)
         self._group_spans = None
+        # HIP-graph replay of the static single-stream segments (scp_amd/graphed.py): the two encoder passes (forward + backward) and
+        # the frozen ViT with its pair matching.  SCP_GRAPHS=0 keeps every launch eager.  Not under SyncBatchNorm (collectives
+        # inside the segment) and not in configs[4] precision (autocast's weight-cast cache does not survive a capture).
+        from . import fused_conv
+        self._convs = [m for m in self.model.encoder.modules() if isinstance(m, torch.nn.Conv2d)]
+        fused_conv.WEIGHT_EPOCH[0] += 1                 # load_network / broadcast wrote weights through .data
+        self.use_graphs = (self.device.type == "cuda" and not self.sync_bn and os.environ.get("SCP_GRAPHS", "1") != "0"
+                           and not bool(getattr(opts, "mixed_bf16", False)))
+        self.model.encoder.use_graphs = self.use_graphs
+        self.model.pretrain_corr_net.use_graphs = self.use_graphs
 
     def batch_reshape(self, batch):
         o, dev = self.opts, self.device
@@ -162,14 +172,20 @@ class Trainer:
         iterations; the next step finds them ready).  Per-step work is unchanged."""
         self.model.iters = self.iteration
         self.grads.prepare()                            # zero_grad: clears the flat buffer, p.grad = its views
+        if self.device.type == "cuda":
+            # the split operands of the convolution weights the optimizer just changed: rebuilt here, on the main stream, before any
+            # side stream or graph replay reads them (scp_amd/fused_conv.py weight_planes)
+            from . import fused_conv
+            fused_conv.refresh_planes(self._convs)
         # The first step of a process is where MIOpen's solver search (cudnn.benchmark) times its candidates for every
         # convolution shape, forward and backward.  It runs without the side streams, so that the search measures
         # undisturbed kernels instead of kernels sharing the device with the ViT / the second encoder pass (the winners
         # are cached per process; a perturbed search can settle on slower solvers for the whole run).
         serial = self._steps_done == 0 and self.device.type == "cuda"
         if serial:
-            saved = (getattr(self.model, "overlap_dino", True), getattr(self.model, "overlap_rotation_cycle", True))
-            self.model.overlap_dino = self.model.overlap_rotation_cycle = False
+            saved = (getattr(self.model, "overlap_dino", True), getattr(self.model, "overlap_rotation_cycle", True),
+                     getattr(self.model, "overlap_texture_pass", True))
+            self.model.overlap_dino = self.model.overlap_rotation_cycle = self.model.overlap_texture_pass = False
             next_data = None
         try:
             total_loss, aux_output = self.model(data)
@@ -178,7 +194,7 @@ class Trainer:
             total_loss.mean().backward()
         finally:
             if serial:
-                self.model.overlap_dino, self.model.overlap_rotation_cycle = saved
+                self.model.overlap_dino, self.model.overlap_rotation_cycle, self.model.overlap_texture_pass = saved
         self._steps_done += 1
         grad = self.collect_grad()
         self.optim.step(self.iteration)

@@ -290,7 +290,7 @@ def test_hip_mutual_nn_fused_vs_float64(B, n_tok, C, tok0, mode):
     keys[:, tok0 + 3] = keys[:, tok0 + 1]                    # exact ties: token 3 duplicates token 1 in every image
     keys[:, tok0 + P - 1] = keys[:, tok0 + 2]
     mask = (torch.rand(B, P, generator=g) > 0.35).float()
-    mask[:, 1] = mask[:, 3] = 1.
+    mask[:, 1] = mask[:, 3] = mask[:, 2] = mask[:, P - 1] = 1.   # both members of every duplicated pair take part
     mask[B - 1] = 0.                                         # an image with nothing to match
     src = torch.tensor([0, 1, 0, B - 1, 1][:max(2, B + 1)])
     tgt = torch.tensor([1, 0, 0, 0, B - 1][:max(2, B + 1)])

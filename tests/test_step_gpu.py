@@ -37,10 +37,12 @@ def test_full_step_free_running_on_gpu():
     terms amplify that.  The allowed deviation per loss is NOT hand-picked: it is the spread the REFERENCE ITSELF shows
     when its own encoder outputs are perturbed at that level (tests/golden/step_conditioning_bottle_b2x2.npz, recorded by
     make_golden.py step_conditioning; see step_case.conditioning_band).  Terms the reference holds to 1e-4 under such
-    perturbations must meet north_star's 1e-4 here."""
+    perturbations must meet north_star's 1e-4 here.  (Round 3 asserted min(band, 3 x the largest deviation this build had shown so
+    far); that self-calibrated table is gone -- VERDICT r3 -- and tools/parity_sweep.py (profiles/r04_parity_sweep.txt) shows the
+    free-running deviations do not depend on which matrix cores the encoder / ViT run on.)"""
     import numpy as np
     model, data, d = step_case.build("cuda")
-    band, spread, sigmas = step_case.conditioning_band()
+    band, spread, sigmas = step_case.conditioning_band("step_conditioning_bottle_b2x2")
     cap = {}
     fwd = model.encoder.forward
 
@@ -49,19 +51,6 @@ def test_full_step_free_running_on_gpu():
         cap["enc"] = out
         return out
     model.encoder.forward = spy
-    # what is ASSERTED is tighter than the reference's own conditioning band wherever the observations allow: per term
-    # max(1e-4, 3 x the largest deviation observed on the MI355X so far), never wider than the band -- a 10x regression of a
-    # term fails.  Observations: round 2 (profiles/r02_ref_tests.txt) and round 3 (profiles/r03_step_tests.txt); the depth
-    # term (and the total with it) moves between boxes/processes with MIOpen's solver choice for the encoder (depth 5.2e-5 in
-    # round 2, 4.5e-4 in round 3: the sigma = gamma = 1e-4 silhouette amplification of SURVEY F12), so their caps stay the
-    # reference's own band.  The split main loops of round 3's second half round the same fp32 quantities differently again (the
-    # encoder's outputs still agree with the reference to <= 1e-6, printed below): the silhouette terms moved inside the
-    # reference's own spread -- mask 1.1e-5 -> 1.5e-4 (spread 2.7e-4), match 5.8e-6 -> 9.1e-5, texture 4.9e-5 -> 1.1e-4 -- and
-    # the table holds the largest value seen for each.
-    observed = {"total_loss": 1.03e-4, "mask_loss": 1.46e-4, "triangle_loss": 1.20e-6, "deform_loss": 1.09e-6, "pullfar_loss": 0.0,
-                "symmetry_loss": 5.92e-7, "match_loss": 9.11e-5, "texture_loss": 1.13e-4, "imatch_loss": 2.08e-6,
-                "cycle_loss_pretrain": 8.55e-8, "cycle_loss": 9.89e-8, "depth_loss": 5.42e-4}
-    asserted = {k: min(b, max(1e-4, 3.0 * observed.get(k, 0.0))) for k, b in band.items()}
     report = step_case.run_and_compare(model, data, d, rtol_loss=band, grad_rel_l2=0.1, grad_cos=0.995)
     # the premise of the band: the encoder's geometric outputs deviate from the reference's by no more than the
     # perturbation levels the fixture covers
@@ -69,13 +58,12 @@ def test_full_step_free_running_on_gpu():
         dev = np.abs(cap["enc"][j].detach().cpu().numpy().astype(np.float64) - d[key])
         print("encoder %-12s deviation from the reference: rms %.2e max %.2e" % (key, np.sqrt((dev ** 2).mean()), dev.max()))
         assert np.sqrt((dev ** 2).mean()) <= float(sigmas.max())
+    # the assertion itself is run_and_compare's (rtol_loss = the reference-recorded band, nothing derived from this build's own
+    # observations); the table is for the log
     for k, (got, ref) in report.items():
         if k in band:
-            print("%-22s rel dev %.2e | asserted %.2e | reference's own spread under perturbation %.2e"
-                  % (k, abs(got - ref) / max(abs(ref), 1e-12), asserted[k], spread[k]))
-    for k, (got, ref) in report.items():
-        if k in band:
-            assert abs(got - ref) <= asserted[k] * max(abs(ref), 1e-6), "%s: rel %.2e > %.2e" % (k, abs(got - ref) / max(abs(ref), 1e-6), asserted[k])
+            print("%-22s rel dev %.2e | band %.2e = max(1e-4, 1.5 x the reference's own spread under perturbation %.2e)"
+                  % (k, abs(got - ref) / max(abs(ref), 1e-12), band[k], spread[k]))
 
 
 def test_full_step_b8_laptop_vs_oracle_backend(monkeypatch):
@@ -134,7 +122,7 @@ def test_full_step_b8_laptop_vs_oracle_backend(monkeypatch):
     gpu.pretrain_corr_net.nn_override = tuple(t.cuda() for t in sel_nn)
     gpu.pretrain_corr_net.topk_override = sel_topk.cuda()
     got_aux, got_pose, got_grad = run(gpu, synth.make_batch(bs, rep, 256, seed=3, device="cuda"))
-    band, _, _ = step_case.conditioning_band()
+    band, _, _ = step_case.conditioning_band("step_conditioning_laptop_b2x4")     # recorded from the reference at this mesh / batch
     for k, ref in ref_aux.items():
         rel = abs(got_aux[k] - ref) / max(abs(ref), 1e-6)
         print("%-22s cpu-oracle %.9g gpu %.9g rel %.2e" % (k, ref, got_aux[k], rel))
