@@ -155,6 +155,14 @@ int scp_vit_linear(const float* A, const void* W, const float* vec0, const float
 int scp_vit_linear_rows(const float* A, const void* W, const float* vec0, const float* vec1, const float* rowstat,
                         const float* resid, float* C, const int* rows_dev, int max_rows, const int* a_rows, const int* c_rows,
                         int N, int K, int epilogue, void* stream);
+/* The same with pre-split operands on either side (round 4; SCP_GEMM_W_SPLIT3 only):
+ *   A_planes [3][a_rows_total][K] bf16 (A = h + m + l exactly) replaces A when non-NULL: the main loop then has no VALU split;
+ *   C_planes [3][c_rows_total][N] bf16 (N even) receives the epilogue's result split the same way -- the next layer's A_planes; C may
+ *   then be NULL (fc1: only the planes of GELU(.) are ever read).  rows_dev / max_rows / a_rows / c_rows as scp_vit_linear_rows
+ *   (rows_dev NULL: max_rows = M rows, all computed).  Row indices address planes and fp32 tensors alike. */
+int scp_vit_linear_planes(const float* A, const void* A_planes, int a_rows_total, const void* W, const float* vec0, const float* vec1,
+                          const float* rowstat, const float* resid, float* C, void* C_planes, int c_rows_total, const int* rows_dev,
+                          int max_rows, const int* a_rows, const int* c_rows, int N, int K, int epilogue, void* stream);
 /* planes[3][n] bf16 (h, m, l) with x[i] = h[i] + m[i] + l[i] exactly: the weight format of SCP_GEMM_W_SPLIT3 */
 int scp_split_bf16x3(const float* x, void* planes, size_t n, void* stream);
 /* stats[rows,2] = (mean, 1/sqrt(biased var + eps)) of every row of x[rows,C] (nn.LayerNorm's statistics), C <= 1536 */

@@ -43,6 +43,7 @@ __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8
 template <int WM_, int WN_, int NWM_, int NWN_, int NSTAGE_, int MINBLK_>
 struct GemmCfg {
     static constexpr int WM = WM_, WN = WN_, NWM = NWM_, NWN = NWN_, NSTAGE = NSTAGE_, MINBLK = MINBLK_;
+    static constexpr bool APLANES = false;                                        // (csrc/gemm_core_split.h: pre-split A operand)
     static constexpr int BM = 32 * WM * NWM, BN = 32 * WN * NWN, BK = 16;
     static constexpr int NW = NWM * NWN, THREADS = 64 * NW;
     static constexpr int A_PIECES = BM / 16, W_PIECES = BN / 16;                  // 1-KiB LDS-DMA instructions per chunk

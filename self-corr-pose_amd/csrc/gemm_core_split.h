@@ -25,6 +25,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "gemm_core.h"
 
 namespace scp {
@@ -37,19 +39,25 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 // ZSTART: the six partial products of a chunk are summed in a chunk-local accumulator that starts at zero and is added to the
 // running accumulator by the VALU (see compute()); needs 16 WN more VGPRs, which the 4 x 2-tile wavefronts of the ViT's 256 x 128
 // tile do not have while their A operand is still split in registers.
-template <int WM_, int WN_, int NWM_, int NWN_, int MINBLK_, int NPLANES_ = 3, bool ZSTART_ = (WM_ * WN_ <= 4)>
+// APLANES (round 4): the A operand arrives PRE-SPLIT as three bf16 planes [3][rows][K] like W (written once by the epilogue of the
+// kernel that produced it: csrc/vit_gemm.hip), moved by the same LDS-DMA -- the main loop is then DMA -> ds_read -> MFMA with no
+// VALU split at all (the in-register split cost 5.4 VALU instructions per MFMA and was redone by every column block that read the
+// same A rows: 9x for the qkv projection).
+template <int WM_, int WN_, int NWM_, int NWN_, int MINBLK_, int NPLANES_ = 3, bool ZSTART_ = (WM_ * WN_ <= 4), bool APLANES_ = false>
 struct SplitCfg {
     static constexpr int NPLANES = NPLANES_;
-    static constexpr bool ZSTART = ZSTART_;
+    static constexpr bool ZSTART = ZSTART_, APLANES = APLANES_;
     static constexpr int WM = WM_, WN = WN_, NWM = NWM_, NWN = NWN_, NSTAGE = 2, MINBLK = MINBLK_;
     static constexpr int BM = 32 * WM * NWM, BN = 32 * WN * NWN, BK = 16;
     static constexpr int NW = NWM * NWN, THREADS = 64 * NW;
-    static constexpr int A_PIECES = BM / 16;                  // 16 rows x 64 B
+    static constexpr int A_GROUPS = BM / 32;
+    static constexpr int A_PIECES = APLANES ? NPLANES * A_GROUPS : BM / 16;   // planes: 32 rows x 32 B; fp32: 16 rows x 64 B
     static constexpr int W_GROUPS = BN / 32, W_PIECES = NPLANES * W_GROUPS;   // 32 rows x 32 B per plane
-    static_assert(A_PIECES % NW == 0, "A pieces are dealt evenly to the wavefronts");
-    // W piece q goes to wavefront q % NW (its (q / NW)-th); with BN = 64 the six pieces leave two wavefronts with one only
-    static constexpr int A_PER = A_PIECES / NW, W_PER = (W_PIECES + NW - 1) / NW;
-    static constexpr int A_BYTES = BM * 64, PLANE_BYTES = BN * 32;
+    static_assert(APLANES || A_PIECES % NW == 0, "fp32 A pieces are dealt evenly to the wavefronts");
+    // piece q goes to wavefront q % NW (its (q / NW)-th); a count that NW does not divide leaves some wavefronts one piece short
+    static constexpr int A_PER = (A_PIECES + NW - 1) / NW, W_PER = (W_PIECES + NW - 1) / NW;
+    static constexpr int A_PLANE_BYTES = BM * 32;
+    static constexpr int A_BYTES = APLANES ? NPLANES * A_PLANE_BYTES : BM * 64, PLANE_BYTES = BN * 32;
     static constexpr int STAGE_BYTES = A_BYTES + NPLANES * PLANE_BYTES, LDS_BYTES = NSTAGE * STAGE_BYTES;
     static constexpr int NT = WM * WN;
 };
@@ -103,7 +111,31 @@ struct LinearASource {
     }
 };
 
-template <class CFG, class ASRC = LinearASource<CFG>>
+// A-tile source for pre-split operands: planes [NPLANES][rows_total][K] bf16; piece q = (plane q / A_GROUPS, 32 rows of group
+// q % A_GROUPS), dealt to wavefront q % NW; slot s of row r lands at s ^ ((r >> 3) & 1) like W's
+template <class CFG>
+struct PlanesASource {
+    const char* a_base;
+    unsigned a_off[CFG::A_PER];
+    template <class FA>
+    __device__ __forceinline__ void set_rows(const void* A3, int rows_total, int K, int wave, int lane, FA a_row) {
+        a_base = reinterpret_cast<const char*>(A3);
+        const int prow = lane >> 1, pslot = lane & 1;
+#pragma unroll
+        for (int i = 0; i < CFG::A_PER; i++) {
+            const int q = min(wave + CFG::NW * i, CFG::A_PIECES - 1), plane = q / CFG::A_GROUPS, r = 32 * (q % CFG::A_GROUPS) + prow;
+            const int slot = pslot ^ ((r >> 3) & 1);
+            a_off[i] = ((unsigned)plane * (unsigned)rows_total * (unsigned)K + (unsigned)a_row(r) * (unsigned)K + 8u * slot) * 2u;
+        }
+    }
+    template <int I>
+    __device__ __forceinline__ void issue(int kc, unsigned stage_lds, int wave) const {
+        if ((I + 1) * CFG::NW <= CFG::A_PIECES || wave + CFG::NW * I < CFG::A_PIECES)          // wavefront-uniform
+            glds16(a_off[I], a_base + (size_t)kc * 32, stage_lds + (unsigned)(wave + CFG::NW * I) * 1024u);
+    }
+};
+
+template <class CFG, class ASRC = std::conditional_t<CFG::APLANES, PlanesASource<CFG>, LinearASource<CFG>>>
 struct SplitGemmCore {
     struct Acc { f32x16 t[CFG::NT]; };
 
@@ -123,8 +155,12 @@ struct SplitGemmCore {
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const int half = lane >> 5, l31 = lane & 31;
         const int ra = row_base() + l31, rw = col_base() + l31;
+        if constexpr (CFG::APLANES) {
+            a_rd[0] = a_rd[1] = ra * 32 + 16 * (half ^ ((ra >> 3) & 1));
+        } else {
 #pragma unroll
-        for (int c = 0; c < 2; c++) a_rd[c] = ra * 64 + 16 * ((2 * half + c) ^ ((ra >> 2) & 3));
+            for (int c = 0; c < 2; c++) a_rd[c] = ra * 64 + 16 * ((2 * half + c) ^ ((ra >> 2) & 3));
+        }
         w_rd = CFG::A_BYTES + rw * 32 + 16 * (half ^ ((rw >> 3) & 1));
     }
     __device__ __forceinline__ int row_base() const { return 32 * CFG::WM * (wave / CFG::NWN); }
@@ -145,11 +181,19 @@ struct SplitGemmCore {
     // the interface gemm_core.h's GemmCore shares (vit_gemm.hip picks a core per launch): A [M,K] fp32 row-major
     template <class FA, class FW>
     __device__ __forceinline__ void set_rows(const float* A, const void* W3, int N, int K, FA a_row, FW w_row) {
+        static_assert(!CFG::APLANES, "planes A: use set_rows_planes");
         asrc.set_rows(A, K, wave, lane, a_row);
         set_w_rows(W3, N, K, w_row);
     }
+    // pre-split A: planes [NPLANES][a_rows_total][K]
+    template <class FA, class FW>
+    __device__ __forceinline__ void set_rows_planes(const void* A3, int a_rows_total, const void* W3, int N, int K, FA a_row, FW w_row) {
+        static_assert(CFG::APLANES, "fp32 A: use set_rows");
+        asrc.set_rows(A3, a_rows_total, K, wave, lane, a_row);
+        set_w_rows(W3, N, K, w_row);
+    }
     __device__ __forceinline__ void set_linear_sources(const float* A, const void* W3, int m0, int n0, int M, int N, int K) {
-        set_rows(A, W3, N, K, [&](int r) { return min(m0 + r, M - 1); }, [&](int r) { return min(n0 + r, N - 1); });
+        if constexpr (!CFG::APLANES) set_rows(A, W3, N, K, [&](int r) { return min(m0 + r, M - 1); }, [&](int r) { return min(n0 + r, N - 1); });
     }
 
     __device__ __forceinline__ void issue(int kc, int stage) const {
@@ -163,8 +207,60 @@ struct SplitGemmCore {
         });
     }
 
+    // chunk compute for pre-split A with zero-started chunk accumulators, scheduled by hand at statement level: the A fragments of
+    // row tile i + 1 are read while tile i's MFMAs run (two fragment sets), a tile's twelve MFMAs form two interleaved chains on its
+    // chunk accumulators c[0], c[1], the VALU folds them into the running accumulator right after (pinned there by the empty asm and
+    // the scheduling barrier: the compiler otherwise keeps one chunk accumulator pair per row tile alive and spills)
+    template <int S>
+    __device__ __forceinline__ void compute_planes(Acc& acc) const {
+        const char* st = lds + S * CFG::STAGE_BYTES;
+        bf16x8 wf[3][CFG::WN];
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int j = 0; j < CFG::WN; j++) wf[p][j] = *reinterpret_cast<const bf16x8*>(st + w_rd + p * CFG::PLANE_BYTES + j * 1024);
+        bf16x8 af[2][3];
+        auto load_a = [&](int i, bf16x8 (&f)[3]) {
+#pragma unroll
+            for (int p = 0; p < 3; p++) f[p] = *reinterpret_cast<const bf16x8*>(st + a_rd[0] + p * CFG::A_PLANE_BYTES + i * 1024);
+        };
+        load_a(0, af[0]);
+        static_for<0, CFG::WM>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            if constexpr (i + 1 < CFG::WM) load_a(i + 1, af[(i + 1) & 1]);
+            const bf16x8 &ah = af[i & 1][0], &am = af[i & 1][1], &al = af[i & 1][2];
+            f32x16 c[CFG::WN];
+#pragma unroll
+            for (int j = 0; j < CFG::WN; j++) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; r++) z[r] = 0.f;
+                c[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wf[1][j], z, 0, 0, 0);
+            }
+            auto mac = [&](const bf16x8& av, int p) {
+#pragma unroll
+                for (int j = 0; j < CFG::WN; j++) c[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wf[p][j], c[j], 0, 0, 0);
+            };
+            mac(al, 0);
+            mac(ah, 2);
+            mac(am, 0);
+            mac(ah, 1);
+            mac(ah, 0);
+#pragma unroll
+            for (int j = 0; j < CFG::WN; j++) {
+                acc.t[i * CFG::WN + j] += c[j];
+                asm volatile("" : "+v"(acc.t[i * CFG::WN + j]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+
     template <int S>
     __device__ __forceinline__ void compute(Acc& acc) const {
+        if constexpr (CFG::APLANES && CFG::ZSTART && CFG::NPLANES == 3) {
+            compute_planes<S>(acc);
+            return;
+        }
         const char* st = lds + S * CFG::STAGE_BYTES;
         bf16x8 wf[CFG::NPLANES][CFG::WN];
 #pragma unroll
@@ -173,17 +269,26 @@ struct SplitGemmCore {
             for (int j = 0; j < CFG::WN; j++) wf[p][j] = *reinterpret_cast<const bf16x8*>(st + w_rd + p * CFG::PLANE_BYTES + j * 1024);
 #pragma unroll
         for (int i = 0; i < CFG::WM; i++) {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(st + a_rd[0] + i * 2048);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(st + a_rd[1] + i * 2048);
-            const f32x8 x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            Split3 a;
+            if constexpr (CFG::APLANES) {
+                a.h = *reinterpret_cast<const bf16x8*>(st + a_rd[0] + i * 1024);
+                if constexpr (CFG::NPLANES == 3) {
+                    a.m = *reinterpret_cast<const bf16x8*>(st + a_rd[0] + CFG::A_PLANE_BYTES + i * 1024);
+                    a.l = *reinterpret_cast<const bf16x8*>(st + a_rd[0] + 2 * CFG::A_PLANE_BYTES + i * 1024);
+                }
+            } else {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(st + a_rd[0] + i * 2048);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(st + a_rd[1] + i * 2048);
+                const f32x8 x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if constexpr (CFG::NPLANES == 1) a.h = __builtin_convertvector(x, bf16x8);
+                else a = split3(x);
+            }
             if constexpr (CFG::NPLANES == 1) {
-                const bf16x8 ah = __builtin_convertvector(x, bf16x8);
 #pragma unroll
                 for (int j = 0; j < CFG::WN; j++)
-                    acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wf[0][j], acc.t[i * CFG::WN + j], 0, 0, 0);
+                    acc.t[i * CFG::WN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, wf[0][j], acc.t[i * CFG::WN + j], 0, 0, 0);
                 continue;
             }
-            const Split3 a = split3(x);
             if constexpr (CFG::NPLANES == 3 && !CFG::ZSTART) {
                 // smallest terms first; six products per accumulator tile, tiles interleaved so that consecutive MFMAs are independent
                 auto mac = [&](const bf16x8& av, int p) {

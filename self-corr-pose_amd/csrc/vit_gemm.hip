@@ -55,13 +55,22 @@ using QtrSplit = scp::SplitCfg<1, 2, 2, 2, 2>;      //  64 x 128
 // ... and with operands rounded to bf16, one product (SCP_GEMM_W_BF16: BASELINE configs[4] precision; W = one bf16 plane)
 using BigBf16 = scp::SplitCfg<4, 2, 2, 2, 2, 1>;
 using QtrBf16 = scp::SplitCfg<1, 2, 2, 2, 2, 1>;
+// ... and with the A operand PRE-SPLIT by the producing kernel's epilogue (round 4): three bf16 planes [3][M][K] moved by LDS-DMA
+// like W, no VALU in the main loop; the six products of a chunk are summed in a zero-started accumulator (SplitCfg::ZSTART)
+using BigPlanes = scp::SplitCfg<4, 2, 2, 2, 2, 3, true, true>;     // 256 x 128, 2-stage ring = 72 KiB
+using QtrPlanes = scp::SplitCfg<1, 2, 2, 2, 2, 3, true, true>;
 constexpr int THREADS = 256;
 constexpr int BN = 128, QM = 64;                    // column block; row quarter
 static_assert(BigCfg::BN == BN && QtrCfg::BN == BN && BigCfg::BM == 4 * QM && QtrCfg::BM == QM, "tile shapes");
 static_assert(BigSplit::BN == BN && QtrSplit::BN == BN && BigSplit::BM == 4 * QM && QtrSplit::BM == QM, "tile shapes");
 static_assert(BigSplit::THREADS == THREADS && BigCfg::THREADS == THREADS, "one block size");
+static_assert(BigPlanes::BN == BN && QtrPlanes::BN == BN && BigPlanes::BM == 4 * QM && QtrPlanes::BM == QM, "tile shapes");
 
 struct GemmArgs {
+    const void* A3;        // CORE 3: the A operand as bf16 planes [3][a_rows_total][K] (A is then unused)
+    int a_rows_total;
+    __bf16* C3;            // optional: the result ALSO (or, with C == nullptr, ONLY) as bf16 planes [3][c_rows_total][N] -- the next
+    int c_rows_total;      // kernel's pre-split A operand
     const float* A;        // [M, K]
     const void* W;         // [N, K] fp32, or the planes [3][N][K] bf16 of the split path
     const float* vec0;     // EPI_LN*: s[N]            EPI_BIAS*: bias[N]
@@ -124,13 +133,13 @@ __device__ __forceinline__ int xcd_order(int t, int n) {
 template <class CFG, class Core, int EPI, bool INDEXED>
 __device__ __forceinline__ void run_tile(const GemmArgs& g, float* lds, int M, int m0, int n0) {
     Core core(lds);
-    core.set_rows(
-        g.A, g.W, g.N, g.K,
-        [&](int r) {
-            const int m = min(m0 + r, M - 1);
-            return (INDEXED && g.a_rows) ? g.a_rows[m] : m;
-        },
-        [&](int r) { return min(n0 + r, g.N - 1); });
+    auto a_row = [&](int r) {
+        const int m = min(m0 + r, M - 1);
+        return (INDEXED && g.a_rows) ? g.a_rows[m] : m;
+    };
+    auto w_row = [&](int r) { return min(n0 + r, g.N - 1); };
+    if constexpr (CFG::APLANES) core.set_rows_planes(g.A3, g.a_rows_total, g.W, g.N, g.K, a_row, w_row);
+    else core.set_rows(g.A, g.W, g.N, g.K, a_row, w_row);
     typename Core::Acc acc;
     core.run(acc, g.K / CFG::BK);
 
@@ -171,6 +180,7 @@ __device__ __forceinline__ void run_tile(const GemmArgs& g, float* lds, int M, i
 #pragma unroll
                 for (int r = 0; r < 16; r++) res[r] = g.resid[(size_t)orow(r) * g.N + nc];
             }
+            scp::f32x8 xv[2];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = mb + scp::acc_row(r, half);
@@ -182,17 +192,49 @@ __device__ __forceinline__ void run_tile(const GemmArgs& g, float* lds, int M, i
                     x += v0;
                     if (EPI == SCP_GEMM_BIAS_RESIDUAL) x += res[r];
                 }
-                if (m < M && n_ok) g.C[(size_t)orow(r) * g.N + n] = x;
+                if (g.C && m < M && n_ok) g.C[(size_t)orow(r) * g.N + n] = x;
+                xv[r >> 3][r & 7] = x;
+            }
+            if (g.C3) {
+                // the result as three bf16 planes (x = h + m + l exactly), the pre-split A operand of the next GEMM.  A lane holds
+                // ONE column: rows are taken in pairs (r, r + 1), split together (packed bf16 pairs), and exchanged with the
+                // neighbouring column's lane so that even lanes store row r's pair (n, n + 1) and odd lanes row r + 1's pair
+                // (n - 1, n): dword stores, 64 B contiguous per row and half-wavefront.
+                const bool odd = l31 & 1;
+                const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+                const size_t plane = (size_t)g.c_rows_total * g.N;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const scp::Split3 sp = scp::split3(xv[q]);
+                    const scp::u32x4 ph = __builtin_bit_cast(scp::u32x4, sp.h), pm = __builtin_bit_cast(scp::u32x4, sp.m),
+                                     pl = __builtin_bit_cast(scp::u32x4, sp.l);
+#pragma unroll
+                    for (int pr = 0; pr < 4; pr++) {
+                        const int r = 8 * q + 2 * pr + (odd ? 1 : 0);
+                        const int m = mb + scp::acc_row(r, half);
+                        __bf16* dst = g.C3 + (size_t)orow(r) * g.N + (n - (odd ? 1 : 0));
+                        const bool ok = m < M && n_ok;
+                        auto put = [&](unsigned own, __bf16* at) {
+                            const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xF, 0xF, true);
+                            const unsigned v = __builtin_amdgcn_perm(nb, own, sel);
+                            if (ok) *reinterpret_cast<unsigned*>(at) = v;
+                        };
+                        put(ph[pr], dst);
+                        put(pm[pr], dst + plane);
+                        put(pl[pr], dst + 2 * plane);
+                    }
+                }
             }
         }
     }
 }
 
-// CORE: 0 = fp32 matrix cores, 1 = bf16 cores on exactly split operands, 2 = bf16 cores on rounded operands
+// CORE: 0 = fp32 matrix cores, 1 = bf16 cores on exactly split operands (A split in registers), 2 = bf16 cores on rounded operands,
+// 3 = bf16 cores on exactly split operands, A pre-split (planes)
 template <int EPI, bool INDEXED, int CORE>
 __global__ __launch_bounds__(THREADS, 2) void vit_gemm_kernel(const GemmArgs g) {
-    using Big = std::conditional_t<CORE == 1, BigSplit, std::conditional_t<CORE == 2, BigBf16, BigCfg>>;
-    using Qtr = std::conditional_t<CORE == 1, QtrSplit, std::conditional_t<CORE == 2, QtrBf16, QtrCfg>>;
+    using Big = std::conditional_t<CORE == 1, BigSplit, std::conditional_t<CORE == 2, BigBf16, std::conditional_t<CORE == 3, BigPlanes, BigCfg>>>;
+    using Qtr = std::conditional_t<CORE == 1, QtrSplit, std::conditional_t<CORE == 2, QtrBf16, std::conditional_t<CORE == 3, QtrPlanes, QtrCfg>>>;
     using BigCore = std::conditional_t<CORE == 0, scp::GemmCore<BigCfg>, scp::SplitGemmCore<Big>>;
     using QtrCore = std::conditional_t<CORE == 0, scp::GemmCore<QtrCfg>, scp::SplitGemmCore<Qtr>>;
     __shared__ __attribute__((aligned(16))) float lds[Big::LDS_BYTES / 4];
@@ -377,26 +419,34 @@ int dispatch(const GemmArgs& g, int epilogue, hipStream_t st) {
 }
 
 int vit_linear_impl(const float* A, const void* W, const float* vec0, const float* vec1, const float* rowstat, const float* resid,
-                    float* C, int M, const int* m_dev, const int* a_rows, const int* c_rows, int N, int K, int epilogue, void* stream) {
+                    float* C, int M, const int* m_dev, const int* a_rows, const int* c_rows, int N, int K, int epilogue, void* stream,
+                    const void* A3 = nullptr, int a_rows_total = 0, void* C3 = nullptr, int c_rows_total = 0) {
     if (M <= 0 || N <= 0 || K <= 0) return scp::fail(hipErrorInvalidValue, "vit_linear: empty problem");
+    if (!A && !A3) return scp::fail(hipErrorInvalidValue, "vit_linear: no A operand");
+    if (!C && !C3) return scp::fail(hipErrorInvalidValue, "vit_linear: no output");
+    if (A3 && (a_rows_total < M || 3 * (size_t)a_rows_total * (size_t)K >= (1ull << 31)))
+        return scp::fail(hipErrorInvalidValue, "vit_linear: A planes smaller than M rows or larger than 2^32 bytes");
+    if (C3 && (c_rows_total < M || (N & 1))) return scp::fail(hipErrorInvalidValue, "vit_linear: output planes need c_rows_total >= M and an even N");
     if (K % (BigCfg::NSTAGE * BigCfg::BK) != 0) return scp::fail(hipErrorInvalidValue, "vit_linear: K must be a multiple of 32");
     if ((size_t)M * (size_t)K >= (1ull << 30) || (size_t)N * (size_t)K >= (1ull << 30))
         return scp::fail(hipErrorInvalidValue, "vit_linear: operand larger than 2^30 elements");
     const bool split = (epilogue & SCP_GEMM_W_SPLIT3) != 0, bf16 = (epilogue & SCP_GEMM_W_BF16) != 0;
     epilogue &= ~(SCP_GEMM_W_SPLIT3 | SCP_GEMM_W_BF16);
     if (split && bf16) return scp::fail(hipErrorInvalidValue, "vit_linear: SCP_GEMM_W_SPLIT3 and SCP_GEMM_W_BF16 exclude each other");
+    if (A3 && !split) return scp::fail(hipErrorInvalidValue, "vit_linear: A planes need the split weight planes (SCP_GEMM_W_SPLIT3)");
     if (split && 3 * (size_t)N * (size_t)K >= (1ull << 31)) return scp::fail(hipErrorInvalidValue, "vit_linear: split weight larger than 2^32 bytes");
     const bool ln = epilogue == SCP_GEMM_LN || epilogue == SCP_GEMM_LN_GELU;
     if (!vec0 || (ln && (!vec1 || !rowstat)) || (epilogue == SCP_GEMM_BIAS_RESIDUAL && !resid))
         return scp::fail(hipErrorInvalidValue, "vit_linear: missing epilogue operand");
     GemmArgs g{};
     g.A = A; g.W = W; g.vec0 = vec0; g.vec1 = vec1; g.rowstat = rowstat; g.resid = resid; g.C = C;
+    g.A3 = A3; g.a_rows_total = a_rows_total; g.C3 = static_cast<__bf16*>(C3); g.c_rows_total = c_rows_total;
     g.M = M; g.N = N; g.K = K; g.m_dev = m_dev; g.a_rows = a_rows; g.c_rows = c_rows;
     g.nblk_n = (N + BN - 1) / BN;
     g.slots = device_slots();
     g.clock = (g_clock_slots && g_clock_i < g_clock_n) ? g_clock_slots + 2 * (g_clock_i++) : nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int bad = split ? dispatch<1>(g, epilogue, st) : bf16 ? dispatch<2>(g, epilogue, st) : dispatch<0>(g, epilogue, st);
+    const int bad = (split && A3) ? dispatch<3>(g, epilogue, st) : split ? dispatch<1>(g, epilogue, st) : bf16 ? dispatch<2>(g, epilogue, st) : dispatch<0>(g, epilogue, st);
     if (bad) return bad;
     return scp::check_launch("vit_linear");
 }
@@ -412,6 +462,13 @@ extern "C" int scp_vit_linear_rows(const float* A, const void* W, const float* v
                                    const int* c_rows, int N, int K, int epilogue, void* stream) {
     if (!rows_dev) return scp::fail(hipErrorInvalidValue, "vit_linear_rows: null row count");
     return vit_linear_impl(A, W, vec0, vec1, rowstat, resid, C, max_rows, rows_dev, a_rows, c_rows, N, K, epilogue, stream);
+}
+
+extern "C" int scp_vit_linear_planes(const float* A, const void* A_planes, int a_rows_total, const void* W, const float* vec0, const float* vec1,
+                                     const float* rowstat, const float* resid, float* C, void* C_planes, int c_rows_total, const int* rows_dev,
+                                     int max_rows, const int* a_rows, const int* c_rows, int N, int K, int epilogue, void* stream) {
+    return vit_linear_impl(A, W, vec0, vec1, rowstat, resid, C, max_rows, rows_dev, a_rows, c_rows, N, K, epilogue, stream, A_planes, a_rows_total,
+                           C_planes, c_rows_total);
 }
 
 extern "C" int scp_row_mean_rstd(const float* x, float* stats, int rows, int C, float eps, void* stream) {

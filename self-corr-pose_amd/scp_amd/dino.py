@@ -180,6 +180,9 @@ GEMM_W_SPLIT3, GEMM_W_BF16 = 0x100, 0x200                                # inclu
 # accumulation -- csrc/gemm_core_split.h; as close to float64 as the fp32 matrix cores, ~1.5x their rate).
 # "fp32": v_mfma_f32_32x32x2_f32.  SCP_VIT_GEMM=fp32 in the environment selects the latter for a whole process.
 GEMM_MODE = os.environ.get("SCP_VIT_GEMM", "split")
+# split mode: activations reach the next GEMM pre-split (bf16 planes written by the producing epilogue; csrc/vit_gemm.hip CORE 3).
+# SCP_VIT_PRESPLIT=0: every GEMM splits its fp32 A operand in registers, as in round 3 (A/B switch).
+PRESPLIT_ACTIVATIONS = os.environ.get("SCP_VIT_PRESPLIT", "1") == "1"
 
 
 def split_weight(w):
@@ -194,21 +197,27 @@ def split_weight(w):
 
 
 def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilogue=GEMM_BIAS, rows=None, a_rows=None, c_rows=None,
-               max_rows=None, mode=None, w_split=None):
+               max_rows=None, mode=None, w_split=None, a_planes=None, out_planes=None, fp32_out=True):
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T) on the matrix cores (csrc/vit_gemm.hip, include/scp_hip.h scp_vit_linear);
     `resid` may be `out` itself (in-place residual stream).  Forward only, GPU tensors only.  `mode` (default GEMM_MODE):
     "split" = bf16 matrix cores on exactly split operands (`w_split` = split_weight(w) if the caller keeps it), "fp32" = fp32
     matrix cores; both are fp32-accurate.
     Row selection made on the device (scp_vit_linear_rows): `rows` = int32 device scalar, only the first rows[0] GEMM rows
     are computed and the host never reads the count; GEMM row m reads a[a_rows[m]] and uses rowstat / resid / out row
-    c_rows[m] (int32 index lists, None = identity); untouched rows of `out` keep their contents."""
+    c_rows[m] (int32 index lists, None = identity); untouched rows of `out` keep their contents.
+    Pre-split operands (split mode only, scp_vit_linear_planes): `a_planes` [3, rows, K] bfloat16 = the A operand as the producing
+    layer's epilogue left it (`a` may then be None; the main loop has no VALU split); `out_planes` [3, rows, N] bfloat16 receives the
+    result split the same way (the next layer's a_planes); `fp32_out=False` with out_planes: the fp32 result is not stored at all."""
     from . import capi
-    if torch.is_grad_enabled() and (a.requires_grad or w.requires_grad):
+    if torch.is_grad_enabled() and ((a is not None and a.requires_grad) or w.requires_grad):
         raise RuntimeError("scp_amd.dino.vit_linear is forward-only (frozen ViT)")
-    m, k = a.shape
+    if a is None and a_planes is None:
+        raise RuntimeError("vit_linear: no A operand")
+    m, k = a.shape if a is not None else a_planes.shape[1:]
     n = w.shape[0]
-    if out is None:
-        out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    dev = a.device if a is not None else a_planes.device
+    if out is None and (fp32_out or out_planes is None):
+        out = torch.empty(m, n, dtype=torch.float32, device=dev)
     L = capi.lib()
     mode = gemm_mode() if mode is None else mode
     if mode == "bf16":
@@ -230,6 +239,26 @@ def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilog
         w_ptr = capi.dev_ptr(w, "w")
     else:
         raise RuntimeError("vit_linear: unknown mode %r" % (mode,))
+    if a_planes is not None or out_planes is not None:
+        if mode != "split":
+            raise RuntimeError("vit_linear: operand planes need the split main loop (mode %r)" % (mode,))
+        for t, name, cols in ((a_planes, "a_planes", k), (out_planes, "out_planes", n)):
+            if t is not None and not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.dim() == 3 and t.shape[0] == 3
+                                      and t.shape[2] == cols):
+                raise RuntimeError("vit_linear: %s must be a contiguous [3, rows, %d] bfloat16 tensor" % (name, cols))
+        for t, name in ((rows, "rows"), (a_rows, "a_rows"), (c_rows, "c_rows")):
+            if t is not None and not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+                raise RuntimeError("vit_linear: %s must be a contiguous int32 device tensor" % name)
+        ip = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+        if rows is not None and max_rows is None:
+            max_rows = m
+        code = L.scp_vit_linear_planes(ip(a if a_planes is None else None), ip(a_planes), 0 if a_planes is None else a_planes.shape[1], w_ptr,
+                                       capi.dev_ptr(vec0, "vec0"), capi.opt_ptr(vec1, "vec1"), capi.opt_ptr(rowstat, "rowstat"),
+                                       capi.opt_ptr(resid, "resid"), ip(out), ip(out_planes),
+                                       0 if out_planes is None else out_planes.shape[1], ip(rows), m if rows is None else max_rows,
+                                       ip(a_rows), ip(c_rows), n, k, epilogue, capi.current_stream())
+        capi.check(code, "scp_vit_linear_planes")
+        return out
     if rows is None:
         code = L.scp_vit_linear(capi.dev_ptr(a, "a"), w_ptr, capi.dev_ptr(vec0, "vec0"),
                                 capi.opt_ptr(vec1, "vec1"), capi.opt_ptr(rowstat, "rowstat"),
@@ -309,31 +338,49 @@ class _Block(nn.Module):
             self._fold_key = key
         return self._fold
 
-    def forward_fused(self, x2d, b, n):
+    def forward_fused(self, x2d, b, n, x3=None):
         """x2d [b*n, dim] residual stream, updated IN PLACE:  x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x)))
-        (vision_transformer_flexible.py:126-132)."""
+        (vision_transformer_flexible.py:126-132).
+        x3 (split mode): the bf16 planes [3, b*n, dim] of x2d (x = h + m + l exactly), kept in step with it: every GEMM that
+        consumes the residual stream or the MLP's hidden activation reads its A operand pre-split (no VALU split in its main loop),
+        and the epilogues that produce them -- proj + residual, fc1 + GELU, fc2 + residual -- write the planes once (the hidden
+        activation exists ONLY as planes)."""
         (wq, sq, tq), (w1, s1, t1) = self._folded()
         a = self.attn
         sp = self._planes
-        qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN, w_split=sp["qkv"])
+        pl = x3 is not None and gemm_mode() == "split"
+        qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN, w_split=sp["qkv"],
+                         a_planes=x3 if pl else None)
         y = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, x2d.shape[1] // a.num_heads, a.scale)
-        vit_linear(y.view(b * n, -1), a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["proj"])
+        vit_linear(y.view(b * n, -1), a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["proj"],
+                   out_planes=x3 if pl else None)
+        if pl:
+            h3 = torch.empty(3, b * n, w1.shape[0], dtype=torch.bfloat16, device=x2d.device)
+            vit_linear(None, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), epilogue=GEMM_LN_GELU, w_split=sp["fc1"], a_planes=x3,
+                       out_planes=h3, fp32_out=False)
+            vit_linear(None, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["fc2"],
+                       a_planes=h3, out_planes=x3)
+            return x2d
         h = vit_linear(x2d, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), epilogue=GEMM_LN_GELU, w_split=sp["fc1"])
         vit_linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["fc2"])
         return x2d
 
-    def tail_keys_fused(self, x2d, b, n, keep, key_block):
+    def tail_keys_fused(self, x2d, b, n, keep, key_block, x3=None):
         """The last block before the key layer, and the keys themselves, for the tokens in `keep` only (bool [b, n]):
         after this block's attention nothing mixes tokens any more, so proj / MLP of this block and LN1 + K of `key_block`
         are needed only for the tokens whose keys are consumed (pretrained_corr.py:85-89 masks every other token out of the
         matching).  The QKV projection still runs on all tokens (keys / values of every token feed the kept queries); the
         attention runs for the kept queries only.  The GEMMs take their row count and row index list from the device, and the
-        keys of all other tokens are returned as zeros.  Same values for the kept tokens as the full path (row-wise identical GEMMs)."""
+        keys of all other tokens are returned as zeros.  Same values for the kept tokens as the full path (row-wise identical GEMMs).
+        Returns the keys token-major: [b, n, heads * d]; with `x3` (the residual stream's bf16 planes, see forward_fused) the keys'
+        own planes ride along as `._scp_planes` -- the pre-split W operand of the mutual-nearest-neighbour kernel."""
         (wq, sq, tq), (w1, s1, t1) = self._folded()
         a = self.attn
         c = x2d.shape[1]
         sp = self._planes
-        qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN, w_split=sp["qkv"])
+        pl = x3 is not None and gemm_mode() == "split"
+        qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN, w_split=sp["qkv"],
+                         a_planes=x3 if pl else None)
         # attention: keys / values of all tokens, queries only for the kept ones (per image, compacted to the front of the
         # query slots; their outputs land on their own rows)
         k8 = keep.to(torch.uint8)
@@ -344,29 +391,44 @@ class _Block(nn.Module):
         idx = torch.argsort(flat.to(torch.uint8), descending=True, stable=True).to(torch.int32)   # kept rows first, original order
         rows = flat.sum(dtype=torch.int32).reshape(1)
         m = b * n
-        sel = dict(rows=rows, max_rows=m)
+        sel = dict(rows=rows, max_rows=m, a_rows=idx, c_rows=idx)
         # x[idx] += proj(y[idx]);  h = gelu(fc1(LN2 x[idx]));  x[idx] += fc2(h);  k[idx] = Wk LN1(x[idx]) -- rows addressed
         # through the index list inside the GEMM (no gather / scatter copies); statistics are taken for all rows (11 us)
-        vit_linear(y, a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, a_rows=idx, c_rows=idx,
-                   w_split=sp["proj"], **sel)
-        h = torch.empty(m, w1.shape[0], dtype=torch.float32, device=x2d.device)           # only the kept rows are written / read
-        vit_linear(x2d, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), out=h, epilogue=GEMM_LN_GELU, a_rows=idx, c_rows=idx,
-                   w_split=sp["fc1"], **sel)
-        vit_linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, a_rows=idx, c_rows=idx,
-                   w_split=sp["fc2"], **sel)
+        vit_linear(y, a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["proj"],
+                   out_planes=x3 if pl else None, **sel)
         (kq, ks, kt), _ = key_block._folded()
         k = torch.zeros(m, c, dtype=torch.float32, device=x2d.device)
+        if pl:
+            h3 = torch.empty(3, m, w1.shape[0], dtype=torch.bfloat16, device=x2d.device)     # only the kept rows are written / read
+            vit_linear(None, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), epilogue=GEMM_LN_GELU, w_split=sp["fc1"], a_planes=x3,
+                       out_planes=h3, fp32_out=False, **sel)
+            vit_linear(None, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["fc2"],
+                       a_planes=h3, out_planes=x3, **sel)
+            k3 = torch.zeros(3, m, c, dtype=torch.bfloat16, device=x2d.device)
+            vit_linear(None, kq[c:2 * c], ks[c:2 * c], kt[c:2 * c], row_mean_rstd(x2d, key_block.norm1.eps), out=k, epilogue=GEMM_LN,
+                       w_split=key_block._planes["k"], a_planes=x3, out_planes=k3, **sel)
+            k = k.view(b, n, c)
+            k._scp_planes = k3
+            return k
+        h = torch.empty(m, w1.shape[0], dtype=torch.float32, device=x2d.device)           # only the kept rows are written / read
+        vit_linear(x2d, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), out=h, epilogue=GEMM_LN_GELU, w_split=sp["fc1"], **sel)
+        vit_linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["fc2"], **sel)
         vit_linear(x2d, kq[c:2 * c], ks[c:2 * c], kt[c:2 * c], row_mean_rstd(x2d, key_block.norm1.eps), out=k, epilogue=GEMM_LN,
-                   a_rows=idx, c_rows=idx, w_split=key_block._planes["k"], **sel)
+                   w_split=key_block._planes["k"], **sel)
         return k.view(b, n, c)
 
-    def keys_fused(self, x2d, b, n):
+    def keys_fused(self, x2d, b, n, x3=None):
         """K third of qkv(LN1(x)), token-major [b, n, heads * d]  (the only part of block 9 the DINO features need)"""
         (wq, sq, tq), _ = self._folded()
         c = x2d.shape[1]
-        k = vit_linear(x2d, wq[c:2 * c], sq[c:2 * c], tq[c:2 * c], row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN,
-                       w_split=self._planes["k"])
-        return k.view(b, n, c)
+        pl = x3 is not None and gemm_mode() == "split"
+        k3 = torch.empty(3, b * n, c, dtype=torch.bfloat16, device=x2d.device) if pl else None
+        k = vit_linear(None if pl else x2d, wq[c:2 * c], sq[c:2 * c], tq[c:2 * c], row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN,
+                       w_split=self._planes["k"], a_planes=x3 if pl else None, out_planes=k3)
+        k = k.view(b, n, c)
+        if pl:
+            k._scp_planes = k3
+        return k
 
 
 class _PatchEmbed(nn.Module):
@@ -434,14 +496,16 @@ class VisionTransformer(nn.Module):
             tok = self.prepare_tokens(x).float().contiguous()
             b, n, c = tok.shape
             x2d = tok.view(b * n, c)
+            # split main loop: the residual stream also lives as bf16 planes, the pre-split A operand of the layers that read it
+            x3 = split_weight(x2d) if (gemm_mode() == "split" and PRESPLIT_ACTIVATIONS) else None
             if keep is not None and layer >= 1:
                 for blk in self.blocks[:layer - 1]:
-                    blk.forward_fused(x2d, b, n)
+                    blk.forward_fused(x2d, b, n, x3)
                 keep_tok = torch.cat((torch.zeros(b, 1, dtype=torch.bool, device=x.device), keep.reshape(b, n - 1).bool()), 1)
-                return self.blocks[layer - 1].tail_keys_fused(x2d, b, n, keep_tok, self.blocks[layer])
+                return self.blocks[layer - 1].tail_keys_fused(x2d, b, n, keep_tok, self.blocks[layer], x3)
             for blk in self.blocks[:layer]:
-                blk.forward_fused(x2d, b, n)
-            return self.blocks[layer].keys_fused(x2d, b, n)
+                blk.forward_fused(x2d, b, n, x3)
+            return self.blocks[layer].keys_fused(x2d, b, n, x3)
         tok, pending = self.prepare_tokens(x).contiguous(), None
         for blk in self.blocks[:layer]:
             tok, pending = blk(tok, pending)

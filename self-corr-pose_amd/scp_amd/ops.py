@@ -82,7 +82,12 @@ def mutual_nn_pairs(keys, src_img, tgt_img, mask_down, tok0=1):
     _require_gpu(keys, "mutual_nn_pairs")
     from . import dino
     mode = dino.gemm_mode()
-    return corr_ops.mutual_nn_fused(keys, src_img, tgt_img, mask_down, tok0, "fp32" if mode == "fp32" else "split")
+    planes = getattr(keys, "_scp_planes", None)            # left by the K projection's epilogue (scp_amd/dino.py) when it pre-splits
+    if mode == "fp32":
+        planes = "fp32"
+    elif planes is None or tuple(planes.shape) != (3, keys.shape[0] * keys.shape[1], keys.shape[2]):
+        planes = "split"
+    return corr_ops.mutual_nn_fused(keys, src_img, tgt_img, mask_down, tok0, planes)
 
 
 def pool2x2_scores(pc, hf, wf):
