@@ -110,8 +110,9 @@ class KernelClock:
     def __enter__(self):
         def wrapped(a, w, *args, **kwargs):
             if self.enabled:
-                self.flops.append(None if kwargs.get("rows") is not None else 2.0 * a.shape[0] * a.shape[1] * w.shape[0])
-                self.shapes.append((a.shape[0], w.shape[0], a.shape[1]))
+                m, k = a.shape if a is not None else kwargs["a_planes"].shape[1:]      # pre-split A operand: [3, M, K] planes
+                self.flops.append(None if kwargs.get("rows") is not None else 2.0 * m * k * w.shape[0])
+                self.shapes.append((m, w.shape[0], k))
             return self.orig(a, w, *args, **kwargs)
         setattr(self.module, self.name, wrapped)
         return self
@@ -552,7 +553,9 @@ def main():
 
     # row-selected launches (last block's tail on the masked tokens) are not timed: their row count lives on the device
     full_gemm = lambda a, w, *rest, **kw: kw.get("rows") is None
-    count_gemm = lambda a, w, *rest, **kw: gemm_flops.append(2.0 * a.shape[0] * a.shape[1] * w.shape[0])
+    def count_gemm(a, w, *rest, **kw):
+        m, k = a.shape if a is not None else kw["a_planes"].shape[1:]
+        gemm_flops.append(2.0 * m * k * w.shape[0])
     # strides 5 and 3 are coprime to the 33 / 8 selected launches per step: over the timed steps every layer shape is sampled evenly
     with KernelTimer(native, "backward_soft_rasterize", is_softtex) as kt, \
             KernelTimer(dino_mod, "fused_attention", lambda *a, **k: len(a) <= 6 and k.get("q_rows") is None, stride=3) as at, \

@@ -197,6 +197,9 @@ struct SplitGemmCore {
     }
 
     __device__ __forceinline__ void issue(int kc, int stage) const {
+#ifdef SCP_PROBE_NO_DMA            // tools/probes: the main loop without its global -> LDS traffic (stale LDS contents)
+        if (kc >= 2) return;
+#endif
         const unsigned dst = lds0 + stage * CFG::STAGE_BYTES;
         kc += kc0;
         static_for<0, CFG::A_PER>([&](auto i) { asrc.template issue<decltype(i)::value>(kc, dst, wave); });
@@ -207,10 +210,12 @@ struct SplitGemmCore {
         });
     }
 
-    // chunk compute for pre-split A with zero-started chunk accumulators, scheduled by hand at statement level: the A fragments of
-    // row tile i + 1 are read while tile i's MFMAs run (two fragment sets), a tile's twelve MFMAs form two interleaved chains on its
-    // chunk accumulators c[0], c[1], the VALU folds them into the running accumulator right after (pinned there by the empty asm and
-    // the scheduling barrier: the compiler otherwise keeps one chunk accumulator pair per row tile alive and spills)
+    // chunk compute for pre-split A with zero-started chunk accumulators, software-pipelined at statement level: the A fragments of
+    // row tile i + 1 are read while tile i's MFMAs run (two fragment sets); a tile's twelve MFMAs form two interleaved chains on
+    // ITS pair of chunk accumulators (two pairs alternate), and the VALU folds a pair into the running accumulator while the NEXT
+    // tile's MFMAs issue (sched_group_barrier: one MFMA, then two or three adds), so that the matrix pipe never waits for the adds;
+    // only the last tile's fold of a chunk is exposed.  Without the fences the compiler keeps one chunk-accumulator pair per row
+    // tile alive and spills.
     template <int S>
     __device__ __forceinline__ void compute_planes(Acc& acc) const {
         const char* st = lds + S * CFG::STAGE_BYTES;
@@ -225,34 +230,51 @@ struct SplitGemmCore {
             for (int p = 0; p < 3; p++) f[p] = *reinterpret_cast<const bf16x8*>(st + a_rd[0] + p * CFG::A_PLANE_BYTES + i * 1024);
         };
         load_a(0, af[0]);
+        f32x16 c[2][CFG::WN];
         static_for<0, CFG::WM>([&](auto ii) {
-            constexpr int i = decltype(ii)::value;
+            constexpr int i = decltype(ii)::value, cur = i & 1, prv = cur ^ 1;
             if constexpr (i + 1 < CFG::WM) load_a(i + 1, af[(i + 1) & 1]);
             const bf16x8 &ah = af[i & 1][0], &am = af[i & 1][1], &al = af[i & 1][2];
-            f32x16 c[CFG::WN];
 #pragma unroll
             for (int j = 0; j < CFG::WN; j++) {
                 f32x16 z;
 #pragma unroll
                 for (int r = 0; r < 16; r++) z[r] = 0.f;
-                c[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wf[1][j], z, 0, 0, 0);
+                c[cur][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wf[1][j], z, 0, 0, 0);
             }
             auto mac = [&](const bf16x8& av, int p) {
 #pragma unroll
-                for (int j = 0; j < CFG::WN; j++) c[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wf[p][j], c[j], 0, 0, 0);
+                for (int j = 0; j < CFG::WN; j++) c[cur][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wf[p][j], c[cur][j], 0, 0, 0);
             };
+#ifndef SCP_PROBE_NO_MFMA          // tools/probes: one MFMA per chain instead of six
             mac(al, 0);
             mac(ah, 2);
             mac(am, 0);
             mac(ah, 1);
+#endif
             mac(ah, 0);
+            if constexpr (i > 0) {
 #pragma unroll
-            for (int j = 0; j < CFG::WN; j++) {
-                acc.t[i * CFG::WN + j] += c[j];
-                asm volatile("" : "+v"(acc.t[i * CFG::WN + j]));
+                for (int j = 0; j < CFG::WN; j++) {
+                    acc.t[(i - 1) * CFG::WN + j] += c[prv][j];
+                    asm volatile("" : "+v"(acc.t[(i - 1) * CFG::WN + j]));
+                }
+                // the ds_reads of the next tile's fragments first, then MFMA / VALU alternating (the previous tile's fold)
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+                for (int g_ = 0; g_ < 6 * CFG::WN; g_++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+#pragma unroll
+        for (int j = 0; j < CFG::WN; j++) {
+            acc.t[(CFG::WM - 1) * CFG::WN + j] += c[(CFG::WM - 1) & 1][j];
+            asm volatile("" : "+v"(acc.t[(CFG::WM - 1) * CFG::WN + j]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     template <int S>

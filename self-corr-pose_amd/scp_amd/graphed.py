@@ -35,13 +35,16 @@ class _Replay(torch.autograd.Function):
                 dst.copy_(src)
         g["fwd"].replay()
         ctx.seg = seg
-        return tuple(o.detach() for o in g["outputs"])
+        outs = tuple(o.detach() for o in g["outputs"])
+        # outputs that carried no gradient in the captured function carry none here either
+        ctx.mark_non_differentiable(*[o for i, o in enumerate(outs) if i not in g["out_req"]])
+        return outs
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
         g = ctx.seg.graphs
-        for dst, src in zip(g["grad_outputs"], (grads[i] for i in g["out_req"])):
+        for dst, src in zip(g["grad_outputs"], [grads[i] for i in g["out_req"]]):
             if src is None:
                 dst.zero_()
             elif dst.data_ptr() != src.data_ptr():

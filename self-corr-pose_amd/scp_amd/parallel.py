@@ -57,6 +57,12 @@ class FlatGradients:
         self._armed = False
         self._prepared = False
         self._silent, self._fired, self._poisoned = set(), set(), set()
+        # which parameters received a gradient ON ANY RANK (decides whose .grad ends as None: see finish()).  Established by one
+        # MAX all-reduce + host read in the first step (and after reset_static_graph()), then only VERIFIED on the device every step
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._global_used = None               # host: bool list per parameter, identical on every rank
+        self._global_used_dev = None
+        self._used_mismatch = None             # device flag: some rank's used set differed from the established one
         self.launched_in_backward = 0          # buckets whose collective was enqueued from a hook (test / log)
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" and self.active else None
         # hooks at every world size: with one rank they only record which parameters received a gradient (finish() needs that
@@ -170,9 +176,42 @@ class FlatGradients:
             self.launched_in_backward += 1
 
     def reset_static_graph(self):
-        """forget which parameters were unused in the previous step: every bucket waits for all of its parameters again
-        (call before a step whose set of used parameters differs from the last one's)"""
+        """forget which parameters were unused in the previous step: every bucket waits for all of its parameters again, and the
+        set of parameters used on any rank is established afresh by the next finish() (one host read).  COLLECTIVE in effect: call
+        it on every rank before a step whose set of used parameters differs from the last one's."""
         self._silent = set()
+        self._global_used = self._global_used_dev = self._used_mismatch = None
+
+    def check_static_graph(self):
+        """host check (one device read) that no rank's set of used parameters has departed from the established one since the
+        last check; Trainer.train() calls it where it reads the losses back anyway.  Raises on every rank alike."""
+        if self._used_mismatch is not None and bool(self._used_mismatch.item()):
+            raise RuntimeError("FlatGradients: the set of parameters that receive a gradient changed on some rank; call "
+                               "reset_static_graph() on every rank before such a step")
+
+    def _global_unused(self, local_unused):
+        """the parameters that received no gradient on ANY rank this step (the reference's DDP all-reduces its used-parameter
+        bitmap for the same purpose): a parameter used on some ranks only must be stepped by ALL replicas with the averaged
+        gradient, or they diverge.  One tiny MAX all-reduce per step; its result is read on the host only when the set is being
+        established, afterwards it is compared on the device with the established one (check_static_graph() reads that flag)."""
+        if not self.active:
+            return local_unused
+        key = tuple(self._index[id(p)] for p in local_unused)
+        cache = self.__dict__.setdefault("_local_mask_cache", {})
+        if key not in cache:                                  # built once per distinct local set (a host-to-device copy)
+            m = torch.ones(len(self.params), dtype=torch.int32)
+            if key:
+                m[list(key)] = 0
+            cache[key] = m.to(self.flat.device)
+        local = cache[key].clone()
+        dist.all_reduce(local, op=dist.ReduceOp.MAX, group=self.group)
+        if self._global_used is None:
+            self._global_used = [bool(v) for v in local.cpu().tolist()]
+            self._global_used_dev = local
+            self._used_mismatch = torch.zeros((), dtype=torch.bool, device=self.flat.device)
+        else:
+            self._used_mismatch = self._used_mismatch | (local != self._global_used_dev).any()
+        return [p for p, used in zip(self.params, self._global_used) if not used]
 
     def finish(self, keep_unused_none=False):
         """after backward: adopt gradients that were assigned around the views, launch the buckets that have not fired,
@@ -205,7 +244,7 @@ class FlatGradients:
             if self.comm_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
         if keep_unused_none:
-            for p in unused:
+            for p in self._global_unused(unused):
                 p.grad = None
         return self.flat
 

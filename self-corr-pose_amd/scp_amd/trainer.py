@@ -232,6 +232,7 @@ class Trainer:
             pending.append(total.detach())
             if (i + 1) % opts.batch_log_interval == 0:
                 vals = torch.stack(pending).cpu().tolist()
+                self.grads.check_static_graph()        # the host is synchronised here anyway
                 history.extend(vals)
                 pending = []
                 t1 = time.time()

@@ -7,6 +7,7 @@ ref_harness.py; its SoftRas kernel bodies host-compiled unchanged) on seeded syn
 writes inputs + expected outputs to tests/golden/*.npz.  Only the .npz files travel to the GPU box;
 this script, ref_harness.py and ref_shim.* cannot run there.  See SURVEY.md section 8(c), G1-G7.
 """
+import hashlib
 import os
 import sys
 
@@ -136,11 +137,8 @@ COND_SIGMAS = (1e-6, 3e-6, 1e-5)     # std of the iid Gaussian perturbation of (
 COND_DRAWS = 12
 
 
-def gen_step(tag="step_laptopflags_bottle_b2x2", prior="bottle", batch_size=2, repeat=2, conditioning=None, cond_draws=COND_DRAWS):
-    """G7 (+G5): one full reference MeshNet.forward/backward (model/model.py:61-152) on the synthetic
-    batch of SURVEY 8(d): B = batch_size 2 x repeat 2, 256^2, bottle prior (642 v / 1280 f), laptop
-    flags, recipe weights (tests/recipe.py), jitter = identity, rotation angle pinned to 90 degrees,
-    symmetry sample injected, top-k selection recorded (SURVEY F16)."""
+def _reference_model(prior, batch_size, repeat):
+    """the reference's MeshNet (model/model.py) under the laptop flag set with recipe weights, as gen_step runs it"""
     import tempfile
     import recipe
     import synth
@@ -176,6 +174,19 @@ def gen_step(tag="step_laptopflags_bottle_b2x2", prior="bottle", batch_size=2, r
     assert not unexpected, unexpected
     model.train()
     model.iters = 0
+
+    return model, flags, bottle
+
+
+def gen_step(tag="step_laptopflags_bottle_b2x2", prior="bottle", batch_size=2, repeat=2, conditioning=None, cond_draws=COND_DRAWS):
+    """G7 (+G5): one full reference MeshNet.forward/backward (model/model.py:61-152) on the synthetic
+    batch of SURVEY 8(d): B = batch_size 2 x repeat 2, 256^2, bottle prior (642 v / 1280 f), laptop
+    flags, recipe weights (tests/recipe.py), jitter = identity, rotation angle pinned to 90 degrees,
+    symmetry sample injected, top-k selection recorded (SURVEY F16)."""
+    import recipe
+    import synth
+    model, flags, bottle = _reference_model(prior, batch_size, repeat)
+    bsz = batch_size * repeat
 
     # injected symmetry sample (k = 2 symmetry rotations for the laptop flags)
     k = model.mesh.symm_rots.shape[0]
@@ -271,7 +282,8 @@ def gen_step(tag="step_laptopflags_bottle_b2x2", prior="bottle", batch_size=2, r
             seen = {}
 
             def wrapped(x, *a, **kw):
-                key = (tuple(x.shape), float(x.double().sum()), float((x.double() ** 2).sum()))
+                # order-sensitive: at B = 32 the reference's two DINO chunks hold the SAME images in different order
+                key = (tuple(x.shape), hashlib.md5(x.detach().contiguous().numpy().tobytes()).hexdigest())
                 if key not in seen:
                     seen[key] = fn(x, *a, **kw)
                 return seen[key]
@@ -317,6 +329,41 @@ def gen_step(tag="step_laptopflags_bottle_b2x2", prior="bottle", batch_size=2, r
          **{k: v.detach().numpy() for k, v in grads.items()}, **out)
     for k, v in sorted(out.items()):
         print("  %-28s %.9g" % (k, v))
+
+
+def gen_render():
+    """G2: Renderer.render_all (model/module/renderer.py:38-73) by itself -- the four SoftRas passes, the projected
+    vertices and the visibility weight -- on the geometry the step fixture recorded (B = 2 of its 4 images, bottle prior 642 v /
+    1280 f, 256 x 256), random vertex textures; the nine outputs (image planes at every second pixel + full-tensor statistics) and
+    the gradients of a fixed random functional of them w.r.t. pred_v, tex, rotation, translation."""
+    import synth
+    model, flags, _ = _reference_model("bottle", 2, 2)
+    d = np.load(os.path.join(HERE, "step_laptopflags_bottle_b2x2.npz"))
+    data = synth.make_batch(2, 2, 256, seed=0)
+    n = 2
+    g = torch.Generator().manual_seed(77)
+    pred_v = torch.tensor(d["pred_v"][:n]).requires_grad_(True)
+    rotation = torch.tensor(d["rotation"][:n]).requires_grad_(True)
+    translation = torch.tensor(d["translation"][:n]).requires_grad_(True)
+    tex = torch.rand(n, pred_v.shape[1], 3, generator=g).requires_grad_(True)
+    foc_crop, pp_crop = data[7][:n].float(), data[9][:n].float()
+    faces = model.mesh.faces[None].repeat(n, 1, 1)
+    outs = model.renderer.render_all(pred_v, faces, tex, foc_crop, pp_crop, rotation, translation, None)
+    names = ("mask_render", "tex_render", "depth_render", "match_gt", "imatch_gt", "tex_mask", "depth_mask", "match_mask", "depth_weight")
+    weights = {k: torch.randn(o.shape, generator=g) for k, o in zip(names, outs)}
+    # the canonical-xyz pass (match_gt, match_mask) is left out of the functional: the training step consumes it through
+    # comparisons and a detached target only (loss_utils.py:317-320; SURVEY F8: its backward is identically zero there), and the
+    # build computes it without an autograd graph
+    in_loss = [k for k, o in zip(names, outs) if o.requires_grad and k not in ("match_gt", "match_mask")]
+    loss = sum((o * weights[k]).sum() for k, o in zip(names, outs) if k in in_loss)
+    loss.backward()
+    sub = lambda t: t.detach().numpy()[..., ::2, ::2] if t.dim() >= 3 and t.shape[-1] == 256 else t.detach().numpy()
+    save("render_all_bottle_b2", pred_v=pred_v.detach().numpy(), rotation=rotation.detach().numpy(), translation=translation.detach().numpy(),
+         tex=tex.detach().numpy(), foc_crop=foc_crop.numpy(), pp_crop=pp_crop.numpy(), faces=model.mesh.faces.numpy().astype(np.int64),
+         **{"out_" + k: sub(o) for k, o in zip(names, outs)}, **{"stats_" + k: _stats(o) for k, o in zip(names, outs)},
+         weights_seed=np.int64(77),   # the functional's weights: torch.Generator().manual_seed(77); rand(tex) first, then randn per output in order
+         grad_pred_v=pred_v.grad.numpy(), grad_tex=tex.grad.numpy(), grad_rotation=rotation.grad.numpy(),
+         grad_translation=translation.grad.numpy(), requires_grad=np.array(in_loss))
 
 
 def gen_corr():
@@ -692,7 +739,7 @@ def gen_data():
     print("  items:", len(ds), " img", tuple(e["img"].shape), e["img"].dtype, " depth", e["depth"].dtype)
 
 
-GENERATORS = {"softras": gen_softras, "step": gen_step, "corr": gen_corr, "losses": gen_losses,
+GENERATORS = {"softras": gen_softras, "render": gen_render, "step": gen_step, "corr": gen_corr, "losses": gen_losses,
               "step_laptop": gen_step_laptop, "step_single": gen_step_single, "step_conditioning": gen_step_conditioning,
               "step_conditioning_laptop_b8": gen_step_conditioning_laptop_b8, "step_conditioning_bottle_b32": gen_step_conditioning_bottle_b32,
               "flatten": gen_flatten, "posefit": gen_posefit, "data": gen_data}

@@ -229,6 +229,95 @@ def test_parameter_that_becomes_used_gloo_world2():
     assert all(got.values()), "a gradient that arrived after its bucket's all-reduce must raise"
 
 
+def _one_rank_uses_it_worker(rank, world, port, out):
+    """a parameter that receives a gradient on rank 0 only: every replica must keep its (averaged) gradient -- not None on the rank
+    that did not use it -- so that AdamW steps it identically everywhere; a parameter unused on BOTH ranks ends with grad None.
+    Later: the used set changes on one rank without reset_static_graph() -> check_static_graph() raises on every rank."""
+    _init(rank, world, port)
+    from scp_amd.parallel import FlatGradients
+    torch.manual_seed(0)
+    a, b, c = torch.nn.Linear(8, 8), torch.nn.Linear(8, 8), torch.nn.Linear(8, 8)
+    params = list(a.parameters()) + list(b.parameters()) + list(c.parameters())
+    red = FlatGradients(params)
+    red.broadcast_parameters()
+    x = torch.randn(4, 8, generator=torch.Generator().manual_seed(3 + rank))
+
+    def step(use_b):
+        red.prepare()
+        y = a(x)
+        if use_b:
+            y = y + b(x)
+        y.square().mean().backward()
+        red.finish(keep_unused_none=True).div_(world)
+    step(use_b=(rank == 0))
+    ok = all(p.grad is not None for p in a.parameters()) and all(p.grad is not None for p in b.parameters())
+    ok = ok and all(p.grad is None for p in c.parameters())
+    gb = b.weight.grad.clone()
+    both = [None] * world
+    dist.all_gather_object(both, gb.numpy())
+    ok = ok and bool((both[0] == both[1]).all()) and float(gb.abs().sum()) > 0      # the same averaged gradient on both ranks
+    red.check_static_graph()                                                        # nothing has changed yet
+    step(use_b=False)                                                               # rank 0 stops using b: the set changed
+    raised = False
+    try:
+        red.check_static_graph()
+    except RuntimeError:
+        raised = True
+    red.reset_static_graph()
+    step(use_b=False)
+    ok = ok and raised and all(p.grad is None for p in b.parameters())
+    out.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_parameter_used_on_one_rank_only_gloo_world2():
+    got = _run(_one_rank_uses_it_worker)
+    assert all(got.values())
+
+
+def _sync_bn_worker(rank, world, port, out):
+    """Trainer(sync_bn=True) (the reference's multi-GPU choice, trainer.py:67): two ranks with B images each normalise with the
+    statistics of the JOINT 2B batch -- the encoder's features on each rank equal those of one process that sees all 2B images.
+    torch's SyncBatchNorm only takes GPU tensors: two RCCL ranks on two GPUs."""
+    for p in (ROOT, os.path.join(ROOT, "self-corr-pose_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = "cuda:%d" % rank
+    import scenes
+    import scp_amd.dino as dino
+    from scp_amd.flags import Options
+    from scp_amd.trainer import Trainer
+    dino.ALLOW_RANDOM_INIT = True
+    opts = Options("laptop_wild6d", batch_size=1, repeat=2, train=True, total_iters=50, img_size=64, corr_h=16, corr_w=16, ngpu=world)
+    torch.manual_seed(0)
+    tr = Trainer(opts, prior=scenes.bottle_like(2), device=dev, sync_bn=True)
+    assert any(isinstance(m, torch.nn.SyncBatchNorm) for m in tr.model.modules())
+    enc = tr.model.encoder
+    enc.random_jitter = torch.nn.Identity()
+    imgs = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(7)).to(dev)
+    _, mine = enc.encode_img(imgs[2 * rank:2 * rank + 2])
+    # the joint batch through plain BatchNorm in one process (same weights: built from the same seed, broadcast from rank 0)
+    torch.manual_seed(0)
+    ref = Trainer(opts, prior=scenes.bottle_like(2), device=dev, sync_bn=False, process_group=None)
+    ref.model.load_state_dict(tr.model.state_dict(), strict=False)
+    ref.model.encoder.random_jitter = torch.nn.Identity()
+    _, joint = ref.model.encoder.encode_img(imgs)
+    err = float((mine - joint[2 * rank:2 * rank + 2]).abs().max())
+    out.put((rank, err))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sync_batchnorm_equals_joint_batch_rccl_world2():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (SyncBatchNorm takes GPU tensors only; RCCL refuses two ranks on one device)")
+    got = _run(_sync_bn_worker)
+    assert all(v <= 1e-5 for v in got.values()), got
+
+
 def _rccl_two_rank_worker(rank, world, port, out):
     """2 real RCCL ranks on 2 GPUs: 1 x (2B) equals 2 x B (mean of the per-rank gradients == gradient of the mean loss over the
     joint batch), and >= 2 buckets are enqueued from inside backward"""
