@@ -155,11 +155,16 @@ int scp_vit_linear(const float* A, const void* W, const float* vec0, const float
 int scp_vit_linear_rows(const float* A, const void* W, const float* vec0, const float* vec1, const float* rowstat,
                         const float* resid, float* C, const int* rows_dev, int max_rows, const int* a_rows, const int* c_rows,
                         int N, int K, int epilogue, void* stream);
-/* The same with pre-split operands on either side (round 4; SCP_GEMM_W_SPLIT3 only):
- *   A_planes [3][a_rows_total][K] bf16 (A = h + m + l exactly) replaces A when non-NULL: the main loop then has no VALU split;
- *   C_planes [3][c_rows_total][N] bf16 (N even) receives the epilogue's result split the same way -- the next layer's A_planes; C may
- *   then be NULL (fc1: only the planes of GELU(.) are ever read).  rows_dev / max_rows / a_rows / c_rows as scp_vit_linear_rows
- *   (rows_dev NULL: max_rows = M rows, all computed).  Row indices address planes and fp32 tensors alike. */
+/* The same with pre-split operands on either side (round 4; SCP_GEMM_W_SPLIT3 only).  Operand planes here use the TILED layout
+ *   [rows / 32][K / 16][3 planes][32 rows][16 k] bf16   (scp_split_bf16x3_tiled; rows padded to a multiple of 32)
+ * in which every piece one wavefront's LDS-DMA instruction moves is one contiguous KiB (csrc/gemm_core_split.h):
+ *   A_planes (tiled, a_rows_total rows, K) replaces A when non-NULL: the main loop then has no VALU split, and W must be TILED planes
+ *   of the weight as well; with A_planes NULL, W is the plane-major [3][N][K] split of scp_split_bf16x3 as in scp_vit_linear;
+ *   C_planes (tiled, c_rows_total rows, N; N % 16 == 0) receives the epilogue's result split the same way -- the next layer's
+ *   A_planes; C may then be NULL (fc1: only the planes of GELU(.) are ever read).  rows_dev / max_rows / a_rows / c_rows as
+ *   scp_vit_linear_rows (rows_dev NULL: max_rows = M rows, all computed).  Row indices address planes and fp32 tensors alike. */
+size_t scp_split_bf16x3_tiled_elements(int rows, int K);
+int scp_split_bf16x3_tiled(const float* x, void* planes, int rows, int K, void* stream);
 int scp_vit_linear_planes(const float* A, const void* A_planes, int a_rows_total, const void* W, const float* vec0, const float* vec1,
                           const float* rowstat, const float* resid, float* C, void* C_planes, int c_rows_total, const int* rows_dev,
                           int max_rows, const int* a_rows, const int* c_rows, int N, int K, int epilogue, void* stream);
@@ -411,8 +416,9 @@ int scp_mutual_argmax(const float* scores, const float* rowmask, const float* co
  * Replaces pretrained_corr.py:85-89 end to end (`pointcorr = bmm(src_feat^T, tgt_feat)`, mask, `.max(1)`, `.max(2)`), and the
  * per-pair gathers of the feature maps before it (pretrained_corr.py:59-74, loss_utils.py:326-345):
  *   keys       [n_images, n_tok, C] fp32, token-major: the DINO key features as the ViT's K projection leaves them
- *   key_planes [3][n_images * n_tok][C] bf16 = scp_split_bf16x3(keys): the products then run on the bf16 matrix cores with exactly
- *              split operands (fp32-accurate, csrc/gemm_core_split.h); NULL: fp32 matrix cores on `keys` itself
+ *   key_planes = scp_split_bf16x3_tiled(keys as [n_images * n_tok][C]) (TILED planes, see scp_vit_linear_planes): the products then
+ *              run on the bf16 matrix cores with exactly split operands (fp32-accurate, csrc/gemm_core_split.h); NULL: fp32 matrix
+ *              cores on `keys` itself
  *   tokens tok0 .. tok0 + P - 1 of an image take part (tok0 = 1 skips the class token); C % 32 == 0
  *   src_img / tgt_img [N] int32: the images of pair n;  mask [n_images, P] fp32 or NULL: a score counts as -1e5 where the source
  *              token's or the target token's mask is <= 0

@@ -156,8 +156,10 @@ __device__ __forceinline__ void finalize_statistics(const ConvArgs& g, float* ld
 }
 
 // the split twin of a tile shape: same wavefront grid and MFMA tiles per wavefront
+// (round 4: its W planes are TILED -- csrc/gemm_core_split.h -- every LDS-DMA piece of the weight one contiguous KiB instead of
+// 32 rows x 32 B = 32 cache lines: the weight pieces were 3/4 of the main loop's address traffic)
 template <class CFG>
-using SplitOf = scp::SplitCfg<CFG::WM, CFG::WN, CFG::NWM, CFG::NWN, CFG::MINBLK>;
+using SplitOf = scp::SplitCfg<CFG::WM, CFG::WN, CFG::NWM, CFG::NWN, CFG::MINBLK, 3, (CFG::WM * CFG::WN <= 4), false, true>;
 
 template <class FCFG, int TAPS, int EPI, bool STATS, bool SPLIT>
 __global__ __launch_bounds__(FCFG::THREADS, 2) void conv_igemm_kernel(const ConvArgs g) {
@@ -257,8 +259,9 @@ __global__ __launch_bounds__(FCFG::THREADS, 2) void conv_igemm_kernel(const Conv
 }
 
 // weight [Cout, Cin, k, k] (any strides) -> the split operand planes of both directions in one pass:
-//   fwd   [3][Cout][k][k][Cin]   the W operand of the forward implicit GEMM,
-//   dgrad [3][Cin][k][k][Cout]   taps flipped: the W operand of the input gradient (NULL: not wanted)
+//   fwd   rows = Cout, K = (ky, kx, ci)              the W operand of the forward implicit GEMM,
+//   dgrad rows = Cin,  K = (ky, kx, co), taps flipped  the W operand of the input gradient (NULL: not wanted)
+// both in the TILED plane layout of csrc/gemm_core_split.h ([rows / 32][K / 16][3][32][16] bf16, rows padded to 32)
 __global__ void conv_weight_planes_kernel(const float* __restrict__ w, long s_co, long s_ci, long s_ky, long s_kx, int Cout, int Cin,
                                           int k, __bf16* __restrict__ fwd, __bf16* __restrict__ dgrad) {
     const long n = (long)Cout * Cin * k * k;
@@ -274,10 +277,11 @@ __global__ void conv_weight_planes_kernel(const float* __restrict__ w, long s_co
     const float r1 = v - (float)h;
     const __bf16 m = (__bf16)r1;
     const __bf16 l = (__bf16)(r1 - (float)m);
-    fwd[i] = h; fwd[n + i] = m; fwd[2 * n + i] = l;
+    const size_t o = scp::tiled_plane_offset(co, (ky * k + kx) * Cin + ci, 0, (k * k * Cin) >> 4);
+    fwd[o] = h; fwd[o + 512] = m; fwd[o + 1024] = l;
     if (dgrad) {
-        const long j = (((long)ci * k + (k - 1 - ky)) * k + (k - 1 - kx)) * Cout + co;
-        dgrad[j] = h; dgrad[n + j] = m; dgrad[2 * n + j] = l;
+        const size_t j = scp::tiled_plane_offset(ci, ((k - 1 - ky) * k + (k - 1 - kx)) * Cout + co, 0, (k * k * Cout) >> 4);
+        dgrad[j] = h; dgrad[j + 512] = m; dgrad[j + 1024] = l;
     }
 }
 
@@ -525,6 +529,8 @@ extern "C" int scp_conv_nhwc_forward_bn(const float* x, const float* w, const vo
 extern "C" int scp_conv_weight_planes(const float* w, long long s_co, long long s_ci, long long s_ky, long long s_kx, int Cout, int Cin,
                                       int ksize, void* planes_fwd, void* planes_dgrad, void* stream) {
     if (!w || !planes_fwd || Cout <= 0 || Cin <= 0 || ksize <= 0) return scp::fail(hipErrorInvalidValue, "conv_weight_planes: bad argument");
+    if ((ksize * ksize * Cin) % 16 || (planes_dgrad && (ksize * ksize * Cout) % 16))
+        return scp::fail(hipErrorInvalidValue, "conv_weight_planes: k*k*Cin (and k*k*Cout for the input gradient) must be multiples of 16");
     const long n = (long)Cout * Cin * ksize * ksize;
     hipLaunchKernelGGL(conv_weight_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w,
                        (long)s_co, (long)s_ci, (long)s_ky, (long)s_kx, Cout, Cin, ksize, static_cast<__bf16*>(planes_fwd),

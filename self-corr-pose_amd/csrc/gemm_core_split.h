@@ -43,10 +43,19 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 // kernel that produced it: csrc/vit_gemm.hip), moved by the same LDS-DMA -- the main loop is then DMA -> ds_read -> MFMA with no
 // VALU split at all (the in-register split cost 5.4 VALU instructions per MFMA and was redone by every column block that read the
 // same A rows: 9x for the qkv projection).
-template <int WM_, int WN_, int NWM_, int NWN_, int MINBLK_, int NPLANES_ = 3, bool ZSTART_ = (WM_ * WN_ <= 4), bool APLANES_ = false>
+//
+// TILED plane layout (APLANES only; "TP"): a [rows][K] operand is stored as  [rows / 32][K / 16][3 planes][32 rows][16 k]  bf16, i.e.
+// every (32-row group, 16-k chunk, plane) is ONE contiguous KiB -- exactly what one wavefront's LDS-DMA instruction moves.  Measured
+// (tools/probes/build_gemm_variants.sh, profiles/r04_gemm_planes_ablation.txt): with row-major planes a DMA instruction touches 32
+// cache lines for its KiB (32 rows x 32 B) and the main loop is bound by that address traffic, not by the matrix pipe (removing 5/6
+// of the MFMAs: -10 %; removing the DMA: -30 %); tiled, it touches 8.
+// WTILED: the W planes are tiled (always with APLANES; a kernel that splits its fp32 A in registers may still take a tiled W).
+template <int WM_, int WN_, int NWM_, int NWN_, int MINBLK_, int NPLANES_ = 3, bool ZSTART_ = (WM_ * WN_ <= 4), bool APLANES_ = false,
+          bool WTILED_ = APLANES_>
 struct SplitCfg {
     static constexpr int NPLANES = NPLANES_;
-    static constexpr bool ZSTART = ZSTART_, APLANES = APLANES_;
+    static constexpr bool ZSTART = ZSTART_, APLANES = APLANES_, TILED = WTILED_;
+    static_assert(!APLANES_ || WTILED_, "pre-split A comes with tiled W planes");
     static constexpr int WM = WM_, WN = WN_, NWM = NWM_, NWN = NWN_, NSTAGE = 2, MINBLK = MINBLK_;
     static constexpr int BM = 32 * WM * NWM, BN = 32 * WN * NWN, BK = 16;
     static constexpr int NW = NWM * NWN, THREADS = 64 * NW;
@@ -63,6 +72,10 @@ struct SplitCfg {
 };
 
 struct Split3 { bf16x8 h, m, l; };
+// element offset of (row, k) of plane p in the tiled plane layout of a [rows][K] operand (kchunks = K / 16)
+__host__ __device__ __forceinline__ size_t tiled_plane_offset(int row, int k, int p, int kchunks) {
+    return ((((size_t)(row >> 5) * kchunks + (k >> 4)) * 3 + p) << 9) + ((row & 31) << 4) + (k & 15);
+}
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // two fp32 -> packed bf16 pair (round to nearest even): one v_cvt_pk_bf16_f32
@@ -125,13 +138,13 @@ struct PlanesASource {
         for (int i = 0; i < CFG::A_PER; i++) {
             const int q = min(wave + CFG::NW * i, CFG::A_PIECES - 1), plane = q / CFG::A_GROUPS, r = 32 * (q % CFG::A_GROUPS) + prow;
             const int slot = pslot ^ ((r >> 3) & 1);
-            a_off[i] = ((unsigned)plane * (unsigned)rows_total * (unsigned)K + (unsigned)a_row(r) * (unsigned)K + 8u * slot) * 2u;
+            a_off[i] = (unsigned)(tiled_plane_offset(a_row(r), 8 * slot, plane, K >> 4) * 2u);
         }
     }
     template <int I>
     __device__ __forceinline__ void issue(int kc, unsigned stage_lds, int wave) const {
         if ((I + 1) * CFG::NW <= CFG::A_PIECES || wave + CFG::NW * I < CFG::A_PIECES)          // wavefront-uniform
-            glds16(a_off[I], a_base + (size_t)kc * 32, stage_lds + (unsigned)(wave + CFG::NW * I) * 1024u);
+            glds16(a_off[I], a_base + (size_t)kc * 3072, stage_lds + (unsigned)(wave + CFG::NW * I) * 1024u);
     }
 };
 
@@ -175,7 +188,8 @@ struct SplitGemmCore {
         for (int i = 0; i < CFG::W_PER; i++) {
             const int q = min(wave + CFG::NW * i, CFG::W_PIECES - 1), plane = q / CFG::W_GROUPS, r = 32 * (q % CFG::W_GROUPS) + prow;
             const int slot = pslot ^ ((r >> 3) & 1);
-            w_off[i] = ((unsigned)plane * (unsigned)N * (unsigned)K + (unsigned)w_row(r) * (unsigned)K + 8u * slot) * 2u;
+            if constexpr (CFG::TILED) w_off[i] = (unsigned)(tiled_plane_offset(w_row(r), 8 * slot, plane, K >> 4) * 2u);
+            else w_off[i] = ((unsigned)plane * (unsigned)N * (unsigned)K + (unsigned)w_row(r) * (unsigned)K + 8u * slot) * 2u;
         }
     }
     // the interface gemm_core.h's GemmCore shares (vit_gemm.hip picks a core per launch): A [M,K] fp32 row-major
@@ -206,7 +220,7 @@ struct SplitGemmCore {
         static_for<0, CFG::W_PER>([&](auto i) {
             constexpr int I = decltype(i)::value;
             if ((I + 1) * CFG::NW <= CFG::W_PIECES || wave + CFG::NW * I < CFG::W_PIECES)      // wavefront-uniform
-                glds16(w_off[I], w_base + (size_t)kc * 32, dst + CFG::A_BYTES + (unsigned)(wave + CFG::NW * I) * 1024u);
+                glds16(w_off[I], w_base + (size_t)kc * (CFG::TILED ? 3072 : 32), dst + CFG::A_BYTES + (unsigned)(wave + CFG::NW * I) * 1024u);
         });
     }
 

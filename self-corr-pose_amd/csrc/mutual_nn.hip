@@ -111,7 +111,7 @@ __global__ void mutual_unpack_kernel(const unsigned long long* __restrict__ colb
 // ---- fused score GEMM + dual argmax -------------------------------------------------------------------------------------------
 struct FusedArgs {
     const float* keys;            // [rows_total, C] fp32, token-major (A operand)
-    const void* w;                // W operand: planes [3][rows_total][C] bf16 (split core) or the same fp32 keys (fp32 core)
+    const void* w;                // W operand: TILED planes of the keys (split core; rows padded to 32) or the same fp32 keys (fp32 core)
     const int* src_img;           // [N] image of the pair's source / target side
     const int* tgt_img;
     const float* mask;            // [B, P] per-image mask at the key resolution (> 0 = inside), or nullptr
@@ -120,7 +120,9 @@ struct FusedArgs {
     int N, P, C, n_tok, tok0, rows_total;
 };
 
-using FusedSplitCfg = scp::SplitCfg<2, 2, 2, 2, 2>;        // 128 x 128 tile, 4 wavefronts of 64 x 64, 40 KiB ring
+// 128 x 128 tile, 4 wavefronts of 64 x 64, 40 KiB ring; A = fp32 keys split in registers, W = their TILED bf16 planes
+// (csrc/gemm_core_split.h: every LDS-DMA piece one contiguous KiB), as the ViT's K projection leaves them or scp_split_bf16x3_tiled makes them
+using FusedSplitCfg = scp::SplitCfg<2, 2, 2, 2, 2, 3, true, false, true>;
 using FusedFp32Cfg = scp::GemmCfg<2, 2, 2, 2, 2, 2>;
 
 template <int CTRL>

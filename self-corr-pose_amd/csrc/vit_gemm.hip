@@ -196,13 +196,14 @@ __device__ __forceinline__ void run_tile(const GemmArgs& g, float* lds, int M, i
                 xv[r >> 3][r & 7] = x;
             }
             if (g.C3) {
-                // the result as three bf16 planes (x = h + m + l exactly), the pre-split A operand of the next GEMM.  A lane holds
+                // the result as three bf16 planes (x = h + m + l exactly) in the TILED layout of csrc/gemm_core_split.h -- the
+                // pre-split A operand of the next GEMM, every LDS-DMA piece of it one contiguous KiB.  A lane holds
                 // ONE column: rows are taken in pairs (r, r + 1), split together (packed bf16 pairs), and exchanged with the
                 // neighbouring column's lane so that even lanes store row r's pair (n, n + 1) and odd lanes row r + 1's pair
                 // (n - 1, n): dword stores, 64 B contiguous per row and half-wavefront.
                 const bool odd = l31 & 1;
                 const unsigned sel = odd ? 0x03020706u : 0x05040100u;
-                const size_t plane = (size_t)g.c_rows_total * g.N;
+                const int kch = g.N >> 4;                                  // the planes are the next layer's A operand: its K = this N
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const scp::Split3 sp = scp::split3(xv[q]);
@@ -212,7 +213,7 @@ __device__ __forceinline__ void run_tile(const GemmArgs& g, float* lds, int M, i
                     for (int pr = 0; pr < 4; pr++) {
                         const int r = 8 * q + 2 * pr + (odd ? 1 : 0);
                         const int m = mb + scp::acc_row(r, half);
-                        __bf16* dst = g.C3 + (size_t)orow(r) * g.N + (n - (odd ? 1 : 0));
+                        __bf16* dst = g.C3 + scp::tiled_plane_offset(orow(r), n - (odd ? 1 : 0), 0, kch);
                         const bool ok = m < M && n_ok;
                         auto put = [&](unsigned own, __bf16* at) {
                             const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xF, 0xF, true);
@@ -220,8 +221,8 @@ __device__ __forceinline__ void run_tile(const GemmArgs& g, float* lds, int M, i
                             if (ok) *reinterpret_cast<unsigned*>(at) = v;
                         };
                         put(ph[pr], dst);
-                        put(pm[pr], dst + plane);
-                        put(pl[pr], dst + 2 * plane);
+                        put(pm[pr], dst + 512);
+                        put(pl[pr], dst + 1024);
                     }
                 }
             }
@@ -376,6 +377,21 @@ __global__ void split_bf16x3_kernel(const float* __restrict__ x, __bf16* __restr
     planes[2 * n + i] = (__bf16)(r1 - (float)m);
 }
 
+// x [rows][K] fp32 -> tiled planes (csrc/gemm_core_split.h: [rows / 32][K / 16][3][32][16] bf16); thread = 8 consecutive k of a row
+__global__ void split_bf16x3_tiled_kernel(const float* __restrict__ x, __bf16* __restrict__ planes, int rows, int K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_row = K >> 3;
+    if (i >= (size_t)rows * per_row) return;
+    const int row = (int)(i / per_row), k0 = 8 * (int)(i - (size_t)row * per_row);
+    const float4 a = *reinterpret_cast<const float4*>(x + (size_t)row * K + k0), b = *reinterpret_cast<const float4*>(x + (size_t)row * K + k0 + 4);
+    const scp::f32x8 v = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const scp::Split3 s = scp::split3(v);
+    __bf16* dst = planes + scp::tiled_plane_offset(row, k0, 0, K >> 4);
+    *reinterpret_cast<scp::bf16x8*>(dst) = s.h;
+    *reinterpret_cast<scp::bf16x8*>(dst + 512) = s.m;
+    *reinterpret_cast<scp::bf16x8*>(dst + 1024) = s.l;
+}
+
 // scp_kernel_clock_begin / _end: while a slot buffer is installed every vit_linear launch gets the next slot
 unsigned long long* g_clock_slots = nullptr;
 int g_clock_n = 0, g_clock_i = 0;
@@ -424,9 +440,10 @@ int vit_linear_impl(const float* A, const void* W, const float* vec0, const floa
     if (M <= 0 || N <= 0 || K <= 0) return scp::fail(hipErrorInvalidValue, "vit_linear: empty problem");
     if (!A && !A3) return scp::fail(hipErrorInvalidValue, "vit_linear: no A operand");
     if (!C && !C3) return scp::fail(hipErrorInvalidValue, "vit_linear: no output");
-    if (A3 && (a_rows_total < M || 3 * (size_t)a_rows_total * (size_t)K >= (1ull << 31)))
-        return scp::fail(hipErrorInvalidValue, "vit_linear: A planes smaller than M rows or larger than 2^32 bytes");
-    if (C3 && (c_rows_total < M || (N & 1))) return scp::fail(hipErrorInvalidValue, "vit_linear: output planes need c_rows_total >= M and an even N");
+    if (A3 && (a_rows_total < M || (a_rows_total & 31) || 3 * (size_t)a_rows_total * (size_t)K >= (1ull << 31)))
+        return scp::fail(hipErrorInvalidValue, "vit_linear: A planes need a multiple of 32 rows >= M and < 2^32 bytes");
+    if (C3 && (c_rows_total < M || (c_rows_total & 31) || (N & 15)))
+        return scp::fail(hipErrorInvalidValue, "vit_linear: output planes need a multiple of 32 rows >= M and N a multiple of 16");
     if (K % (BigCfg::NSTAGE * BigCfg::BK) != 0) return scp::fail(hipErrorInvalidValue, "vit_linear: K must be a multiple of 32");
     if ((size_t)M * (size_t)K >= (1ull << 30) || (size_t)N * (size_t)K >= (1ull << 30))
         return scp::fail(hipErrorInvalidValue, "vit_linear: operand larger than 2^30 elements");
@@ -496,6 +513,17 @@ extern "C" int scp_kernel_clock_end(void) {
     g_clock_slots = nullptr;
     g_clock_n = g_clock_i = 0;
     return used;
+}
+
+extern "C" size_t scp_split_bf16x3_tiled_elements(int rows, int K) { return (size_t)3 * ((rows + 31) / 32 * 32) * (size_t)K; }
+
+extern "C" int scp_split_bf16x3_tiled(const float* x, void* planes, int rows, int K, void* stream) {
+    if (rows <= 0) return 0;
+    if (!x || !planes || K <= 0 || (K & 15)) return scp::fail(hipErrorInvalidValue, "split_bf16x3_tiled: null argument or K not a multiple of 16");
+    const size_t n = (size_t)rows * (K >> 3);
+    hipLaunchKernelGGL(split_bf16x3_tiled_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       static_cast<__bf16*>(planes), rows, K);
+    return scp::check_launch("split_bf16x3_tiled");
 }
 
 extern "C" int scp_split_bf16x3(const float* x, void* planes, size_t n, void* stream) {

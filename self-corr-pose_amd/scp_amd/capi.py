@@ -52,6 +52,8 @@ SYMBOLS = {
     "scp_selftest_exact_division": (ctypes.c_int, [ctypes.c_ulonglong, ctypes.c_uint, _P, _P]),
     "scp_vit_linear": (ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 4 + [_P]),
     "scp_vit_linear_rows": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
+    "scp_split_bf16x3_tiled_elements": (ctypes.c_size_t, [_I, _I]),
+    "scp_split_bf16x3_tiled": (ctypes.c_int, [_P, _P, _I, _I, _P]),
     "scp_vit_linear_planes": (ctypes.c_int, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P]),
     "scp_fvm_workspace": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "scp_fvm_forward": (ctypes.c_int, [_P] * 5 + [ctypes.c_float] * 2 + [ctypes.c_int] * 5 + [_P] * 6 + [ctypes.c_size_t, _P]),

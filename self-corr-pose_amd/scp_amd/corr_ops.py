@@ -50,27 +50,26 @@ def mutual_nn_fused(keys, src_img, tgt_img, mask_down, tok0=1, planes="split"):
     """scp_mutual_nn_fused: keys [n_images, n_tok, C] fp32 token-major (DINO.key_tokens), src_img / tgt_img [N] image indices of
     the pairs, mask_down [n_images, P] (P = n_tok - tok0) or None  ->  (bw [N,P] = best source token per target token, fw [N,P] =
     best target token per source token) of the masked score matrix S = K_src K_tgt^T, which is never stored.  `planes`: "split"
-    (bf16 matrix cores on exactly split operands; the planes are made here) | "fp32" (fp32 matrix cores) | a [3, n_images * n_tok,
-    C] bfloat16 tensor the caller already holds."""
+    (bf16 matrix cores on exactly split operands; the planes are made here) | "fp32" (fp32 matrix cores) | the dino.TiledPlanes
+    [n_images * n_tok, C] of the keys the caller already holds (the K projection's epilogue writes them)."""
     L = capi.lib()
     if not (keys.is_cuda and keys.dtype == torch.float32 and keys.dim() == 3):
         raise RuntimeError("mutual_nn_fused: keys must be a CUDA float32 [n_images, n_tok, C] tensor (no CPU fallback)")
     keys = keys.detach().contiguous()
     b, n_tok, c = keys.shape
     p = n_tok - tok0
+    from .dino import TiledPlanes, split_tiled
     if isinstance(planes, str):
         if planes == "split":
-            w3 = torch.empty((3, b * n_tok, c), dtype=torch.bfloat16, device=keys.device)
-            capi.check(L.scp_split_bf16x3(capi.dev_ptr(keys, "keys"), ctypes.c_void_p(w3.data_ptr()), keys.numel(), capi.current_stream()),
-                       "scp_split_bf16x3")
+            w3 = split_tiled(keys.view(b * n_tok, c)).blob
         elif planes == "fp32":
             w3 = None
         else:
             raise RuntimeError("mutual_nn_fused: unknown mode %r" % (planes,))
     else:
-        w3 = planes
-        if not (w3.is_cuda and w3.dtype == torch.bfloat16 and w3.is_contiguous() and tuple(w3.shape) == (3, b * n_tok, c)):
-            raise RuntimeError("mutual_nn_fused: planes must be the contiguous [3, %d, %d] bfloat16 split of keys" % (b * n_tok, c))
+        if not (isinstance(planes, TiledPlanes) and (planes.rows, planes.cols) == (b * n_tok, c) and planes.blob.is_cuda):
+            raise RuntimeError("mutual_nn_fused: planes must be the TiledPlanes [%d, %d] split of keys" % (b * n_tok, c))
+        w3 = planes.blob
     si = src_img.to(device=keys.device, dtype=torch.int32).contiguous()
     ti = tgt_img.to(device=keys.device, dtype=torch.int32).contiguous()
     n = si.numel()

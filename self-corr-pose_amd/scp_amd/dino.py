@@ -196,6 +196,37 @@ def split_weight(w):
     return planes
 
 
+class TiledPlanes:
+    """a [rows, cols] fp32 operand as three bf16 planes in the TILED layout of csrc/gemm_core_split.h:
+    [ceil(rows / 32)][cols / 16][3 planes][32 rows][16 k] -- every piece an LDS-DMA instruction moves is one contiguous KiB.
+    `blob` is the flat bfloat16 storage; untile() gives the plane-major [3, rows, cols] view of it as a copy (tests)."""
+
+    def __init__(self, rows, cols, device, blob=None):
+        if cols % 16:
+            raise RuntimeError("TiledPlanes: the column count must be a multiple of 16")
+        self.rows, self.cols, self.rows_pad = rows, cols, (rows + 31) // 32 * 32
+        self.blob = blob if blob is not None else torch.empty(3 * self.rows_pad * cols, dtype=torch.bfloat16, device=device)
+
+    def zero_(self):
+        self.blob.zero_()
+        return self
+
+    def untile(self):
+        t = self.blob.view(self.rows_pad // 32, self.cols // 16, 3, 32, 16).permute(2, 0, 3, 1, 4)
+        return t.reshape(3, self.rows_pad, self.cols)[:, :self.rows].contiguous()
+
+
+def split_tiled(x):
+    """x [rows, cols] fp32 -> TiledPlanes with x = h + m + l exactly (scp_split_bf16x3_tiled)"""
+    from . import capi
+    x = x.detach().contiguous()
+    rows, cols = x.shape
+    out = TiledPlanes(rows, cols, x.device)
+    capi.check(capi.lib().scp_split_bf16x3_tiled(capi.dev_ptr(x, "x"), ctypes.c_void_p(out.blob.data_ptr()), rows, cols, capi.current_stream()),
+               "scp_split_bf16x3_tiled")
+    return out
+
+
 def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilogue=GEMM_BIAS, rows=None, a_rows=None, c_rows=None,
                max_rows=None, mode=None, w_split=None, a_planes=None, out_planes=None, fp32_out=True):
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T) on the matrix cores (csrc/vit_gemm.hip, include/scp_hip.h scp_vit_linear);
@@ -205,17 +236,18 @@ def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilog
     Row selection made on the device (scp_vit_linear_rows): `rows` = int32 device scalar, only the first rows[0] GEMM rows
     are computed and the host never reads the count; GEMM row m reads a[a_rows[m]] and uses rowstat / resid / out row
     c_rows[m] (int32 index lists, None = identity); untouched rows of `out` keep their contents.
-    Pre-split operands (split mode only, scp_vit_linear_planes): `a_planes` [3, rows, K] bfloat16 = the A operand as the producing
-    layer's epilogue left it (`a` may then be None; the main loop has no VALU split); `out_planes` [3, rows, N] bfloat16 receives the
-    result split the same way (the next layer's a_planes); `fp32_out=False` with out_planes: the fp32 result is not stored at all."""
+    Pre-split operands (split mode only, scp_vit_linear_planes): `a_planes` = TiledPlanes [rows, K], the A operand as the producing
+    layer's epilogue left it (`a` may then be None; the main loop has no VALU split; `w_split` must then be the TiledPlanes of w);
+    `out_planes` = TiledPlanes [rows, N] receives the result split the same way (the next layer's a_planes); `fp32_out=False` with
+    out_planes: the fp32 result is not stored at all."""
     from . import capi
     if torch.is_grad_enabled() and ((a is not None and a.requires_grad) or w.requires_grad):
         raise RuntimeError("scp_amd.dino.vit_linear is forward-only (frozen ViT)")
     if a is None and a_planes is None:
         raise RuntimeError("vit_linear: no A operand")
-    m, k = a.shape if a is not None else a_planes.shape[1:]
+    m, k = a.shape if a is not None else (a_planes.rows, a_planes.cols)
     n = w.shape[0]
-    dev = a.device if a is not None else a_planes.device
+    dev = a.device if a is not None else a_planes.blob.device
     if out is None and (fp32_out or out_planes is None):
         out = torch.empty(m, n, dtype=torch.float32, device=dev)
     L = capi.lib()
@@ -229,11 +261,17 @@ def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilog
         w_ptr = ctypes.c_void_p(w_split.data_ptr())
         epilogue = epilogue | GEMM_W_BF16
     elif mode == "split":
-        if w_split is None:
-            w_split = split_weight(w)
-        if not (w_split.is_cuda and w_split.dtype == torch.bfloat16 and w_split.is_contiguous() and tuple(w_split.shape) == (3, n, k)):
-            raise RuntimeError("vit_linear: w_split must be the contiguous [3,%d,%d] bfloat16 planes of w" % (n, k))
-        w_ptr = ctypes.c_void_p(w_split.data_ptr())
+        if a_planes is not None:
+            if w_split is None:
+                w_split = split_tiled(w)
+            w_ptr = None                                  # set with the other plane operands below
+        else:
+            if w_split is None:
+                w_split = split_weight(w)
+            if not (torch.is_tensor(w_split) and w_split.is_cuda and w_split.dtype == torch.bfloat16 and w_split.is_contiguous()
+                    and tuple(w_split.shape) == (3, n, k)):
+                raise RuntimeError("vit_linear: w_split must be the contiguous [3,%d,%d] bfloat16 planes of w" % (n, k))
+            w_ptr = ctypes.c_void_p(w_split.data_ptr())
         epilogue = epilogue | GEMM_W_SPLIT3
     elif mode == "fp32":
         w_ptr = capi.dev_ptr(w, "w")
@@ -243,19 +281,23 @@ def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilog
         if mode != "split":
             raise RuntimeError("vit_linear: operand planes need the split main loop (mode %r)" % (mode,))
         for t, name, cols in ((a_planes, "a_planes", k), (out_planes, "out_planes", n)):
-            if t is not None and not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.dim() == 3 and t.shape[0] == 3
-                                      and t.shape[2] == cols):
-                raise RuntimeError("vit_linear: %s must be a contiguous [3, rows, %d] bfloat16 tensor" % (name, cols))
+            if t is not None and not (isinstance(t, TiledPlanes) and t.cols == cols and t.blob.is_cuda):
+                raise RuntimeError("vit_linear: %s must be TiledPlanes with %d columns" % (name, cols))
+        if a_planes is not None:
+            if not (isinstance(w_split, TiledPlanes) and (w_split.rows, w_split.cols) == (n, k)):
+                raise RuntimeError("vit_linear: with a_planes, w_split must be split_tiled(w)")
+            w_ptr = ctypes.c_void_p(w_split.blob.data_ptr())
         for t, name in ((rows, "rows"), (a_rows, "a_rows"), (c_rows, "c_rows")):
             if t is not None and not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
                 raise RuntimeError("vit_linear: %s must be a contiguous int32 device tensor" % name)
         ip = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+        bp = lambda t: ctypes.c_void_p(0 if t is None else t.blob.data_ptr())
         if rows is not None and max_rows is None:
             max_rows = m
-        code = L.scp_vit_linear_planes(ip(a if a_planes is None else None), ip(a_planes), 0 if a_planes is None else a_planes.shape[1], w_ptr,
+        code = L.scp_vit_linear_planes(ip(a if a_planes is None else None), bp(a_planes), 0 if a_planes is None else a_planes.rows_pad, w_ptr,
                                        capi.dev_ptr(vec0, "vec0"), capi.opt_ptr(vec1, "vec1"), capi.opt_ptr(rowstat, "rowstat"),
-                                       capi.opt_ptr(resid, "resid"), ip(out), ip(out_planes),
-                                       0 if out_planes is None else out_planes.shape[1], ip(rows), m if rows is None else max_rows,
+                                       capi.opt_ptr(resid, "resid"), ip(out), bp(out_planes),
+                                       0 if out_planes is None else out_planes.rows_pad, ip(rows), m if rows is None else max_rows,
                                        ip(a_rows), ip(c_rows), n, k, epilogue, capi.current_stream())
         capi.check(code, "scp_vit_linear_planes")
         return out
@@ -329,6 +371,9 @@ class _Block(nn.Module):
                 if gemm_mode() == "split" and wq.is_cuda:
                     self._planes = dict(qkv=split_weight(wq), k=split_weight(wq[c:2 * c]), fc1=split_weight(w1),
                                         proj=split_weight(self.attn.proj.weight), fc2=split_weight(self.mlp.fc2.weight))
+                    if PRESPLIT_ACTIVATIONS:     # tiled planes: the W operand of the layers whose A operand arrives pre-split
+                        self._planes.update(qkv_t=split_tiled(wq), k_t=split_tiled(wq[c:2 * c].contiguous()), fc1_t=split_tiled(w1),
+                                            fc2_t=split_tiled(self.mlp.fc2.weight))
                 elif gemm_mode() == "bf16" and wq.is_cuda:
                     rnd = lambda t: t.detach().to(torch.bfloat16).contiguous()
                     self._planes = dict(qkv=rnd(wq), k=rnd(wq[c:2 * c]), fc1=rnd(w1), proj=rnd(self.attn.proj.weight),
@@ -349,16 +394,16 @@ class _Block(nn.Module):
         a = self.attn
         sp = self._planes
         pl = x3 is not None and gemm_mode() == "split"
-        qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN, w_split=sp["qkv"],
+        qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN, w_split=sp["qkv_t" if pl else "qkv"],
                          a_planes=x3 if pl else None)
         y = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, x2d.shape[1] // a.num_heads, a.scale)
         vit_linear(y.view(b * n, -1), a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["proj"],
                    out_planes=x3 if pl else None)
         if pl:
-            h3 = torch.empty(3, b * n, w1.shape[0], dtype=torch.bfloat16, device=x2d.device)
-            vit_linear(None, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), epilogue=GEMM_LN_GELU, w_split=sp["fc1"], a_planes=x3,
+            h3 = TiledPlanes(b * n, w1.shape[0], x2d.device)
+            vit_linear(None, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), epilogue=GEMM_LN_GELU, w_split=sp["fc1_t"], a_planes=x3,
                        out_planes=h3, fp32_out=False)
-            vit_linear(None, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["fc2"],
+            vit_linear(None, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["fc2_t"],
                        a_planes=h3, out_planes=x3)
             return x2d
         h = vit_linear(x2d, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), epilogue=GEMM_LN_GELU, w_split=sp["fc1"])
@@ -379,7 +424,7 @@ class _Block(nn.Module):
         c = x2d.shape[1]
         sp = self._planes
         pl = x3 is not None and gemm_mode() == "split"
-        qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN, w_split=sp["qkv"],
+        qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN, w_split=sp["qkv_t" if pl else "qkv"],
                          a_planes=x3 if pl else None)
         # attention: keys / values of all tokens, queries only for the kept ones (per image, compacted to the front of the
         # query slots; their outputs land on their own rows)
@@ -399,14 +444,14 @@ class _Block(nn.Module):
         (kq, ks, kt), _ = key_block._folded()
         k = torch.zeros(m, c, dtype=torch.float32, device=x2d.device)
         if pl:
-            h3 = torch.empty(3, m, w1.shape[0], dtype=torch.bfloat16, device=x2d.device)     # only the kept rows are written / read
-            vit_linear(None, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), epilogue=GEMM_LN_GELU, w_split=sp["fc1"], a_planes=x3,
+            h3 = TiledPlanes(m, w1.shape[0], x2d.device)                                       # only the kept rows are written / read
+            vit_linear(None, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), epilogue=GEMM_LN_GELU, w_split=sp["fc1_t"], a_planes=x3,
                        out_planes=h3, fp32_out=False, **sel)
-            vit_linear(None, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["fc2"],
+            vit_linear(None, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["fc2_t"],
                        a_planes=h3, out_planes=x3, **sel)
-            k3 = torch.zeros(3, m, c, dtype=torch.bfloat16, device=x2d.device)
+            k3 = TiledPlanes(m, c, x2d.device).zero_()
             vit_linear(None, kq[c:2 * c], ks[c:2 * c], kt[c:2 * c], row_mean_rstd(x2d, key_block.norm1.eps), out=k, epilogue=GEMM_LN,
-                       w_split=key_block._planes["k"], a_planes=x3, out_planes=k3, **sel)
+                       w_split=key_block._planes["k_t"], a_planes=x3, out_planes=k3, **sel)
             k = k.view(b, n, c)
             k._scp_planes = k3
             return k
@@ -422,9 +467,9 @@ class _Block(nn.Module):
         (wq, sq, tq), _ = self._folded()
         c = x2d.shape[1]
         pl = x3 is not None and gemm_mode() == "split"
-        k3 = torch.empty(3, b * n, c, dtype=torch.bfloat16, device=x2d.device) if pl else None
+        k3 = TiledPlanes(b * n, c, x2d.device) if pl else None
         k = vit_linear(None if pl else x2d, wq[c:2 * c], sq[c:2 * c], tq[c:2 * c], row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN,
-                       w_split=self._planes["k"], a_planes=x3 if pl else None, out_planes=k3)
+                       w_split=self._planes["k_t" if pl else "k"], a_planes=x3 if pl else None, out_planes=k3)
         k = k.view(b, n, c)
         if pl:
             k._scp_planes = k3
@@ -497,7 +542,7 @@ class VisionTransformer(nn.Module):
             b, n, c = tok.shape
             x2d = tok.view(b * n, c)
             # split main loop: the residual stream also lives as bf16 planes, the pre-split A operand of the layers that read it
-            x3 = split_weight(x2d) if (gemm_mode() == "split" and PRESPLIT_ACTIVATIONS) else None
+            x3 = split_tiled(x2d) if (gemm_mode() == "split" and PRESPLIT_ACTIVATIONS) else None
             if keep is not None and layer >= 1:
                 for blk in self.blocks[:layer - 1]:
                     blk.forward_fused(x2d, b, n, x3)

@@ -79,9 +79,24 @@ def split_planes(t):
     return planes
 
 
+def tiled_planes_numel(rows, k):
+    return 3 * ((rows + 31) // 32 * 32) * k
+
+
+def split_planes_tiled(t):
+    """the W operand of the split convolution kernels from a weight already in [rows, ...K] order (e.g. [Cout, k, k, Cin]): flat
+    bf16 storage in the TILED plane layout (csrc/gemm_core_split.h; scp_split_bf16x3_tiled)"""
+    rows = t.shape[0]
+    k = t.numel() // rows
+    planes = torch.empty(tiled_planes_numel(rows, k), dtype=torch.bfloat16, device=t.device)
+    capi.check(capi.lib().scp_split_bf16x3_tiled(_ptr(t.contiguous()), _ptr(planes), rows, k, capi.current_stream()), "split_bf16x3_tiled")
+    return planes
+
+
 def weight_planes(conv, with_dgrad):
     """The split operands of a convolution's weight for this weight version, kept on the module: "fwd" = planes of
-    [Cout, k, k, Cin], "dgrad" = planes of the flipped / transposed [Cin, k, k, Cout] the input gradient multiplies with.
+    [Cout, k, k, Cin], "dgrad" = planes of the flipped / transposed [Cin, k, k, Cout] the input gradient multiplies with, both in the
+    tiled plane layout (flat bf16 storage).
     Both encoder passes of a step (and their backward passes) share them.  The buffers are PERSISTENT (their addresses are baked into
     the HIP graphs of scp_amd.graphed) and rebuilt IN PLACE when the weight has changed: lazily here, keyed by (storage, tensor
     version, WEIGHT_EPOCH), or eagerly by refresh_planes(), which Trainer.step calls once per step on the main stream before any side
@@ -98,10 +113,10 @@ def weight_planes(conv, with_dgrad):
             raise RuntimeError("scp_amd.fused_conv: weight planes are stale under graph capture -- call refresh_planes() first")
         cout, cin, k, _ = w.shape
         if "fwd" not in cache:
-            cache["fwd"] = torch.empty(3, cout, k, k, cin, dtype=torch.bfloat16, device=w.device)
+            cache["fwd"] = torch.empty(tiled_planes_numel(cout, k * k * cin), dtype=torch.bfloat16, device=w.device)
         build_dgrad = with_dgrad or "dgrad" in cache
         if build_dgrad and "dgrad" not in cache:
-            cache["dgrad"] = torch.empty(3, cin, k, k, cout, dtype=torch.bfloat16, device=w.device)
+            cache["dgrad"] = torch.empty(tiled_planes_numel(cin, k * k * cout), dtype=torch.bfloat16, device=w.device)
         wd = w.detach()
         # one launch fills both plane sets (a "fwd" set that is current is rewritten with the values it already holds)
         capi.check(capi.lib().scp_conv_weight_planes(ctypes.c_void_p(wd.data_ptr()), wd.stride(0), wd.stride(1), wd.stride(2), wd.stride(3),

@@ -85,7 +85,7 @@ def mutual_nn_pairs(keys, src_img, tgt_img, mask_down, tok0=1):
     planes = getattr(keys, "_scp_planes", None)            # left by the K projection's epilogue (scp_amd/dino.py) when it pre-splits
     if mode == "fp32":
         planes = "fp32"
-    elif planes is None or tuple(planes.shape) != (3, keys.shape[0] * keys.shape[1], keys.shape[2]):
+    elif planes is None or (planes.rows, planes.cols) != (keys.shape[0] * keys.shape[1], keys.shape[2]):
         planes = "split"
     return corr_ops.mutual_nn_fused(keys, src_img, tgt_img, mask_down, tok0, planes)
 

@@ -31,7 +31,7 @@ def conv_core(request):
 def _conv(x_nhwc, w_khwc, bias=None, stride=1, leaky=False, slope=0.1, partials=False):
     from scp_amd import capi, fused_conv
     L = capi.lib()
-    w3 = fused_conv.split_planes(w_khwc) if CORE == "split" else None
+    w3 = fused_conv.split_planes_tiled(w_khwc) if CORE == "split" else None
     n, h, w, cin = x_nhwc.shape
     cout, k = w_khwc.shape[0], w_khwc.shape[1]
     ho = (h + 2 * (k // 2) - k) // stride + 1

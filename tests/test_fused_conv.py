@@ -182,7 +182,10 @@ def test_weight_planes_kernel_equals_the_torch_composition():
         finally:
             fused_conv.CONV_MODE = old
         w = conv.weight.detach()
-        ref_f = fused_conv.split_planes(w.permute(0, 2, 3, 1).contiguous())
-        ref_d = fused_conv.split_planes(w.flip(2, 3).permute(1, 2, 3, 0).contiguous())
+        ref_f = fused_conv.split_planes_tiled(w.permute(0, 2, 3, 1).contiguous())
+        ref_d = fused_conv.split_planes_tiled(w.flip(2, 3).permute(1, 2, 3, 0).contiguous())
         assert torch.equal(cache["fwd"], ref_f) and torch.equal(cache["dgrad"], ref_d)
-        assert torch.equal(cache["fwd"].double().sum(0), w.permute(0, 2, 3, 1).double())
+        # tiled layout [rows / 32][K / 16][3][32][16] -> plane-major: the planes sum back to the weight exactly
+        from scp_amd.dino import TiledPlanes
+        planes = TiledPlanes(96, 9 * 64, "cuda", blob=cache["fwd"]).untile()
+        assert torch.equal(planes.double().sum(0).reshape(96, 3, 3, 64), w.permute(0, 2, 3, 1).double())

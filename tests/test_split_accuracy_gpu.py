@@ -127,7 +127,7 @@ def _conv(x_nhwc, w_khwc, core, partials=False):
     from scp_amd import capi, fused_conv
     L = capi.lib()
     split = core == "split"
-    w3 = fused_conv.split_planes(w_khwc) if split else None
+    w3 = fused_conv.split_planes_tiled(w_khwc) if split else None
     n, h, w, cin = x_nhwc.shape
     cout, k = w_khwc.shape[0], w_khwc.shape[1]
     y = torch.empty(n, h, w, cout, device="cuda")

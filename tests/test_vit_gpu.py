@@ -213,12 +213,12 @@ def test_fused_block_matches_oracle(B, N, gemm_mode):
             # the same with pre-split activations: planes in step with the fp32 residual stream, same tolerance, and the planes the
             # block leaves equal its fp32 result exactly
             x2 = x.view(B * N, 384).clone()
-            x3 = dino.split_weight(x2)
+            x3 = dino.split_tiled(x2)
             kp = blk.keys_fused(x2.clone(), B, N, x3)
-            assert torch.equal(kp._scp_planes.float().double().sum(0), kp.view(B * N, 384).double())
+            assert torch.equal(kp._scp_planes.untile().float().double().sum(0), kp.view(B * N, 384).double())
             got_kp = kp.view(B, N, 6, 64).permute(0, 2, 1, 3).cpu().double()
             got_p = blk.forward_fused(x2, B, N, x3).view(B, N, 384)
-            assert torch.equal(x3.float().double().sum(0), x2.double())
+            assert torch.equal(x3.untile().float().double().sum(0), x2.double())
             for g_, r_ in ((got_p.cpu().double(), ref), (got_kp, ref_k)):
                 assert (g_ - r_).abs().max().item() <= 2e-5 * r_.abs().max().item()
     for name, g_, r_ in (("block", got, ref), ("keys", got_k, ref_k)):
@@ -255,9 +255,10 @@ def test_split_path_is_as_accurate_as_the_fp32_cores():
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,K,N", [(1025 * 2 + 37, 384, 1152), (700, 1536, 384), (33 * 256 + 5, 384, 384)])
 def test_vit_linear_with_presplit_operands(M, K, N):
-    """scp_vit_linear_planes (round 4): A given as bf16 planes (no VALU split in the main loop) and / or the result written as
-    planes by the epilogue.  Against float64 with the tolerance of the fp32-A path; the planes written equal the fp32 result
-    EXACTLY (h + m + l == x); fp32_out=False leaves only planes; every epilogue; row-index lists address planes and fp32 alike."""
+    """scp_vit_linear_planes (round 4): A given as TILED bf16 planes (no VALU split in the main loop, every LDS-DMA piece one
+    contiguous KiB) and / or the result written as tiled planes by the epilogue.  Against float64 with the tolerance of the fp32-A
+    path; the planes written equal the fp32 result EXACTLY (h + m + l == x); fp32_out=False leaves only planes; every epilogue;
+    row-index lists address planes and fp32 alike."""
     from scp_amd import dino
     g = torch.Generator().manual_seed(M + K)
     a = (torch.randn(M, K, generator=g) * 1.3 + 0.2).cuda()
@@ -265,8 +266,8 @@ def test_vit_linear_with_presplit_operands(M, K, N):
     v0, v1 = (torch.randn(N, generator=g) * 0.1).cuda(), (torch.randn(N, generator=g) * 0.1).cuda()
     st = (torch.rand(M, 2, generator=g) + 0.5).cuda()
     res = torch.randn(M, N, generator=g).cuda()
-    a3, w3 = dino.split_weight(a), dino.split_weight(w)
-    assert torch.equal(a3.float().double().sum(0), a.double())
+    a3, w3t, w3 = dino.split_tiled(a), dino.split_tiled(w), dino.split_weight(w)
+    assert torch.equal(a3.untile().float().double().sum(0), a.double()) and torch.equal(a3.untile(), dino.split_weight(a))
     z = a.double() @ w.double().t()
     ln = st[:, 1:2].double() * (z - st[:, 0:1].double() * v0.double()) + v1.double()
     cases = {dino.GEMM_BIAS: z + v0.double(), dino.GEMM_BIAS_RESIDUAL: z + v0.double() + res.double(), dino.GEMM_LN: ln,
@@ -274,32 +275,33 @@ def test_vit_linear_with_presplit_operands(M, K, N):
     for epi, ref in cases.items():
         lnk = epi in (dino.GEMM_LN, dino.GEMM_LN_GELU)
         kw = dict(vec1=v1 if lnk else None, rowstat=st if lnk else None, resid=res if epi == dino.GEMM_BIAS_RESIDUAL else None,
-                  epilogue=epi, w_split=w3, mode="split")
+                  epilogue=epi, mode="split")
         scale = ref.abs().max().item()
-        o3 = torch.full((3, M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-        got = dino.vit_linear(None, w, v0, a_planes=a3, out_planes=o3, **kw)
+        o3 = dino.TiledPlanes(M, N, "cuda")
+        o3.blob.fill_(float("nan"))
+        got = dino.vit_linear(None, w, v0, a_planes=a3, out_planes=o3, w_split=w3t, **kw)
         assert (got.double() - ref).abs().max().item() <= 1e-5 * max(scale, 1.0), epi
-        assert torch.equal(o3.float().double().sum(0), got.double()), "planes must add up to the fp32 result exactly"
-        o3b = torch.full((3, M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-        none = dino.vit_linear(None, w, v0, a_planes=a3, out_planes=o3b, fp32_out=False, **kw)
-        assert none is None and torch.equal(o3b, o3)
-        # planes out from an fp32 A (the proj layer's case) and planes in with fp32 out only (the qkv layer's case)
-        o3c = torch.empty_like(o3)
-        got_c = dino.vit_linear(a, w, v0, out_planes=o3c, **kw)
-        assert torch.equal(o3c.float().double().sum(0), got_c.double())
+        assert torch.equal(o3.untile().float().double().sum(0), got.double()), "planes must add up to the fp32 result exactly"
+        o3b = dino.TiledPlanes(M, N, "cuda")
+        none = dino.vit_linear(None, w, v0, a_planes=a3, out_planes=o3b, fp32_out=False, w_split=w3t, **kw)
+        assert none is None and torch.equal(o3b.untile(), o3.untile())
+        # planes out from an fp32 A (the proj layer's case: plane-major W planes)
+        o3c = dino.TiledPlanes(M, N, "cuda")
+        got_c = dino.vit_linear(a, w, v0, out_planes=o3c, w_split=w3, **kw)
+        assert torch.equal(o3c.untile().float().double().sum(0), got_c.double())
         assert (got_c.double() - ref).abs().max().item() <= 1e-5 * max(scale, 1.0)
     # row selection: GEMM row m reads A-plane row idx[m] and writes fp32 / plane row idx[m]; the rest stays untouched
     keep = torch.rand(M, generator=g) < 0.4
     idx = torch.argsort(keep.to(torch.uint8), descending=True, stable=True).to(torch.int32).cuda()
     rows = keep.sum(dtype=torch.int32).reshape(1).cuda()
-    full3 = torch.empty(3, M, N, dtype=torch.bfloat16, device="cuda")
-    full = dino.vit_linear(None, w, v0, a_planes=a3, out_planes=full3, resid=res, epilogue=dino.GEMM_BIAS_RESIDUAL, w_split=w3, mode="split")
-    out, out3 = res.clone(), torch.zeros(3, M, N, dtype=torch.bfloat16, device="cuda")
-    dino.vit_linear(None, w, v0, a_planes=a3, out_planes=out3, resid=out, out=out, epilogue=dino.GEMM_BIAS_RESIDUAL, w_split=w3, mode="split",
+    full3 = dino.TiledPlanes(M, N, "cuda")
+    full = dino.vit_linear(None, w, v0, a_planes=a3, out_planes=full3, resid=res, epilogue=dino.GEMM_BIAS_RESIDUAL, w_split=w3t, mode="split")
+    out, out3 = res.clone(), dino.TiledPlanes(M, N, "cuda").zero_()
+    dino.vit_linear(None, w, v0, a_planes=a3, out_planes=out3, resid=out, out=out, epilogue=dino.GEMM_BIAS_RESIDUAL, w_split=w3t, mode="split",
                     rows=rows, a_rows=idx, c_rows=idx, max_rows=M)
     keep = keep.cuda()
     assert torch.equal(out[keep], full[keep]) and torch.equal(out[~keep], res[~keep])
-    assert torch.equal(out3[:, keep], full3[:, keep]) and bool((out3[:, ~keep] == 0).all())
+    assert torch.equal(out3.untile()[:, keep], full3.untile()[:, keep]) and bool((out3.untile()[:, ~keep] == 0).all())
 
 
 @pytest.mark.gpu

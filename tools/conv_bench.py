@@ -58,7 +58,7 @@ for name, cin, cout, k, s, h, cnt in LAYERS:
     xn, wn, gn = x.detach().permute(0, 2, 3, 1), w.detach().permute(0, 2, 3, 1), g.permute(0, 2, 3, 1)      # NHWC views of the same storage
     assert xn.is_contiguous() and wn.is_contiguous() and gn.is_contiguous()
     if k in (1, 3) and cin >= 32:
-        wn3 = fused_conv.split_planes(wn) if SPLIT else None
+        wn3 = fused_conv.split_planes_tiled(wn) if SPLIT else None
         skf, skf_b = fused_conv._splitk(B, h, h, cin, cout, k, s, SPLIT, "cuda")
         yo = torch.empty(B, ho, ho, cout, device="cuda")
         of = t(lambda: capi.check(L.scp_conv_nhwc_forward(P(xn), P(None if SPLIT else wn), P(wn3), P(None), P(yo), P(None), B, h, h, cin, cout, k, s, 0, 0.0, P(skf), skf_b,
@@ -66,7 +66,7 @@ for name, cin, cout, k, s, h, cnt in LAYERS:
         assert (yo - y.detach().permute(0, 2, 3, 1)).abs().max() <= 2e-4 * y.abs().max()
         if s == 1:
             wt = w.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous()
-            wt3 = fused_conv.split_planes(wt) if SPLIT else None
+            wt3 = fused_conv.split_planes_tiled(wt) if SPLIT else None
             skd, skd_b = fused_conv._splitk(B, h, h, cout, cin, k, 1, SPLIT, "cuda")
             dxo = torch.empty(B, h, h, cin, device="cuda")
             od = t(lambda: capi.check(L.scp_conv_nhwc_forward(P(gn), P(None if SPLIT else wt), P(wt3), P(None), P(dxo), P(None), B, h, h, cout, cin, k, 1, 0, 0.0, P(skd), skd_b,

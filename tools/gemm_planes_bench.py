@@ -39,15 +39,15 @@ for name, K, N, epi, a_pl, out_pl, fp32_out in (("qkv  LN", 384, 1152, dino.GEMM
     v1 = torch.randn(N, device="cuda", generator=g) * 0.1
     st = torch.rand(M, 2, device="cuda", generator=g) + 0.5
     resid = torch.randn(M, N, device="cuda", generator=g)
-    w3, a3 = dino.split_weight(W), dino.split_weight(A)
-    o3 = torch.empty(3, M, N, dtype=torch.bfloat16, device="cuda")
+    w3, w3t, a3 = dino.split_weight(W), dino.split_tiled(W), dino.split_tiled(A)
+    o3 = dino.TiledPlanes(M, N, "cuda")
     out = torch.empty(M, N, device="cuda")
     ln = epi in (dino.GEMM_LN, dino.GEMM_LN_GELU)
     kw = dict(vec1=v1 if ln else None, rowstat=st if ln else None, resid=resid if epi == dino.GEMM_BIAS_RESIDUAL else None, epilogue=epi,
-              w_split=w3, mode="split")
-    regs = lambda: dino.vit_linear(A, W, v0, out=out, **kw)
+              mode="split")
+    regs = lambda: dino.vit_linear(A, W, v0, out=out, w_split=w3, **kw)
     planes = lambda: dino.vit_linear(None if a_pl else A, W, v0, out=out if fp32_out else None, a_planes=a3 if a_pl else None,
-                                     out_planes=o3 if out_pl else None, fp32_out=fp32_out, **kw)
+                                     out_planes=o3 if out_pl else None, fp32_out=fp32_out, w_split=w3t if a_pl else w3, **kw)
     regs()
     ref_out = out.clone()
     out.zero_()
@@ -61,10 +61,10 @@ for name, K, N, epi, a_pl, out_pl, fp32_out in (("qkv  LN", 384, 1152, dino.GEMM
     else:
         exact = z + v0.double() + resid[:2048].double()
     scale = exact.abs().max().item()
-    got = (o3[:, :2048].double().sum(0) if not fp32_out else out[:2048].double())
+    got = (o3.untile()[:, :2048].double().sum(0) if not fp32_out else out[:2048].double())
     err_p = (got - exact).abs().max().item() / scale
     err_r = (ref_out[:2048].double() - exact).abs().max().item() / scale
-    consistent = bool(torch.equal(o3.float().double().sum(0), out.double())) if (out_pl and fp32_out) else None
+    consistent = bool(torch.equal(o3.untile().float().double().sum(0), out.double())) if (out_pl and fp32_out) else None
     t_r, t_p = timeit(regs), timeit(planes)
     fl = 2.0 * M * N * K
     tot["regs"] += t_r
