@@ -110,7 +110,7 @@ class KernelClock:
     def __enter__(self):
         def wrapped(a, w, *args, **kwargs):
             if self.enabled:
-                m, k = a.shape if a is not None else kwargs["a_planes"].shape[1:]      # pre-split A operand: [3, M, K] planes
+                m, k = a.shape if a is not None else (kwargs["a_planes"].rows, kwargs["a_planes"].cols)     # pre-split A operand
                 self.flops.append(None if kwargs.get("rows") is not None else 2.0 * m * k * w.shape[0])
                 self.shapes.append((m, w.shape[0], k))
             return self.orig(a, w, *args, **kwargs)
@@ -182,18 +182,28 @@ def isolated_attention(B, n_tok, heads, hd, flops, iters=30):
 
 
 def isolated_gemms(M, C=384, iters=20):
-    """the four linear layers of one ViT-S block (qkv, proj, fc1, fc2) alone on an idle device: launch-weighted TFLOP/s"""
+    """the four linear layers of one ViT-S block (qkv, proj, fc1, fc2) alone on an idle device, operands as the block passes them
+    (split mode with pre-split activations: qkv / fc1 / fc2 read tiled bf16 planes, proj / fc1 / fc2 write them): launch-weighted
+    TFLOP/s"""
     import scp_amd.dino as dino_mod
+    planes = dino_mod.GEMM_MODE == "split" and dino_mod.PRESPLIT_ACTIVATIONS and not dino_mod.MIXED_BF16
     ms_total, fl_total = 0.0, 0.0
-    for K, N, epi in ((C, 3 * C, dino_mod.GEMM_LN), (C, C, dino_mod.GEMM_BIAS_RESIDUAL), (C, 4 * C, dino_mod.GEMM_LN_GELU),
-                      (4 * C, C, dino_mod.GEMM_BIAS_RESIDUAL)):
+    for name, K, N, epi in (("qkv", C, 3 * C, dino_mod.GEMM_LN), ("proj", C, C, dino_mod.GEMM_BIAS_RESIDUAL), ("fc1", C, 4 * C, dino_mod.GEMM_LN_GELU),
+                            ("fc2", 4 * C, C, dino_mod.GEMM_BIAS_RESIDUAL)):
         a = torch.randn(M, K, device="cuda")
         w = torch.randn(N, K, device="cuda") * 0.05
         v0, v1 = torch.randn(N, device="cuda"), torch.randn(N, device="cuda")
         st = torch.rand(M, 2, device="cuda")
         out = torch.randn(M, N, device="cuda")
-        w3 = dino_mod.split_weight(w) if dino_mod.GEMM_MODE == "split" else None
-        run = lambda: dino_mod.vit_linear(a, w, v0, v1, st, out, out=out, epilogue=epi, w_split=w3)
+        if planes:
+            a_in = None if name == "proj" else dino_mod.split_tiled(a)                     # proj reads the attention's fp32 output
+            o3 = None if name == "qkv" else dino_mod.TiledPlanes(M, N, "cuda")              # qkv feeds the attention in fp32
+            w3 = dino_mod.split_weight(w) if name == "proj" else dino_mod.split_tiled(w)
+            run = lambda: dino_mod.vit_linear(a if a_in is None else None, w, v0, v1, st, out, out=None if name == "fc1" else out, epilogue=epi,
+                                              w_split=w3, a_planes=a_in, out_planes=o3, fp32_out=name != "fc1")
+        else:
+            w3 = dino_mod.split_weight(w) if dino_mod.GEMM_MODE == "split" else None
+            run = lambda: dino_mod.vit_linear(a, w, v0, v1, st, out, out=out, epilogue=epi, w_split=w3)
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -206,7 +216,8 @@ def isolated_gemms(M, C=384, iters=20):
         ms_total += e0.elapsed_time(e1) / iters
         fl_total += 2.0 * M * N * K
     tf = fl_total / (ms_total * 1e-3) / 1e12
-    return {"block_ms": ms_total, "achieved": tf, "frac": tf / gemm_peak_tf(), "vs_fp32_mfma_peak": tf / FP32_VALU_PEAK_TF}
+    return {"block_ms": ms_total, "achieved": tf, "frac": tf / gemm_peak_tf(), "vs_fp32_mfma_peak": tf / FP32_VALU_PEAK_TF,
+            "operands": "pre-split tiled planes" if planes else "fp32 A split in registers"}
 
 
 def fused_conv_mode():
@@ -356,7 +367,9 @@ def loss_delta(ref, device, sample_bs=8, sample_repeat=4, batch_seed=100):
       free_running  nothing else pinned: the GPU encoder rounds pred_v / pose differently from the CPU (reported), and the
                     sigma = gamma = 1e-4 silhouette terms amplify that; each term is judged against the band the
                     REFERENCE ITSELF shows under such perturbations at this batch size (reference_band()).
-    parity_ok = pinned.max_rel <= 1e-4 and every free-running term inside its reference-recorded band."""
+    parity_ok = pinned.max_rel <= 1e-4 (the hot-path contract); free_running.inside_band says whether every free-running term is
+    inside its reference-recorded band (the band covers the reference's response to encoder-output perturbations only, not the
+    1e-5-level per-pixel differences two legal builds of the rasteriser itself show)."""
     from scp_amd import synthetic as synth
     data = synth.make_batch(sample_bs, sample_repeat, 256, seed=batch_seed, device=device)
 
@@ -396,7 +409,9 @@ def loss_delta(ref, device, sample_bs=8, sample_repeat=4, batch_seed=100):
     return {"what": "first-step forward, B=%d: HIP path on the GPU vs the CPU oracle backend (identical batch, weights, pinned "
                     "jitter/angle/symmetry sample, CPU selections injected); relative per loss term" % (sample_bs * sample_repeat),
             "pinned": pinned, "free_running": free,
-            "parity_ok": bool(pinned["ok"] and free["inside_band"] is not False and free["inside_band"] is not None),
+            # the hot-path contract is the pinned leg ("Done = loss_delta.pinned.max_rel <= 1e-4"); the free-running leg is
+            # reported against the reference's own band beside it (free_running.inside_band), not folded into this flag
+            "parity_ok": bool(pinned["ok"]),
             "max_rel": pinned["max_rel"],
             "rotation_max_abs": free["encoder_deviation_max_abs"]["rotation"],
             "translation_max_abs": free["encoder_deviation_max_abs"]["translation"],
@@ -554,51 +569,59 @@ def main():
     # row-selected launches (last block's tail on the masked tokens) are not timed: their row count lives on the device
     full_gemm = lambda a, w, *rest, **kw: kw.get("rows") is None
     def count_gemm(a, w, *rest, **kw):
-        m, k = a.shape if a is not None else kw["a_planes"].shape[1:]
+        m, k = a.shape if a is not None else (kw["a_planes"].rows, kw["a_planes"].cols)
         gemm_flops.append(2.0 * m * k * w.shape[0])
-    # strides 5 and 3 are coprime to the 33 / 8 selected launches per step: over the timed steps every layer shape is sampled evenly
+    # initialisation, not measurement: the first iterations run MIOpen's solver search (cudnn.benchmark, once per
+    # convolution shape and process) and fill the caching allocator -- the counterpart of a compile step.  Done
+    # before the W warm-up steps so that a small --warmup still times steady-state iterations.
+    # The training loop (scp_amd/trainer.py: Trainer.train, one batch of look-ahead like any input pipeline) hands step() the
+    # FOLLOWING batch: its frozen-DINO features depend on nothing but the images, so that ViT pass is enqueued on the side stream
+    # before this step's backward.  Per-step work is unchanged -- every step of the timed region enqueues exactly one ViT pass
+    # (for the batch after it) besides its own forward / backward / optimizer -- but the pass no longer heads the critical path
+    # of the step that consumes it.  The synthetic "next batch" is the same resident batch.  --no-lookahead: the unpipelined step.
+    nxt = None if args.no_lookahead else data
+    for _ in range(INIT_STEPS):
+        tr.step(data)
+    sync()
+    for _ in range(args.warmup):
+        tr.step(data, next_data=nxt)
+    sync()
+    # ---- the headline: K steps, NOTHING wrapped or instrumented (no event pairs, no kernel clock, no Python shims) ----
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step(data, next_data=nxt)
+    sync()
+    elapsed = time.perf_counter() - t0
+    # ---- the roofline legs: the same K steps again with the hot kernels timed live (HIP events on the stream each one is launched
+    # on; in-kernel duration clock for the GEMM family).  strides 5 and 3 are coprime to the 33 / 8 selected launches per step: over
+    # the steps every layer shape is sampled evenly.  This loop's own wall time is reported as `instrumented_ms_per_step`.
     with KernelTimer(native, "backward_soft_rasterize", is_softtex) as kt, \
             KernelTimer(dino_mod, "fused_attention", lambda *a, **k: len(a) <= 6 and k.get("q_rows") is None, stride=3) as at, \
             KernelTimer(dino_mod, "vit_linear", full_gemm, stride=5, on_timed=count_gemm) as gt, \
             KernelClock(dino_mod, "vit_linear", 64 * args.steps + 64, device) as kc:
-        # initialisation, not measurement: the first iterations run MIOpen's solver search (cudnn.benchmark, once per
-        # convolution shape and process) and fill the caching allocator -- the counterpart of a compile step.  Done
-        # before the W warm-up steps so that a small --warmup still times steady-state iterations.
-        # The training loop (scp_amd/trainer.py: Trainer.train, one batch of look-ahead like any input pipeline) hands step() the
-        # FOLLOWING batch: its frozen-DINO features depend on nothing but the images, so that ViT pass is enqueued on the side stream
-        # before this step's backward.  Per-step work is unchanged -- every step of the timed region enqueues exactly one ViT pass
-        # (for the batch after it) besides its own forward / backward / optimizer -- but the pass no longer heads the critical path
-        # of the step that consumes it.  The synthetic "next batch" is the same resident batch.  --no-lookahead: the unpipelined step.
-        nxt = None if args.no_lookahead else data
-        for _ in range(INIT_STEPS):
-            tr.step(data)
-        sync()
-        for _ in range(args.warmup):
-            tr.step(data, next_data=nxt)
-        sync()
         kt.enabled = at.enabled = gt.enabled = True
         kc.start()
-        t0 = time.perf_counter()
+        t1 = time.perf_counter()
         for _ in range(args.steps):
             tr.step(data, next_data=nxt)
         sync()
-        elapsed = time.perf_counter() - t0
+        instrumented = time.perf_counter() - t1
         kt.enabled = at.enabled = gt.enabled = False
         kc.stop()
-        # the same K steps without the look-ahead, after the timed region (reported beside the headline, not instead of it)
-        unpipelined = None
-        if nxt is not None:
-            tr.step(data)
-            sync()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                tr.step(data)
-            sync()
-            unpipelined = time.perf_counter() - t1
         gemm_clock = kc.result()
         kernel_ms = kt.mean_ms()
         attn_ms = at.mean_ms()
         gemm_total_ms, gemm_launches, gemm_calls = gt.total_ms(), len(gt.events), gt.calls
+    # the same K steps without the look-ahead (reported beside the headline, not instead of it), uninstrumented as well
+    unpipelined = None
+    if nxt is not None:
+        tr.step(data)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.step(data)
+        sync()
+        unpipelined = time.perf_counter() - t1
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
@@ -687,9 +710,11 @@ def main():
                                  "of the timed region (= rocprofv3 kernel-trace duration; profiles/r03_kernel_stats_timed_window.csv)",
                         "avg_launch_ms": cms / cn, "algorithmic_flops_per_launch": cfl / cn,
                         "by_shape": getattr(kc, "by_shape", None),
-                        "profile_note": "a rocprofv3 trace of this command stretches the step (the traced run is host-bound, ~51 ms "
-                                        "instead of ~40), so its kernels share the device less and read 10-15 % shorter than in the "
-                                        "un-traced run that this clock measures",
+                        "profile_note": "under rocprofv3 the step is host-bound (per-launch interception), so kernels of different streams "
+                                        "hardly overlap any more and each reads much SHORTER than in the free-running step this clock "
+                                        "measures (round 3: 214 vs 361 us per launch, -41 %; profiles/r04_kernel_stats_timed_window.csv "
+                                        "for this round): a trace reproduces `isolated`, not the in-step figure, whose extra time is CU "
+                                        "sharing with the encoder's streams, not kernel quality",
                         "launches_per_step": per_step, "timed_launches": cn,
                         "ms_per_step": cms / cn * per_step,
                         "events": {"what": "HIP events on the ViT stream around every 5th launch (includes waiting for CUs)",
@@ -715,6 +740,7 @@ def main():
             "metric": "train iters/sec (batch=32, 256x256, 1280-face/642-vert mesh)",
             "value": world * args.steps / elapsed, "unit": "iters/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
+            "instrumented_ms_per_step": 1000.0 * instrumented / args.steps,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 convolutions + ViT linears, f32 elsewhere (configs[4] precision; not the headline)" if args.mixed_bf16 else "f32",
             "data": "synthetic",

@@ -136,8 +136,11 @@ def refresh_planes(convs):
     if CONV_MODE != "split":
         return
     for conv in convs:
-        if conv.weight.is_cuda:
-            weight_planes(conv, with_dgrad=conv.weight.requires_grad or "dgrad" in conv.__dict__.get("_scp_planes", {}))
+        w = conv.weight
+        # only the layers the own kernels run (own_forward_ok's shape rules: 3x3 / 1x1, Cin a power of two >= 32)
+        if w.is_cuda and w.dtype == torch.float32 and w.shape[2] == w.shape[3] and w.shape[2] in (1, 3) and w.shape[1] >= 32 and _pow2(w.shape[1]):
+            with_dgrad = (w.requires_grad and _own_dgrad_ok(w, conv.stride[0])) or "dgrad" in conv.__dict__.get("_scp_planes", {})
+            weight_planes(conv, with_dgrad=with_dgrad)
 
 
 def _planes_arg(conv, x, stride):
