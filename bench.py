@@ -239,7 +239,9 @@ def gemm_peak_tf():
     return BF16_MFMA_PEAK_TF / 6.0 if dino_mod.GEMM_MODE == "split" else FP32_VALU_PEAK_TF
 
 
-def build_trainer(device, world, batch_size=8, repeat=4, seed=0, mixed_bf16=None):
+def build_trainer(device, world, batch_size=8, repeat=4, seed=0, mixed_bf16=None, high_res=False):
+    """high_res: BASELINE configs[4] geometry -- 512 x 512 images, corr_h = corr_w = 128 (the only consistent choice), ViT
+    sequence 4097, icosphere-4 mesh (2562 v / 5120 f)"""
     if mixed_bf16 is None:      # tools/*.py reuse this builder; SCP_MIXED_BF16=1 switches them to configs[4] precision
         mixed_bf16 = os.environ.get("SCP_MIXED_BF16", "0") == "1"
     import scp_amd.dino as dino
@@ -247,10 +249,11 @@ def build_trainer(device, world, batch_size=8, repeat=4, seed=0, mixed_bf16=None
     from scp_amd.flags import Options
     from scp_amd.trainer import Trainer
     dino.ALLOW_RANDOM_INIT = True
+    extra = dict(img_size=512, corr_h=128, corr_w=128) if high_res else {}
     opts = Options("laptop_wild6d", batch_size=batch_size, repeat=repeat, train=True, ngpu=world, vis_freq=10 ** 9,
-                   mixed_bf16=mixed_bf16)
+                   mixed_bf16=mixed_bf16, **extra)
     torch.manual_seed(seed)
-    return Trainer(opts, prior=synthetic.bottle_like(3), device=device), opts
+    return Trainer(opts, prior=synthetic.bottle_like(4 if high_res else 3), device=device), opts
 
 
 def pin_rng_consumers(model, seed=99):
@@ -290,6 +293,20 @@ def cpu_baseline(sample_bs=8, sample_repeat=4, batch_seed=100, stage_times=False
 
     patch = _Patch()
     oracle_backend.install(patch)
+    stages, render_calls = {}, {"fwd": [], "bwd": []}
+
+    def timed(obj, name, key):
+        """wrap obj.name so that its wall time is added to stages[key] (the CPU step is synchronous)"""
+        fn = getattr(obj, name)
+
+        def wrapped(*a, **k):
+            t = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                stages[key] = stages.get(key, 0.0) + time.perf_counter() - t
+        patch.setattr(obj, name, wrapped)
+
     try:
         threads = torch.get_num_threads()
         tr, _ = build_trainer("cpu", 1, 1, 2)
@@ -297,21 +314,68 @@ def cpu_baseline(sample_bs=8, sample_repeat=4, batch_seed=100, stage_times=False
         tr, _ = build_trainer("cpu", 1, sample_bs, sample_repeat)
         pin_rng_consumers(tr.model)
         data = synth.make_batch(sample_bs, sample_repeat, 256, seed=batch_seed, device="cpu")
+        # per-stage seconds: forward stages by wrapping the model's own calls, the rasteriser by its entry points
+        from scp_amd.soft_renderer.cuda import soft_rasterize as native
+        m = tr.model
+        timed(m.pretrain_corr_net.net, "key_tokens", "dino_vit_fwd")
+        timed(m.encoder, "forward", "encoder_pass1_fwd")
+        timed(m.corr_net, "compute_rotation_cycle_loss", "rotation_cycle_fwd (2nd encoder pass + pixel-pixel matching)")
+        timed(m.corr_net, "match", "feature_vertex_match_fwd")
+        timed(m.pretrain_corr_net, "compute_cycle_loss", "pretrained_cycle_fwd (incl. dino_vit_fwd)")
+        for name, key in (("forward_soft_rasterize", "fwd"), ("backward_soft_rasterize", "bwd")):
+            fn = getattr(native, name)
+
+            def wrapped(*a, _fn=fn, _key=key, _sigma=9 if key == "fwd" else 12):
+                t = time.perf_counter()
+                out = _fn(*a)
+                render_calls[_key].append((float(a[_sigma]), time.perf_counter() - t))
+                return out
+            patch.setattr(native, name, wrapped)
         t0 = time.perf_counter()
-        total, aux, _ = tr.step(data)
-        dt = time.perf_counter() - t0
+        tr.model.iters = tr.iteration
+        tr.grads.prepare()
+        total, aux = tr.model(data)
+        t1 = time.perf_counter()
+        total.mean().backward()
+        t2 = time.perf_counter()
+        tr.collect_grad()
+        tr.optim.step(tr.iteration)
+        t3 = time.perf_counter()
+        dt = t3 - t0
         pc = tr.model.pretrain_corr_net
         ref = {"aux": {k: float(v) for k, v in aux.items()}, "total": float(total.mean()),
                "rotation": tr.model.last_pose[0].clone(), "translation": tr.model.last_pose[1].clone(),
                "geometry": tuple(t.clone() for t in tr.model.last_geometry),
                "features": tuple(t.clone() for t in tr.model.last_features),
                "nn": tuple(t.clone() for t in pc.last_nn), "topk": pc.last_topk.clone()}
+        rf, rb = sum(t for _, t in render_calls["fwd"]), sum(t for _, t in render_calls["bwd"])
+        stages["pretrained_cycle_fwd (excl. dino_vit_fwd)"] = stages.pop("pretrained_cycle_fwd (incl. dino_vit_fwd)") - stages.get("dino_vit_fwd", 0.0)
+        stages.update({"render_fwd (%d passes)" % len(render_calls["fwd"]): rf, "render_bwd (%d passes)" % len(render_calls["bwd"]): rb,
+                       "forward_total": t1 - t0, "backward_total (incl. render_bwd)": t2 - t1, "clip+adamw": t3 - t2})
+        # "as written" (BASELINE.md 4.3): what the reference's own schedule would cost on these cores -- the DINO ViT over 4B images x
+        # 12 blocks (timed on 8 images of the batch through the full 12-block ViT, scaled by images) instead of B x 9 1/3,
+        # four render passes forward and backward instead of the deduplicated ones (a sigma = 1e-4 pass added per missing pass)
+        n_img = sample_bs * sample_repeat
+        with torch.no_grad():
+            t = time.perf_counter()
+            tr.model.pretrain_corr_net.net.model(data[0][:min(8, n_img)])
+            vit12 = (time.perf_counter() - t) / min(8, n_img)
+        thin_f = [t for s_, t in render_calls["fwd"] if s_ < 5e-4] or [0.0]
+        thin_b = [t for s_, t in render_calls["bwd"] if s_ < 5e-4] or [0.0]
+        extra = (4 * n_img * vit12 - stages.get("dino_vit_fwd", 0.0)) + max(0, 4 - len(render_calls["fwd"])) * float(np.mean(thin_f)) \
+            + max(0, 4 - len(render_calls["bwd"])) * float(np.mean(thin_b))
+        as_written = {"value": (n_img / 32.0) / (dt + extra), "step_s": dt + extra,
+                      "dino_vit_fwd_s": 4 * n_img * vit12, "render_fwd_s (4 passes)": rf + max(0, 4 - len(render_calls["fwd"])) * float(np.mean(thin_f)),
+                      "render_bwd_s (4 passes)": rb + max(0, 4 - len(render_calls["bwd"])) * float(np.mean(thin_b)),
+                      "how": "deduplicated step + (4B images x 12 ViT blocks, from %d images through the full ViT) + one sigma=1e-4 pass per "
+                             "render pass the build shares or skips (SURVEY F4, F5, F7, F8)" % min(8, n_img)}
     finally:
         patch.undo()
-    n_img = sample_bs * sample_repeat
     return {"value": (n_img / 32.0) / dt, "unit": "train iters/sec (32-image iterations)", "cores": threads,
             "kind": "port", "sample": "1 full training step at B=%d (batch_size %d x repeat %d, 256x256, 642v/1280f) = the bench "
-                                      "batch itself, %.1f s" % (n_img, sample_bs, sample_repeat, dt)}, ref
+                                      "batch itself, %.1f s" % (n_img, sample_bs, sample_repeat, dt),
+            "variant": "deduplicated (B unique images x 9 1/3 ViT blocks, shared render passes) -- the algorithm the GPU path runs",
+            "stages_s": {k: float("%.3f" % v) for k, v in stages.items()}, "as_written": as_written}, ref
 
 
 CONDITIONING_FIXTURE = os.path.join(ROOT, "tests", "golden", "step_conditioning_bottle_b8x4.npz")
@@ -394,8 +458,10 @@ def loss_delta(ref, device, sample_bs=8, sample_repeat=4, batch_seed=100):
     free, tr, free_rel = run(False)
     pv, rot, trans = (t.cpu() for t in tr.model.last_geometry)
     dev = lambda a, b: float("%.3e" % (a - b).abs().max())
+    f_img, f_mesh = (t.cpu() for t in tr.model.last_features)
     free["encoder_deviation_max_abs"] = {"pred_v": dev(pv, ref["geometry"][0]), "rotation": dev(rot, ref["geometry"][1]),
-                                         "translation": dev(trans, ref["geometry"][2])}
+                                         "translation": dev(trans, ref["geometry"][2]), "img_feat": dev(f_img, ref["features"][0]),
+                                         "mesh_feat": dev(f_mesh, ref["features"][1])}
     own_bw, own_fw = tr.model.pretrain_corr_net.last_nn
     flips = float((own_bw.cpu() != ref["nn"][0]).float().mean() + (own_fw.cpu() != ref["nn"][1]).float().mean()) / 2
     band = reference_band()
@@ -527,6 +593,10 @@ def main():
                     help="skip the isolated-kernel reference figures (profiling runs: keeps extra launches out of the trace)")
     ap.add_argument("--mixed-bf16", action="store_true",
                     help="BASELINE configs[4] precision (bf16 convolutions / ViT linears, fp32 elsewhere); NOT the headline")
+    ap.add_argument("--high-res", action="store_true",
+                    help="BASELINE configs[4] geometry: 512x512 images, 2562-vertex / 5120-face mesh, B = --hr-batch x 4 (with --mixed-bf16: "
+                         "its precision too); NOT the headline")
+    ap.add_argument("--hr-batch", type=int, default=2, help="batch_size (videos) of the --high-res workload; repeat stays 4")
     ap.add_argument("--workload", choices=["train", "posefit"], default="train",
                     help="train = BASELINE.json's metric (default); posefit = the test-time pose-fitting path (SURVEY 8f #4)")
     args = ap.parse_args()
@@ -552,7 +622,9 @@ def main():
 
     from scp_amd import synthetic as synth
     from scp_amd.soft_renderer.cuda import soft_rasterize as native
-    tr, opts = build_trainer(device, world, mixed_bf16=args.mixed_bf16)
+    tr, opts = build_trainer(device, world, batch_size=args.hr_batch if args.high_res else 8, mixed_bf16=args.mixed_bf16, high_res=args.high_res)
+    if args.high_res:
+        args.no_cpu_baseline = True          # the CPU leg and the parity leg are the headline workload's
     data = synth.make_batch(opts.batch_size, opts.repeat, opts.img_size, seed=100 + rank, device=device)
     n_faces, n_verts = tr.model.mesh.num_faces, tr.model.mesh.num_verts
 
@@ -737,14 +809,17 @@ def main():
         elif others:
             roofline = dict(next(iter(others.values())), others=others)
         out = {
-            "metric": "train iters/sec (batch=32, 256x256, 1280-face/642-vert mesh)",
+            "metric": ("train iters/sec (batch=%d, 512x512, 5120-face/2562-vert mesh; configs[4], not the headline)" % B) if args.high_res
+            else "train iters/sec (batch=32, 256x256, 1280-face/642-vert mesh)",
             "value": world * args.steps / elapsed, "unit": "iters/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
             "instrumented_ms_per_step": 1000.0 * instrumented / args.steps,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 convolutions + ViT linears, f32 elsewhere (configs[4] precision; not the headline)" if args.mixed_bf16 else "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[2]: B=32 (batch_size 8 x repeat 4) 256x256 per GPU, 642v/1280f mesh, "
+            "config": {"workload": ("configs[4] geometry: B=%d (batch_size %d x repeat 4) 512x512 per GPU, 2562v/5120f mesh, laptop_wild6d flags, "
+                                    "full training step (fwd+bwd+clip+AdamW)" % (B, args.hr_batch)) if args.high_res else
+                                   "configs[2]: B=32 (batch_size 8 x repeat 4) 256x256 per GPU, 642v/1280f mesh, "
                                    "laptop_wild6d flags, full training step (fwd+bwd+clip+AdamW)",
                        "images_per_sec": world * args.steps * B / elapsed, "parallelism": "dp%d" % world,
                        "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else 0,

@@ -19,7 +19,9 @@ Contract for `fn`: static shapes, no host synchronisation, no host-side random d
 allocated through torch (the pool owns it), in-place updates only of tensors whose address is stable (BatchNorm running
 statistics).  Host-side caches that decide WHETHER a kernel is launched (scp_amd.fused_conv.weight_planes) must be filled before
 capture and refreshed outside (Trainer.step does).  Outputs are overwritten by the next replay: consumers read them within the
-step (stream-ordered), which is how the training step uses them.
+step (stream-ordered), which is how the training step uses them.  The parameter gradients a backward replay returns are static
+buffers too: parameters should have their .grad pre-allocated (the Trainer's flat gradient views are), so that autograd adds into
+it instead of adopting the static buffer as .grad.
 Numerics: a replay launches exactly the kernels of the eager call with the same arguments -- bit-identical results (tests)."""
 import torch
 
@@ -89,13 +91,27 @@ class GraphedSegment:
         capi.CAPTURING = True
         try:
             with torch.cuda.graph(fwd, pool=pool):
-                outs = self.fn(*static_in)
+                try:
+                    outs = self.fn(*static_in)
+                except BaseException:
+                    import sys
+                    import traceback
+                    traceback.print_exc()
+                    sys.stderr.flush()
+                    raise
             outs = tuple(outs) if isinstance(outs, (tuple, list)) else (outs,)
             out_req = [i for i, o in enumerate(outs) if o.requires_grad]
             grad_outs = [torch.empty_like(outs[i]) for i in out_req]
             wrt = [t for t in static_in + self.params if t.requires_grad]
             with torch.cuda.graph(bwd, pool=pool):
-                got = torch.autograd.grad([outs[i] for i in out_req], wrt, grad_outs, allow_unused=True)
+                try:
+                    got = torch.autograd.grad([outs[i] for i in out_req], wrt, grad_outs, allow_unused=True)
+                except BaseException:
+                    import sys
+                    import traceback
+                    traceback.print_exc()              # ending an invalidated capture can take the process down: say why first
+                    sys.stderr.flush()
+                    raise
         finally:
             capi.CAPTURING = False
         it = iter(got)

@@ -8,44 +8,41 @@ import torch.nn.functional as F
 from . import functional as srf
 
 
+def _batched(x, dtype, want_dim):
+    """tensor (or array) -> device tensor with a leading batch axis: the three shapes the product passes are already batched
+    tensors; a single mesh (OBJ loader, tests) gains the axis here"""
+    if not torch.is_tensor(x):
+        x = torch.as_tensor(np.asarray(x), dtype=dtype)
+        x = x.cuda() if torch.cuda.is_available() else x
+    return x[None] if x.dim() == want_dim - 1 else x
+
+
 class Mesh(object):
+    """vertices [B,V,3], faces [B,F,3] (int), textures per `texture_type`:
+         "vertex"  [B,V,3]        one colour per vertex (every textured pass of the training step)
+         "surface" [B,F,R*R,3]    R x R texels per face (the mask pass: R = 1, all ones -- SURVEY F14)
+       textures=None means all-ones of the right shape."""
+
+    TEXTURE_RANK = {"surface": 4, "vertex": 3}
+
     def __init__(self, vertices, faces, textures=None, texture_res=1, texture_type="surface"):
-        if isinstance(vertices, np.ndarray):
-            vertices = torch.from_numpy(vertices).float().cuda()
-        if isinstance(faces, np.ndarray):
-            faces = torch.from_numpy(faces).int().cuda()
-        if vertices.dim() == 2:
-            vertices = vertices[None]
-        if faces.dim() == 2:
-            faces = faces[None]
-        self._vertices, self._faces = vertices, faces
-        self.device = vertices.device
-        self.texture_type = texture_type
-        self.batch_size, self.num_vertices = vertices.shape[:2]
-        self.num_faces = faces.shape[1]
+        if texture_type not in self.TEXTURE_RANK:
+            raise ValueError("texture type not applicable")
+        self._vertices = _batched(vertices, torch.float32, 3)
+        self._faces = _batched(faces, torch.int32, 3)
+        self.device, self.texture_type = self._vertices.device, texture_type
+        self.batch_size, self.num_vertices = self._vertices.shape[:2]
+        self.num_faces = self._faces.shape[1]
+        if textures is None:
+            per_item = (self.num_faces, texture_res ** 2, 3) if texture_type == "surface" else (self.num_vertices, 3)
+            self._textures = torch.ones((self.batch_size,) + per_item, dtype=torch.float32, device=self.device)
+            self.texture_res = texture_res if texture_type == "surface" else 1
+        else:
+            self._textures = _batched(textures, torch.float32, self.TEXTURE_RANK[texture_type])
+            self.texture_res = int(np.sqrt(self._textures.shape[2]))
         self._cache = {}
         self._fill_back = False
-        if textures is None:
-            if texture_type == "surface":
-                textures = torch.ones(self.batch_size, self.num_faces, texture_res ** 2, 3,
-                                      dtype=torch.float32, device=self.device)
-                self.texture_res = texture_res
-            elif texture_type == "vertex":
-                textures = torch.ones(self.batch_size, self.num_vertices, 3, dtype=torch.float32,
-                                      device=self.device)
-                self.texture_res = 1
-            else:
-                raise ValueError("texture type not applicable")
-        else:
-            if isinstance(textures, np.ndarray):
-                textures = torch.from_numpy(textures).float().cuda()
-            if textures.dim() == 3 and texture_type == "surface":
-                textures = textures[None]
-            if textures.dim() == 2 and texture_type == "vertex":
-                textures = textures[None]
-            self.texture_res = int(np.sqrt(textures.shape[2]))
-        self._textures = textures
-        self._origin = (vertices, faces, textures)
+        self._origin = (self._vertices, self._faces, self._textures)
 
     # -- mutable geometry; any change drops the gathered views
     @property
