@@ -105,9 +105,10 @@ class Trainer:
             self.reducer.broadcast_parameters(self.model, 0)
         self._group_spans = None
         # HIP-graph replay of the static single-stream segments (scp_amd/graphed.py): the two encoder passes (forward + backward) and
-        # the frozen ViT with its pair matching.  OPT-IN (SCP_GRAPHS=1 or Trainer(..., graphs=True)): measured on one MI355X
-        # (profiles/r04_host_enqueue.txt) the host needs 10.2 ms instead of 21.2 ms to enqueue a step, but the step itself is
-        # device-bound and the replayed nodes cost it +0.6 ms (32.4 vs 31.8 ms) -- worth it only where the host is the scarce resource.
+        # the frozen ViT with its pair matching.  OPT-IN and EXPERIMENTAL (SCP_GRAPHS=1 or Trainer(..., graphs=True)): measured on one
+        # MI355X in the bench workload (profiles/r04_host_enqueue.txt) the host needs 8.5-10.2 ms instead of 21.2 ms to enqueue a step;
+        # the step itself is device-bound and does not get faster (31.8 vs 31.8-32.4 ms).  In other process setups ending the
+        # capture of the encoder's backward graph has crashed inside the HIP runtime (tools/graph_variants.py); not for production.
         # Not under SyncBatchNorm (collectives inside the segment) and not in configs[4] precision (autocast's weight-cast cache does
         # not survive a capture).
         from . import fused_conv

@@ -14,29 +14,34 @@ from scp_amd.flags import Options
 from scp_amd.trainer import Trainer
 from scp_amd import synthetic
 dino.ALLOW_RANDOM_INIT = True
-bs, rep, ident, angle, look, first_eager = %s
-opts = Options("laptop_wild6d", batch_size=bs, repeat=rep, train=True, total_iters=100)
-torch.manual_seed(0)
-if first_eager:
-    t0 = Trainer(opts, prior=synthetic.bottle_like(3), device="cuda", graphs=False)
-    t0.step(synthetic.make_batch(bs, rep, 256, seed=1, device="cuda"))
-    del t0
-tr = Trainer(opts, prior=synthetic.bottle_like(3), device="cuda", graphs=True)
+bs, rep, ident, angle, look, same, how = %s
+if how == "bench":
+    import bench
+    os.environ["SCP_GRAPHS"] = "1"
+    tr, opts = bench.build_trainer("cuda:0", 1, bs, rep)
+else:
+    kw = dict(total_iters=100) if how != "long" else {}
+    if how == "novis":
+        kw["vis_freq"] = 10 ** 9
+    opts = Options("laptop_wild6d", batch_size=bs, repeat=rep, train=True, **kw)
+    torch.manual_seed(0)
+    tr = Trainer(opts, prior=synthetic.bottle_like(3), device="cuda:0" if how == "cuda0" else "cuda", graphs=True)
 if ident:
     tr.model.encoder.random_jitter = torch.nn.Identity()
 if angle is not None:
     tr.model.rotation_angle = angle
 batches = [synthetic.make_batch(bs, rep, 256, seed=30 + i, device="cuda") for i in range(5)]
+if same:
+    batches = [batches[0]] * 5
 for i, d in enumerate(batches):
     nxt = batches[i + 1] if (look and i + 1 < len(batches)) else None
     total, aux, _ = tr.step(d, next_data=nxt)
 torch.cuda.synchronize()
 print("OK loss %%.6f" %% float(total))
 '''
-VARIANTS = {"B4 default": (2, 2, False, None, False, False), "B4 identity-jitter": (2, 2, True, None, False, False),
-            "B4 angle90": (2, 2, False, 90.0, False, False), "B4 lookahead": (2, 2, False, None, True, False),
-            "B4 all (the test)": (2, 2, True, 90.0, True, False), "B4 all after an eager trainer": (2, 2, True, 90.0, True, True),
-            "B8 default": (2, 4, False, None, False, False)}
+VARIANTS = {"B32 bench.build_trainer": (8, 4, False, None, False, True, "bench"), "B32 device cuda:0": (8, 4, False, None, False, True, "cuda0"),
+            "B32 vis_freq off": (8, 4, False, None, False, True, "novis"), "B32 default total_iters": (8, 4, False, None, False, True, "long"),
+            "B32 as before": (8, 4, False, None, False, True, "")}
 for name, cfg in VARIANTS.items():
     r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, ROOT, ROOT, repr(cfg))], capture_output=True, text=True)
     tail = (r.stdout.strip().splitlines() or [""])[-1]
