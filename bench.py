@@ -24,7 +24,7 @@ Extra JSON objects (tier contract):
                 duration on the kernel-duration clock; peak = 2500 / 6 = 416.7 TFLOP/s of fp32-equivalent work (six bf16 MFMA
                 products per algorithmic one), or 157.3 TFLOP/s (fp32 MFMA) in fp32 mode; `vs_fp32_mfma_peak` is always there.
                 `traffic` = HBM bytes per step of those launches from rocprofv3 FETCH_SIZE / WRITE_SIZE passes, read from
-                profiles/r03_traffic.json when that file matches the problem size, else null.
+                profiles/r04_traffic.json when that file matches the problem size, else null.
                 "others": the ViT attention kernel (mfma), the SoftRas backward of the sigma=1e-3 pass (fp32 VALU on active
                 (pixel,face) pairs; HBM figure for the record) and the fused correspondence kernels, same method.
   cpu_baseline  the same step on the host CPU cores (torch CPU + the C oracle rasteriser), rank 0, N=1 only: ONE full
@@ -148,7 +148,7 @@ class KernelClock:
 
 
 INIT_STEPS = 3
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")   # written by tools/traffic_report.py from rocprofv3 PMC passes
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")   # written by tools/traffic_report.py from rocprofv3 PMC passes
 
 
 def measured_traffic(key, size_tag):
@@ -777,9 +777,9 @@ def main():
                         "arithmetic": ("fp32-accurate: operands represented exactly, dropped partial products < 2^-24 |a b|; error "
                                        "vs float64 not above the fp32 matrix cores' (tests/test_vit_gpu.py); SCP_VIT_GEMM=fp32 "
                                        "selects the fp32 cores" if split else "v_mfma_f32_32x32x2_f32"),
-                        "traffic": measured_traffic("vit_gemm", size_tag), "traffic_source": "profiles/r03_traffic.json (per step)",
+                        "traffic": measured_traffic("vit_gemm", size_tag), "traffic_source": "profiles/r04_traffic.json (per step)",
                         "clock": "in-kernel s_memrealtime stamps: first workgroup start to last workgroup end of every full launch "
-                                 "of the timed region (= rocprofv3 kernel-trace duration; profiles/r03_kernel_stats_timed_window.csv)",
+                                 "of the timed region (= rocprofv3 kernel-trace duration; profiles/r04_kernel_stats_timed_window.csv)",
                         "avg_launch_ms": cms / cn, "algorithmic_flops_per_launch": cfl / cn,
                         "by_shape": getattr(kc, "by_shape", None),
                         "profile_note": "under rocprofv3 the step is host-bound (per-launch interception), so kernels of different streams "

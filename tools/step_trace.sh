@@ -1,12 +1,13 @@
 #!/bin/bash
-# tools/step_trace.sh [tag] -- on the GPU box: rocprofv3 kernel trace of a short bench run; kernel stats of the timed window,
+# tools/step_trace.sh [tag] -- on the GPU box: rocprofv3 kernel trace of a short bench run WITH the ViT look-ahead (the headline
+# schedule); kernel stats of the timed window,
 # device-idle analysis (tools/profile_summary.py).  Writes gpurun_out/<tag>_{kernel_stats_timed_window.csv,idle_gaps.txt}
 tag=${1:-step}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/trace_$tag
-rocprofv3 --kernel-trace -d /tmp/trace_$tag --output-format csv -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-isolated --no-lookahead > $R/gpurun_out/${tag}_bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace -d /tmp/trace_$tag --output-format csv -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-isolated > $R/gpurun_out/${tag}_bench_under_rocprof.json 2>/dev/null
 f=$(ls /tmp/trace_$tag/*/*kernel_trace.csv | head -1)
 cd $R
 # window = after the (INIT 3 + warmup 2 + 1)-th optimizer launch, i.e. the last 5 steps
