@@ -202,7 +202,7 @@ def isolated_gemms(M, C=384, iters=20):
             run = lambda: dino_mod.vit_linear(a if a_in is None else None, w, v0, v1, st, out, out=None if name == "fc1" else out, epilogue=epi,
                                               w_split=w3, a_planes=a_in, out_planes=o3, fp32_out=name != "fc1")
         else:
-            w3 = dino_mod.split_weight(w) if dino_mod.GEMM_MODE == "split" else None
+            w3 = dino_mod.split_weight(w) if dino_mod.gemm_mode() == "split" else None      # bf16 / fp32 modes: vit_linear prepares W itself
             run = lambda: dino_mod.vit_linear(a, w, v0, v1, st, out, out=out, epilogue=epi, w_split=w3)
         for _ in range(3):
             run()

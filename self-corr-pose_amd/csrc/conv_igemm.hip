@@ -98,6 +98,9 @@ struct ConvASource {
     }
     template <int I>
     __device__ __forceinline__ void issue(int kc, unsigned stage_lds, int wave) const {
+#ifdef SCP_PROBE_NO_DMA            // tools/probes: the main loop without its global -> LDS traffic
+        if (kc >= 2) return;
+#endif
         const int tap = kc >> lg_cpt, c = kc - (tap << lg_cpt);
         int delta = 64 * c;
         if (TAPS == 9) {

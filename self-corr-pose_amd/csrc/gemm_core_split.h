@@ -317,7 +317,11 @@ struct SplitGemmCore {
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(st + a_rd[1] + i * 2048);
                 const f32x8 x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 if constexpr (CFG::NPLANES == 1) a.h = __builtin_convertvector(x, bf16x8);
+#ifdef SCP_PROBE_NO_SPLIT          // tools/probes: the A operand's VALU split replaced by one conversion (wrong values, timing only)
+                else { a.h = __builtin_convertvector(x, bf16x8); a.m = a.h; a.l = a.h; }
+#else
                 else a = split3(x);
+#endif
             }
             if constexpr (CFG::NPLANES == 1) {
 #pragma unroll
@@ -358,10 +362,12 @@ struct SplitGemmCore {
 #pragma unroll
                     for (int j = 0; j < CFG::WN; j++) c[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wf[p][j], c[j], 0, 0, 0);
                 };
+#ifndef SCP_PROBE_NO_MFMA
                 mac(a.l, 0);
                 mac(a.h, 2);
                 mac(a.m, 0);
                 mac(a.h, 1);
+#endif
                 mac(a.h, 0);
 #pragma unroll
                 for (int j = 0; j < CFG::WN; j++) acc.t[i * CFG::WN + j] += c[j];
