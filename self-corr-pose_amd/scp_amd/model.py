@@ -168,3 +168,5 @@ class MeshNet(nn.Module):
             if "symm_rots" in name or "triangle_loss_fn" in name or "flatten_loss_fn" in name:
                 states.pop(name)
         self.load_state_dict(states, strict=False)
+        from . import fused_conv
+        fused_conv.WEIGHT_EPOCH[0] += 1          # cached operand planes of the convolution weights are stale now

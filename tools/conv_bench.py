@@ -63,7 +63,7 @@ for name, cin, cout, k, s, h, cnt in LAYERS:
         yo = torch.empty(B, ho, ho, cout, device="cuda")
         of = t(lambda: capi.check(L.scp_conv_nhwc_forward(P(xn), P(None if SPLIT else wn), P(wn3), P(None), P(yo), P(None), B, h, h, cin, cout, k, s, 0, 0.0, P(skf), skf_b,
                                                           capi.current_stream()), "fwd"))
-        assert (yo - y.detach().permute(0, 2, 3, 1)).abs().max() <= 2e-4 * y.abs().max()
+        assert os.environ.get("SCP_BENCH_NOCHECK") or (yo - y.detach().permute(0, 2, 3, 1)).abs().max() <= 2e-4 * y.abs().max()
         if s == 1:
             wt = w.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous()
             wt3 = fused_conv.split_planes_tiled(wt) if SPLIT else None
