@@ -82,19 +82,28 @@ __device__ __forceinline__ void fold_rows(float4 a, float4 b, int tc_n, int ri_n
 // dispatcher behind the other streams' kernels, 84 times per step.  The fold order depends only on (blocks, C), never on
 // which workgroup happens to be last, so results stay deterministic.  The ticket word is zero on entry and is re-armed
 // (zeroed) by the last workgroup.
-__device__ __forceinline__ bool last_block_arrived(unsigned* ticket) {
-    __shared__ int is_last;
+// `flag`: one LDS word of the caller's own buffer that is free at this point (the convolution kernels pass the first word of
+// their operand ring: a separate __shared__ word pushed their 40 960-byte ring over a quarter of the CU's 160 KiB and cost the
+// fourth resident workgroup -- round 4).
+__device__ __forceinline__ bool last_block_arrived(unsigned* ticket, int* flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this thread's write-through partial stores have completed ...
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the ticket
-        is_last = t == gridDim.x - 1;
-        if (is_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == gridDim.x - 1;
+        *flag = last;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    const int is_last = *flag;
+    __syncthreads();                                     // everyone has read the flag before the caller reuses the word
     if (!is_last) return false;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // one workgroup: drop what this XCD's L2 may hold of the partial buffers
     return true;
+}
+__device__ __forceinline__ bool last_block_arrived(unsigned* ticket) {
+    __shared__ int is_last;
+    return last_block_arrived(ticket, &is_last);
 }
 
 // all BN_THREADS threads: thread (tc, ri) strides over the blocks k = ri, ri + ri_n, ... with up to 16 independent float4

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(FCFG::THREADS, 2) void conv_igemm_kernel(const Conv
     const int lid0 = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (lid0 >= total) {
         // a padding workgroup still takes its ticket (the last arrival is counted over the whole grid); it can be the last
-        if (STATS && g.ticket && scp_bn::last_block_arrived(g.ticket)) finalize_statistics(g, lds);
+        if (STATS && g.ticket && scp_bn::last_block_arrived(g.ticket, reinterpret_cast<int*>(lds))) finalize_statistics(g, lds);
         return;
     }
     const int lid = lid0 / ksplit, ks = lid0 - lid * ksplit;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(FCFG::THREADS, 2) void conv_igemm_kernel(const Conv
             if (n < g.Cout)
                 __hip_atomic_store(g.partials + ((size_t)which * g.tiles_m + bm) * g.Cout + n, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (g.ticket && scp_bn::last_block_arrived(g.ticket)) finalize_statistics(g, lds);
+        if (g.ticket && scp_bn::last_block_arrived(g.ticket, reinterpret_cast<int*>(lds))) finalize_statistics(g, lds);
     }
 }
 
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void conv_splitk_fold_kernel(const ConvArgs g)
                 __hip_atomic_store(g.partials + ((size_t)1 * g.tiles_m + bm) * g.Cout + n + i, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (g.ticket && scp_bn::last_block_arrived(g.ticket)) finalize_statistics(g, lds);
+        if (g.ticket && scp_bn::last_block_arrived(g.ticket, reinterpret_cast<int*>(lds))) finalize_statistics(g, lds);
     }
 }
 

@@ -370,7 +370,10 @@ struct SplitGemmCore {
 #endif
                 mac(a.h, 0);
 #pragma unroll
-                for (int j = 0; j < CFG::WN; j++) acc.t[i * CFG::WN + j] += c[j];
+                for (int j = 0; j < CFG::WN; j++) {
+                    acc.t[i * CFG::WN + j] += c[j];
+                    asm volatile("" : "+v"(acc.t[i * CFG::WN + j]));      // pins the fold here: c[] dies before the next row tile
+                }
                 __builtin_amdgcn_sched_barrier(0);      // one row tile at a time: the chunk accumulators of two tiles never coexist
             }
         }
