@@ -311,7 +311,10 @@ int scp_batchnorm_act_backward_bf16(const void* dy, const void* x, const void* y
  * scp_conv_nhwc_weight_grad (split != 0: on the bf16 matrix cores with exactly split operands, both operands split in registers;
  *   else fp32 matrix cores): dw [Cout,k,k,Cin] = sum over output pixels of dy[p][co] x[p + tap][ci]; x [N,H,W,Cin],
  *   dy [N,Ho,Wo,Cout]; workspace >= scp_conv_nhwc_weight_grad_workspace(...) bytes (partial sums of the pixel split, folded in a
- *   fixed order: deterministic); dbias (or NULL): [Cout] = sum over pixels of dy. */
+ *   fixed order: deterministic); dbias (or NULL): [Cout] = sum over pixels of dy.
+ *   Shapes: ksize 3 / stride 1 (both cores); with split != 0 also the stride-2 layers of the trunk -- ksize 3 (pad 1) and ksize 1
+ *   (pad 0, the downsample projections), x [N,H,W,Cin] with H, W even, dy [N,H/2,W/2,Cout].  The output map must be a power of two
+ *   >= 8 x 8, Cin and Cout multiples of 64 (else the workspace query returns 0 and the call hipErrorInvalidValue). */
 int scp_conv_nhwc_forward(const float* x, const float* w, const void* w_split, const float* bias, float* y, float* partials, int N,
                           int H, int W, int Cin, int Cout, int ksize, int stride, int leaky, float slope, void* splitk_ws,
                           size_t splitk_bytes, void* stream);
@@ -324,6 +327,12 @@ size_t scp_conv_nhwc_splitk_workspace(int N, int H, int W, int Cin, int Cout, in
  * NULL = not wanted), one launch */
 int scp_conv_weight_planes(const float* w, long long s_co, long long s_ci, long long s_ky, long long s_kx, int Cout, int Cin, int ksize,
                            void* planes_fwd, void* planes_dgrad, void* stream);
+/* input gradient of a 3x3 / stride-2 / pad-1 convolution (torchvision BasicBlock conv1 of layer2..4, image_encoder.py:128-134):
+ * dy [N,Ho,Wo,Cout] -> dx [N,2 Ho,2 Wo,Cin]; w_dgrad_planes = the planes_dgrad of scp_conv_weight_planes.  The input pixels are
+ * taken by parity class (1, 2, 2, 4 contributing taps), each an implicit GEMM over the dy grid on the split main loop; every dx
+ * element is written exactly once.  Cout a power of two >= 32. */
+int scp_conv_nhwc_dgrad_stride2(const float* dy, const void* w_dgrad_planes, float* dx, int N, int Ho, int Wo, int Cout, int Cin,
+                                void* stream);
 int scp_conv_nhwc_partial_rows(int N, int H, int W, int Cin, int Cout, int ksize, int stride, int split, int* tiles_m,
                                int* rows_per_tile);
 /* convolution (no bias) + the batch statistics of the nn.BatchNorm2d that follows it (training mode), one launch: the per-tile

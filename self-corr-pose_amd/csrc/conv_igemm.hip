@@ -23,6 +23,8 @@
 // tools/probes/gemm_v3.hip); algorithmic flops 2 M Cout taps Cin; algorithmic bytes 4 (M_in Cin + taps Cin Cout + M Cout).
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "bn_common.h"
 #include "gemm_core.h"
 #include "gemm_core_split.h"
@@ -258,6 +260,108 @@ __global__ __launch_bounds__(FCFG::THREADS, 2) void conv_igemm_kernel(const Conv
                 __hip_atomic_store(g.partials + ((size_t)which * g.tiles_m + bm) * g.Cout + n, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (g.ticket && scp_bn::last_block_arrived(g.ticket, reinterpret_cast<int*>(lds))) finalize_statistics(g, lds);
+    }
+}
+
+// ---- input gradient of the 3x3 / stride-2 / pad-1 convolutions (first block of layer2..4) -----------------------------------------
+// dx[img][yi][xi][ci] = sum over (ky, kx, co) with yi + 1 - ky and xi + 1 - kx EVEN of dy[img][(yi+1-ky)/2][(xi+1-kx)/2][co] w[co][ci][ky][kx].
+// Which taps contribute depends only on the PARITY of (yi, xi): even -> the centre tap alone (k = 1), odd -> k = 0 and k = 2.  So the
+// input pixels fall into four classes (py, px) with 1, 2, 2 and 4 taps; each class is an implicit GEMM over the dy grid
+//     rows = (img, a, b) of the dy grid  <->  input pixel (2a + py, 2b + px),    K = (taps of the class) x Cout,
+// a tap reading dy at (a + [k == 0], b + [k == 0]) -- beyond the grid: zeros through the buffer descriptor, as in the forward kernel.
+// 9 tap-products per 4 pixels instead of the 36 a "forward kernel on a zero-stuffed dy" would do, and no zeros written or read.
+// The W operand is the `dgrad` plane set of conv_weight_planes_kernel (rows = ci, K = (flipped tap, co)): the class walks the chunks
+// of ITS taps (SplitGemmCore's w_chunk hook).  All four classes in one launch, interleaved tile by tile so that every XCD gets the
+// same mix and the four tiles that read one dy panel run next to each other.
+template <class CFG>
+struct Dgrad2ASource {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned a_pix[CFG::A_PER], tap_ok[CFG::A_PER];
+    int Wo, C, lg_cpt, py, px;
+
+    // tap t of the class -> (ky, kx): py ? {0, 2}[t / nx] : 1
+    __device__ __forceinline__ void tap_kykx(int tap, int& ky, int& kx) const {
+        const int iy = px ? tap >> 1 : tap, ix = px ? tap & 1 : 0;
+        ky = py ? 2 * iy : 1;
+        kx = px ? 2 * ix : 1;
+    }
+    __device__ __forceinline__ void set(const ConvArgs& g, int py_, int px_, int m0, int wave, int lane) {
+        const int prow = lane >> 2, pslot = lane & 3;
+        const int chunk = pslot ^ ((prow >> 2) & 3);
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, (int)g.x_bytes, 0x00020000);
+        Wo = g.W; C = g.Cin; lg_cpt = g.lg_cpt; py = py_; px = px_;
+        const int hw = g.H * g.W, ntaps = (1 + py) * (1 + px);
+#pragma unroll
+        for (int i = 0; i < CFG::A_PER; i++) {
+            const int r = 16 * (wave * CFG::A_PER + i) + prow;
+            const int p = min(m0 + r, g.M - 1);
+            const int img = p / hw, rem = p - img * hw;
+            const int a = rem / g.W, b = rem - a * g.W;
+            a_pix[i] = ((unsigned)p * (unsigned)g.Cin + 4u * chunk) * 4u;
+            unsigned ok = 0;
+            for (int tap = 0; tap < ntaps; tap++) {
+                int ky, kx;
+                tap_kykx(tap, ky, kx);
+                if (a + (ky == 0) < g.H && b + (kx == 0) < g.W) ok |= 1u << tap;
+            }
+            tap_ok[i] = ok;
+        }
+    }
+    template <int I>
+    __device__ __forceinline__ void issue(int kc, unsigned stage_lds, int wave) const {
+        const int tap = kc >> lg_cpt, c = kc - (tap << lg_cpt);
+        int ky, kx;
+        tap_kykx(tap, ky, kx);
+        const int delta = 64 * c + ((ky == 0) * Wo + (kx == 0)) * C * 4;
+        const bool ok = (tap_ok[I] >> tap) & 1u;
+        const unsigned voff = ok ? a_pix[I] + (unsigned)delta : 0x80000000u;
+        bufload16(voff, rsrc, stage_lds + (unsigned)(wave * CFG::A_PER + I) * 1024u);
+    }
+    __device__ __forceinline__ int w_chunk(int kc) const {
+        const int tap = kc >> lg_cpt, c = kc - (tap << lg_cpt);
+        int ky, kx;
+        tap_kykx(tap, ky, kx);
+        return (((2 - ky) * 3 + (2 - kx)) << lg_cpt) + c;
+    }
+};
+
+// ConvArgs here: x = dy [N, H = Ho, W = Wo, Cin = conv Cout], y = dx [N, 2 Ho, 2 Wo, Cout = conv Cin], M = N Ho Wo (rows per class)
+template <class FCFG>
+__global__ __launch_bounds__(FCFG::THREADS, 2) void conv_dgrad_s2_kernel(const ConvArgs g) {
+    using CFG = SplitOf<FCFG>;
+    __shared__ __attribute__((aligned(16))) float lds[CFG::LDS_BYTES / 4];
+    using Core = scp::SplitGemmCore<CFG, Dgrad2ASource<CFG>>;
+    const int total = 4 * g.tiles_m_kernel * g.nblk_n;
+    const int per_xcd = (total + 7) >> 3;
+    const int lid0 = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lid0 >= total) return;
+    const int cls = __builtin_amdgcn_readfirstlane(3 - (lid0 & 3)), lid = lid0 >> 2;             // the 4-tap class first
+    const int py = cls >> 1, px = cls & 1;
+    const int bm = lid / g.nblk_n, bn = lid - bm * g.nblk_n;
+    const int m0 = bm * CFG::BM, n0 = bn * CFG::BN;
+    Core core(lds);
+    core.asrc.set(g, py, px, m0, core.wave, core.lane);
+    core.set_w_rows(g.w_split, g.Cout, 9 * g.Cin, [&](int r) { return min(n0 + r, g.Cout - 1); });
+    typename Core::Acc acc;
+    core.run(acc, ((1 + py) * (1 + px)) << g.lg_cpt);
+
+    const int half = core.lane >> 5, l31 = core.lane & 31;
+    const int hw = g.H * g.W;
+#pragma unroll
+    for (int i = 0; i < CFG::WM; i++) {
+        const int mb = m0 + core.row_base() + 32 * i;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = mb + scp::acc_row(r, half);
+            const int img = m / hw, rem = m - img * hw;
+            const int a = rem / g.W, b = rem - a * g.W;
+            const size_t orow = ((size_t)(img * 2 * g.H + 2 * a + py) * (2 * g.W) + 2 * b + px) * g.Cout;
+#pragma unroll
+            for (int j = 0; j < CFG::WN; j++) {
+                const int n = n0 + core.col_base() + 32 * j + l31;
+                if (m < g.M && n < g.Cout) g.y[orow + n] = acc.t[i * CFG::WN + j][r];
+            }
+        }
     }
 }
 
@@ -527,6 +631,32 @@ extern "C" int scp_conv_nhwc_forward_bn(const float* x, const float* w, const vo
                                   save_scale, save_shift};
     return conv_forward_impl(x, w, w_split, nullptr, y, static_cast<float*>(workspace), ticket, &fin, N, H, W, Cin, Cout, ksize, stride, 0, 0.f,
                              splitk_ws, splitk_bytes, stream);
+}
+
+extern "C" int scp_conv_nhwc_dgrad_stride2(const float* dy, const void* w_dgrad_planes, float* dx, int N, int Ho, int Wo, int Cout, int Cin,
+                                           void* stream) {
+    if (!dy || !w_dgrad_planes || !dx) return scp::fail(hipErrorInvalidValue, "conv_nhwc_dgrad_stride2: null argument");
+    if (N <= 0 || Ho <= 0 || Wo <= 0) return scp::fail(hipErrorInvalidValue, "conv_nhwc_dgrad_stride2: empty problem");
+    const int cpt = Cout / 16;
+    if (Cout % 32 != 0 || (cpt & (cpt - 1)) || Cin <= 0) return scp::fail(hipErrorInvalidValue, "conv_nhwc_dgrad_stride2: Cout must be a power of two >= 32");
+    const long M = (long)N * Ho * Wo, dy_bytes = M * Cout * 4;
+    if (dy_bytes >= (1l << 31) || 4 * M * Cin >= (1l << 31)) return scp::fail(hipErrorInvalidValue, "conv_nhwc_dgrad_stride2: tensor larger than 2^31 bytes");
+    ConvArgs g{};
+    g.x = dy; g.w_split = w_dgrad_planes; g.y = dx;
+    g.H = Ho; g.W = Wo; g.Cin = Cout; g.Cout = Cin; g.M = (int)M; g.x_bytes = (unsigned)dy_bytes;
+    while ((1 << g.lg_cpt) < cpt) g.lg_cpt++;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    auto launch = [&](auto cfg_tag) {
+        using CFG = decltype(cfg_tag);
+        g.nblk_n = (g.Cout + CFG::BN - 1) / CFG::BN;
+        g.tiles_m = g.tiles_m_kernel = (g.M + CFG::BM - 1) / CFG::BM;
+        const int total = 4 * g.tiles_m * g.nblk_n;
+        hipLaunchKernelGGL((conv_dgrad_s2_kernel<CFG>), dim3(((total + 7) >> 3) << 3), dim3(CFG::THREADS), 0, st, g);
+    };
+    if (Cin <= 64) launch(Cfg256x64{});
+    else if (4 * ((M + 127) / 128) * ((Cin + 127) / 128) >= 256) launch(Cfg128x128{});
+    else launch(Cfg64x64{});
+    return scp::check_launch("conv_nhwc_dgrad_stride2");
 }
 
 extern "C" int scp_conv_weight_planes(const float* w, long long s_co, long long s_ci, long long s_ky, long long s_kx, int Cout, int Cin,

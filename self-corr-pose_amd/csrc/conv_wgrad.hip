@@ -35,13 +35,13 @@ using scp::static_for;
 constexpr int THREADS = 256, BC = 64;            // block of output / input channels per workgroup
 constexpr int CHUNK = 16;                        // pixels per chunk
 constexpr int DY_BYTES = CHUNK * BC * 4;         // 4 KiB
-constexpr int X_ROWS = 64;                       // LDS rows reserved for the halo block (54 or 40 used)
-constexpr int STAGE_BYTES = DY_BYTES + X_ROWS * BC * 4;      // 20 KiB
+// LDS rows reserved for the halo block: stride 1: 3 x 18 = 54 or 4 x 10 = 40 used; stride 2 (the first 3x3 of layer2..4, split core
+// only): a chunk of 16 output pixels reads 3 x 33 = 99 or 5 x 17 = 85 input positions
+constexpr int x_rows(int stride) { return stride == 1 ? 64 : 112; }
 constexpr int NSTAGE = 2;
-constexpr int PER = 1 + 4;                       // LDS-DMA pieces per wavefront per chunk: 1 of dy, 4 of x
 
 struct WgradArgs {
-    const float* x;        // [N, H, W, Cin]
+    const float* x;        // [N, S H, S W, Cin] (S = stride)
     const float* dy;       // [N, H, W, Cout]
     float* partial;        // [splits][Cout][9][Cin]
     int lgW, lgH, Cin, Cout;
@@ -59,10 +59,16 @@ __device__ __forceinline__ void bufload16(unsigned voff, __amdgpu_buffer_rsrc_t 
 
 enum { MODE_ISSUE = 0, MODE_TAIL = 1, MODE_LAST = 2 };
 
-// CW = pixels of one image row inside a chunk (16, or 8 for 8-pixel-wide maps: a chunk is then two rows)
-template <int CW>
+// CW = pixels of one image row inside a chunk (16, or 8 for 8-pixel-wide maps: a chunk is then two rows); STR = stride (lgW / lgH are
+// the OUTPUT map's; the input is STR times as large)
+// KS = kernel size: 3 (pad 1: the halo block), or 1 (pad 0, the stride-2 projections: the block is just the chunk's 16 pixels)
+template <int CW, int STR = 1, int KS = 3>
 struct WgradCore {
-    static constexpr int CR = CHUNK / CW, HC = CW + 2, HR = CR + 2;
+    static constexpr int CR = CHUNK / CW, HC = KS == 1 ? CW : STR * (CW - 1) + 3, HR = KS == 1 ? CR : STR * (CR - 1) + 3;
+    static constexpr int X_ROWS = KS == 1 ? 16 : x_rows(STR), STAGE_BYTES = DY_BYTES + X_ROWS * BC * 4;
+    static constexpr int XP = X_ROWS / 16;            // x pieces per wavefront
+    static constexpr int PSTEP = KS == 1 ? STR : 1, PAD = KS == 1 ? 0 : 1;   // block position -> input pixel: STR (y0, x0) + PSTEP pos - PAD
+    static constexpr int PER = 1 + XP;               // LDS-DMA pieces per wavefront per chunk
     static_assert(HR * HC <= X_ROWS, "halo block fits the reserved rows");
     struct Acc { f32x16 t[9]; };
     struct Frag { float a; float b[9]; };
@@ -71,7 +77,7 @@ struct WgradCore {
     __amdgpu_buffer_rsrc_t rsrc;
     unsigned lds0, a_rd, b_rd;
     unsigned dy_off;                 // lane's byte offset inside a dy chunk
-    int x_hr[4], x_hc[4];            // lane's halo position (row, column) per x piece; row < 0: beyond the block
+    int x_hr[XP], x_hc[XP];          // lane's halo position (row, column) per x piece; row < 0: beyond the block
     unsigned x_lane;                 // lane's byte offset inside a pixel's channels
     int wave, lane;
     int chunk0;
@@ -93,8 +99,8 @@ struct WgradCore {
         dy_base = reinterpret_cast<const char*>(g.dy);
         x_lane = (unsigned)(cib * BC) * 4u + 16u * grp;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int row = 4 * (4 * wave + i) + prow;        // LDS row of the halo block
+        for (int i = 0; i < XP; i++) {
+            const int row = 4 * (XP * wave + i) + prow;       // LDS row of the halo block
             x_hr[i] = row < HR * HC ? row / HC : -1000;
             x_hc[i] = row % HC;
         }
@@ -109,12 +115,12 @@ struct WgradCore {
         const unsigned stage = lds0 + (unsigned)s * STAGE_BYTES;
         scp::glds16(dy_off, dy_base + (size_t)p0 * g.Cout * 4, stage + (unsigned)wave * 1024u);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int yy = y0 + x_hr[i] - 1, xx = x0 + x_hc[i] - 1;
-            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const unsigned off = (unsigned)(((img << g.lgH) + yy) << g.lgW) + (unsigned)xx;
+        for (int i = 0; i < XP; i++) {
+            const int yy = STR * y0 + PSTEP * x_hr[i] - PAD, xx = STR * x0 + PSTEP * x_hc[i] - PAD;
+            const bool ok = yy >= 0 && yy < STR * H && xx >= 0 && xx < STR * W;
+            const unsigned off = (unsigned)((img * STR * H + yy) * (STR * W)) + (unsigned)xx;
             const unsigned voff = ok ? off * (unsigned)g.Cin * 4u + x_lane : 0x80000000u;
-            bufload16(voff, rsrc, stage + DY_BYTES + (unsigned)(4 * wave + i) * 1024u);
+            bufload16(voff, rsrc, stage + DY_BYTES + (unsigned)(XP * wave + i) * 1024u);
         }
     }
 
@@ -200,9 +206,12 @@ struct WgradCore {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int CW>
-struct WgradSplitCore : WgradCore<CW> {
-    using Base = WgradCore<CW>;
+template <int CW, int STR = 1, int KS = 3>
+struct WgradSplitCore : WgradCore<CW, STR, KS> {
+    using Base = WgradCore<CW, STR, KS>;
+    static constexpr int STAGE_BYTES = Base::STAGE_BYTES;
+    static constexpr int PS = KS == 1 ? 1 : STR;      // halo columns between consecutive output pixels
+    static constexpr int NX = PS * 7 + KS;            // halo words of one row a lane's 8 pixels touch (all kx)
     using Acc = typename Base::Acc;
     const float* ldsf;
     int a_lane, b_lane;            // float offsets inside a stage of this lane's first dy word / first halo word
@@ -212,8 +221,8 @@ struct WgradSplitCore : WgradCore<CW> {
         const int half = this->lane >> 5, l31 = this->lane & 31;
         const int wm = this->wave >> 1, wn = this->wave & 1;
         a_lane = 8 * half * BC + wm * 32 + l31;                                   // pixel 8 half + i -> dy row
-        // pixel p = 8 half + i sits at halo (row p / CW, column p % CW); the tap adds (ky, kx)
-        const int pr = CW == 16 ? 0 : half, pc0 = CW == 16 ? 8 * half : 0;
+        // pixel p = 8 half + i sits at halo (row PS (p / CW), column PS (p % CW)); the tap adds (ky, kx)
+        const int pr = CW == 16 ? 0 : PS * half, pc0 = CW == 16 ? PS * 8 * half : 0;
         b_lane = DY_BYTES / 4 + (pr * Base::HC + pc0) * BC + wn * 32 + l31;
     }
 
@@ -256,28 +265,30 @@ struct WgradSplitCore : WgradCore<CW> {
         }
         const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Am = __builtin_bit_cast(bf16x8, am), Al = __builtin_bit_cast(bf16x8, al);
 #pragma unroll
-        for (int ky = 0; ky < 3; ky++) {
-            Split x[10];
+        for (int ky = 0; ky < KS; ky++) {
+            // the NX words of halo row ky this lane's 8 pixels touch (stride 2: pixel j of tap kx is word 2 j + kx of 17)
+            Split x[NX + 1];
 #pragma unroll
-            for (int j = 0; j < 10; j += 2)
-                split2(st[b_lane + (ky * Base::HC + j) * BC], st[b_lane + (ky * Base::HC + j + 1) * BC], x[j], x[j + 1]);
-            bf16x8 Bh[3], Bm[3], Bl[3];
+            for (int j = 0; j < NX; j += 2)
+                split2(st[b_lane + (ky * Base::HC + j) * BC], st[b_lane + (ky * Base::HC + (j + 1 < NX ? j + 1 : j)) * BC], x[j], x[j + 1]);
+            bf16x8 Bh[KS], Bm[KS], Bl[KS];
 #pragma unroll
-            for (int kx = 0; kx < 3; kx++) {
+            for (int kx = 0; kx < KS; kx++) {
                 u32x4 h, m, l;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    h[j] = pack(x[kx + 2 * j].h, x[kx + 2 * j + 1].h);
-                    m[j] = pack(x[kx + 2 * j].m, x[kx + 2 * j + 1].m);
-                    l[j] = pack(x[kx + 2 * j].l, x[kx + 2 * j + 1].l);
+                    const int w0 = kx + PS * 2 * j, w1 = kx + PS * (2 * j + 1);
+                    h[j] = pack(x[w0].h, x[w1].h);
+                    m[j] = pack(x[w0].m, x[w1].m);
+                    l[j] = pack(x[w0].l, x[w1].l);
                 }
                 Bh[kx] = __builtin_bit_cast(bf16x8, h); Bm[kx] = __builtin_bit_cast(bf16x8, m); Bl[kx] = __builtin_bit_cast(bf16x8, l);
             }
             // smallest terms first; the three taps of the row alternate so that consecutive MFMAs are independent
-            auto mac = [&](const bf16x8& av, const bf16x8 (&bv)[3]) {
+            auto mac = [&](const bf16x8& av, const bf16x8 (&bv)[KS]) {
 #pragma unroll
-                for (int kx = 0; kx < 3; kx++)
-                    acc.t[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[kx], acc.t[ky * 3 + kx], 0, 0, 0);
+                for (int kx = 0; kx < KS; kx++)
+                    acc.t[ky * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[kx], acc.t[ky * KS + kx], 0, 0, 0);
             };
             mac(Am, Bm);
             mac(Al, Bh);
@@ -291,7 +302,7 @@ struct WgradSplitCore : WgradCore<CW> {
     // nk chunks (even, >= 2)
     __device__ __forceinline__ void run(Acc& acc, int nk) {
 #pragma unroll
-        for (int t = 0; t < 9; t++)
+        for (int t = 0; t < KS * KS; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc.t[t][r] = 0.f;
         this->issue(0, 0);
@@ -307,9 +318,12 @@ struct WgradSplitCore : WgradCore<CW> {
     }
 };
 
-template <int CW, bool SPLIT>
+template <int CW, bool SPLIT, int STR = 1, int KS = 3>
 __global__ __launch_bounds__(THREADS, 2) void conv_wgrad_kernel(const WgradArgs g) {
-    __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE_BYTES / 4];
+    static_assert(SPLIT || (STR == 1 && KS == 3), "the fp32 core's compile-time read offsets are the stride-1 3x3 halo's");
+    using Core = std::conditional_t<SPLIT, WgradSplitCore<CW, STR, KS>, WgradCore<CW, STR, KS>>;
+    constexpr int NT = KS * KS;
+    __shared__ __attribute__((aligned(16))) float lds[NSTAGE * Core::STAGE_BYTES / 4];
     // workgroup b runs on XCD b % 8 and takes a contiguous share of the (split, co block, ci block) list, split slowest: the
     // workgroups that read the same pixels sit on one XCD's L2
     const int total = g.splits * g.ncob * g.ncib;
@@ -321,20 +335,19 @@ __global__ __launch_bounds__(THREADS, 2) void conv_wgrad_kernel(const WgradArgs 
     const int cob = blk / g.ncib, cib = blk - cob * g.ncib;
     const int first = split * g.chunks_per_split;
     const int nk = min(g.chunks_per_split, g.total_chunks - first);
-    using Core = std::conditional_t<SPLIT, WgradSplitCore<CW>, WgradCore<CW>>;
     Core core(g, lds, cob, cib, first);
     typename Core::Acc acc;
     core.run(acc, nk);
     const int half = core.lane >> 5, l31 = core.lane & 31;
     const int wm = core.wave >> 1, wn = core.wave & 1;
-    float* out = g.partial + (size_t)split * g.Cout * 9 * g.Cin;
+    float* out = g.partial + (size_t)split * g.Cout * NT * g.Cin;
     const int ci = cib * BC + wn * 32 + l31;
 #pragma unroll
-    for (int tap = 0; tap < 9; tap++)
+    for (int tap = 0; tap < NT; tap++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int co = cob * BC + wm * 32 + scp::acc_row(r, half);
-            out[((size_t)co * 9 + tap) * g.Cin + ci] = acc.t[tap][r];
+            out[((size_t)co * NT + tap) * g.Cin + ci] = acc.t[tap][r];
         }
 }
 
@@ -396,25 +409,35 @@ Plan make_plan(int N, int H, int W, int Cin, int Cout) {
 
 }  // namespace
 
+namespace {
+// which (ksize, stride) the kernels take: 3x3 stride 1 (both cores); 3x3 stride 2 and 1x1 stride 2 (split core; H, W even)
+bool shape_ok(int H, int W, int ksize, int stride, int split) {
+    if (ksize == 3 && stride == 1) return true;
+    return split && stride == 2 && (ksize == 3 || ksize == 1) && H % 2 == 0 && W % 2 == 0;
+}
+}  // namespace
+
 extern "C" size_t scp_conv_nhwc_weight_grad_workspace(int N, int H, int W, int Cin, int Cout, int ksize, int stride) {
-    if (ksize != 3 || stride != 1) return 0;
-    const Plan p = make_plan(N, H, W, Cin, Cout);
+    if (!shape_ok(H, W, ksize, stride, 1)) return 0;
+    const Plan p = make_plan(N, H / stride, W / stride, Cin, Cout);
     if (!p.ok) return 0;
-    return (size_t)p.splits * Cout * 9 * Cin * sizeof(float);
+    return (size_t)p.splits * Cout * ksize * ksize * Cin * sizeof(float);
 }
 
 extern "C" int scp_conv_nhwc_weight_grad(const float* x, const float* dy, float* dw, float* dbias, void* workspace,
                                          size_t workspace_bytes, int N, int H, int W, int Cin, int Cout, int ksize, int stride,
                                          int split, void* stream) {
     if (!x || !dy || !dw || !workspace) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: null argument");
-    if (ksize != 3 || stride != 1) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: 3x3 / stride 1 only");
+    if (!shape_ok(H, W, ksize, stride, split))
+        return scp::fail(hipErrorInvalidValue, "conv_weight_grad: 3x3 / stride 1, or (split core) 3x3 and 1x1 / stride 2 on even maps");
     if (dbias) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: the bias gradient comes from scp_bias_leaky_relu_backward");
-    const Plan p = make_plan(N, H, W, Cin, Cout);
-    if (!p.ok) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: needs power-of-two H, W >= 8 and channel counts that are multiples of 64");
-    const size_t need = (size_t)p.splits * Cout * 9 * Cin * sizeof(float);
+    const int Ho = H / stride, Wo = W / stride, nt = ksize * ksize;
+    const Plan p = make_plan(N, Ho, Wo, Cin, Cout);
+    if (!p.ok) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: needs a power-of-two output map >= 8 x 8 and channel counts that are multiples of 64");
+    const size_t need = (size_t)p.splits * Cout * nt * Cin * sizeof(float);
     if (workspace_bytes < need) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: workspace too small");
     const long in_bytes = (long)N * H * W * Cin * 4;
-    if (in_bytes >= (1l << 31) || (long)N * H * W * Cout * 4 >= (1l << 32)) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: tensor too large");
+    if (in_bytes >= (1l << 31) || (long)N * Ho * Wo * Cout * 4 >= (1l << 32)) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: tensor too large");
     WgradArgs g{};
     g.x = x; g.dy = dy; g.partial = static_cast<float*>(workspace);
     g.lgW = p.lgW; g.lgH = p.lgH; g.Cin = Cin; g.Cout = Cout;
@@ -423,14 +446,21 @@ extern "C" int scp_conv_nhwc_weight_grad(const float* x, const float* dy, float*
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int total = p.splits * p.ncob * p.ncib;
     const dim3 grid(((total + 7) >> 3) << 3);
-    if (split) {
-        if (W >= 16) hipLaunchKernelGGL((conv_wgrad_kernel<16, true>), grid, dim3(THREADS), 0, st, g);
+    const bool wide = Wo >= 16;
+    if (stride == 2 && ksize == 3) {
+        if (wide) hipLaunchKernelGGL((conv_wgrad_kernel<16, true, 2, 3>), grid, dim3(THREADS), 0, st, g);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<8, true, 2, 3>), grid, dim3(THREADS), 0, st, g);
+    } else if (stride == 2) {
+        if (wide) hipLaunchKernelGGL((conv_wgrad_kernel<16, true, 2, 1>), grid, dim3(THREADS), 0, st, g);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<8, true, 2, 1>), grid, dim3(THREADS), 0, st, g);
+    } else if (split) {
+        if (wide) hipLaunchKernelGGL((conv_wgrad_kernel<16, true>), grid, dim3(THREADS), 0, st, g);
         else hipLaunchKernelGGL((conv_wgrad_kernel<8, true>), grid, dim3(THREADS), 0, st, g);
     } else {
-        if (W >= 16) hipLaunchKernelGGL((conv_wgrad_kernel<16, false>), grid, dim3(THREADS), 0, st, g);
+        if (wide) hipLaunchKernelGGL((conv_wgrad_kernel<16, false>), grid, dim3(THREADS), 0, st, g);
         else hipLaunchKernelGGL((conv_wgrad_kernel<8, false>), grid, dim3(THREADS), 0, st, g);
     }
-    const int n4 = Cout * 9 * Cin / 4;
+    const int n4 = Cout * nt * Cin / 4;
     hipLaunchKernelGGL(wgrad_fold_kernel, dim3((n4 + 15) / 16), dim3(256), 0, st, static_cast<const float*>(workspace), dw, n4, p.splits);
     return scp::check_launch("conv_weight_grad");
 }

@@ -148,6 +148,13 @@ struct PlanesASource {
     }
 };
 
+// an A source may also choose which chunk of W goes with chunk kc of A (`int w_chunk(int kc) const`: the stride-2 input gradient of
+// csrc/conv_igemm.hip walks a subset of the nine taps of the weight planes); default: the same index
+template <class T, class = void>
+struct has_w_chunk : std::false_type {};
+template <class T>
+struct has_w_chunk<T, std::void_t<decltype(std::declval<const T&>().w_chunk(0))>> : std::true_type {};
+
 template <class CFG, class ASRC = std::conditional_t<CFG::APLANES, PlanesASource<CFG>, LinearASource<CFG>>>
 struct SplitGemmCore {
     struct Acc { f32x16 t[CFG::NT]; };
@@ -217,10 +224,12 @@ struct SplitGemmCore {
         const unsigned dst = lds0 + stage * CFG::STAGE_BYTES;
         kc += kc0;
         static_for<0, CFG::A_PER>([&](auto i) { asrc.template issue<decltype(i)::value>(kc, dst, wave); });
+        int wkc = kc;
+        if constexpr (has_w_chunk<ASRC>::value) wkc = __builtin_amdgcn_readfirstlane(asrc.w_chunk(kc));
         static_for<0, CFG::W_PER>([&](auto i) {
             constexpr int I = decltype(i)::value;
             if ((I + 1) * CFG::NW <= CFG::W_PIECES || wave + CFG::NW * I < CFG::W_PIECES)      // wavefront-uniform
-                glds16(w_off[I], w_base + (size_t)kc * (CFG::TILED ? 3072 : 32), dst + CFG::A_BYTES + (unsigned)(wave + CFG::NW * I) * 1024u);
+                glds16(w_off[I], w_base + (size_t)wkc * (CFG::TILED ? 3072 : 32), dst + CFG::A_BYTES + (unsigned)(wave + CFG::NW * I) * 1024u);
         });
     }
 

@@ -93,6 +93,7 @@ SYMBOLS = {
     "scp_batchnorm_apply": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_long, _I, _I, _P, _P]),
     "scp_conv_weight_planes": (ctypes.c_int, [_P, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _I, _I, _I,
                                               _P, _P, _P]),
+    "scp_conv_nhwc_dgrad_stride2": (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "scp_conv_nhwc_partial_rows": (ctypes.c_int, [_I, _I, _I, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "scp_conv_nhwc_weight_grad_workspace": (ctypes.c_size_t, [_I, _I, _I, _I, _I, _I, _I]),
     "scp_conv_nhwc_weight_grad": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -11,9 +11,10 @@ model/module/network/image_encoder.py:119-139.  ONE autograd op:
 (net_blocks.py:336-359 with_bn=False); bias and activation live in the convolution's epilogue.
 
 What the own kernels do not cover goes to MIOpen through ATen, layer by layer and direction by direction, never silently for a
-whole network: the 7x7 stem (Cin = 3) and the backward of the three stride-2 3x3 layers (`aten.convolution_backward`); the 1x1
-stride-2 projections' backward is an own 1x1 product scattered to the even pixels (input gradient) and one gather + library GEMM
-(weight gradient).  CPU tensors, eval-mode BatchNorm, SyncBatchNorm and non-fp32 activations (configs[4] bf16
+whole network: the 7x7 stem (Cin = 3).  The stride-2 layers' backward runs on the split main loop (round 4: input gradient by
+parity class, scp_conv_nhwc_dgrad_stride2; weight gradient of the 3x3 and of the 1x1 projections by the halo-block kernel with a
+strided block); with SCP_CONV_GEMM=fp32 / SCP_CONV_WGRAD=fp32 those directions fall back to `aten.convolution_backward` / one
+gather + library GEMM.  The 1x1 projections' input gradient is an own 1x1 product scattered to the even pixels.  CPU tensors, eval-mode BatchNorm, SyncBatchNorm and non-fp32 activations (configs[4] bf16
 autocast) take the stock composition, which is also what the tests compare with."""
 import ctypes
 
@@ -44,16 +45,21 @@ def own_forward_ok(x, weight, stride):
 
 
 def _own_dgrad_ok(weight, stride):
-    """stride 1, or the 1x1 stride-2 projections of the ResNet trunk (their input gradient is a 1x1 convolution of dy scattered to
-    the even pixels)"""
+    """stride 1; the 1x1 stride-2 projections of the ResNet trunk (their input gradient is a 1x1 convolution of dy scattered to
+    the even pixels); the 3x3 stride-2 layers on the split main loop (scp_conv_nhwc_dgrad_stride2: by input-pixel parity class)"""
     cout, k = weight.shape[0], weight.shape[2]
-    return (stride == 1 or (stride == 2 and k == 1)) and cout >= 32 and _pow2(cout)
+    return (stride == 1 or (stride == 2 and (k == 1 or CONV_MODE == "split"))) and cout >= 32 and _pow2(cout)
 
 
 def _own_wgrad_ok(x_shape, weight, stride):
+    """3x3 stride 1; on the split core also the stride-2 layers of the trunk (3x3 conv1 and the 1x1 projection of layer2..4)"""
     n, cin, h, w = x_shape
-    return (stride == 1 and weight.shape[2] == 3 and h >= 8 and w >= 8 and _pow2(h) and _pow2(w) and cin % 64 == 0
-            and weight.shape[0] % 64 == 0 and (n * h * w) % 32 == 0)
+    k = weight.shape[2]
+    if not ((stride == 1 and k == 3) or (stride == 2 and k in (1, 3) and WGRAD_MODE == "split" and h % 2 == 0 and w % 2 == 0)):
+        return False
+    ho, wo = h // stride, w // stride
+    return (ho >= 8 and wo >= 8 and _pow2(ho) and _pow2(wo) and cin % 64 == 0 and weight.shape[0] % 64 == 0
+            and (n * ho * wo) % 32 == 0)
 
 
 def _conv_out_shape(x, weight, stride):
@@ -181,7 +187,13 @@ def _conv_backward(x, weight, g, stride, need_dx, need_dw, planes=None):
     dx = dw = None
     own_dx = need_dx and _own_dgrad_ok(weight, stride)
     own_dw = need_dw and _own_wgrad_ok(x.shape, weight, stride)
-    if own_dx:
+    if own_dx and stride == 2 and k == 3:
+        own_dx = planes is not None and "dgrad" in planes and h % 2 == 0 and w % 2 == 0
+        if own_dx:
+            dx = torch.empty(x.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+            capi.check(L.scp_conv_nhwc_dgrad_stride2(_ptr(g), _ptr(planes["dgrad"]), _ptr(dx), n, h // 2, w // 2, cout, cin,
+                                                     capi.current_stream()), "conv_nhwc_dgrad_stride2")
+    elif own_dx:
         # the forward kernel on dy with the weights as [Cin, k, k, Cout], taps flipped
         wt3 = planes.get("dgrad") if planes else None
         wt = None if wt3 is not None else weight.flip(2, 3).permute(1, 2, 3, 0).contiguous()
@@ -197,10 +209,10 @@ def _conv_backward(x, weight, g, stride, need_dx, need_dw, planes=None):
             dx = torch.empty(x.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last).zero_()
             dx[:, :, ::2, ::2] = dense
     if own_dw:
-        ws_bytes = L.scp_conv_nhwc_weight_grad_workspace(n, h, w, cin, cout, 3, 1)
+        ws_bytes = L.scp_conv_nhwc_weight_grad_workspace(n, h, w, cin, cout, k, stride)
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
         dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-        capi.check(L.scp_conv_nhwc_weight_grad(_ptr(x), _ptr(g), _ptr(dw), _ptr(None), _ptr(ws), ws_bytes, n, h, w, cin, cout, 3, 1,
+        capi.check(L.scp_conv_nhwc_weight_grad(_ptr(x), _ptr(g), _ptr(dw), _ptr(None), _ptr(ws), ws_bytes, n, h, w, cin, cout, k, stride,
                                                int(WGRAD_MODE == "split"), capi.current_stream()), "conv_nhwc_weight_grad")
     if need_dw and not own_dw and k == 1 and stride == 2:
         # weight gradient of a 1x1 stride-2 projection = dy^T (Cout x pixels) @ x at the even pixels (pixels x Cin): one gather + one

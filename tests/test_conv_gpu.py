@@ -74,6 +74,32 @@ def test_conv_forward_and_input_gradient_vs_float64(n, cin, cout, h, w, k, strid
         assert err <= 1e-5 * dx_ref.abs().max().item(), err
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 128, 16, 16), (3, 32, 64, 8, 12), (32, 64, 128, 64, 64), (32, 128, 256, 32, 32),
+                                           (32, 256, 512, 16, 16), (5, 128, 128, 6, 10), (1, 192, 64, 4, 4)])
+def test_stride2_input_gradient_vs_float64(n, cin, cout, h, w, conv_core):
+    """scp_conv_nhwc_dgrad_stride2: the 3x3 / stride-2 / pad-1 input gradient by parity class (split main loop only), every dx element
+    written exactly once (the output starts as NaN)"""
+    if conv_core != "split":
+        pytest.skip("the stride-2 input gradient runs on the split main loop only")
+    from scp_amd import capi, fused_conv
+    L = capi.lib()
+    g = torch.Generator().manual_seed(n + cin + cout + h)
+    x64 = torch.randn(n, cin, h, w, generator=g).double().cuda().requires_grad_(True)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).cuda()
+    ref = F.conv2d(x64, wt.double(), None, 2, 1)
+    dy = torch.randn(ref.shape, generator=g).cuda()
+    (dx_ref,) = torch.autograd.grad(ref, x64, dy.double())
+    fwd = torch.empty(fused_conv.tiled_planes_numel(cout, 9 * cin), dtype=torch.bfloat16, device="cuda")
+    dgr = torch.empty(fused_conv.tiled_planes_numel(cin, 9 * cout), dtype=torch.bfloat16, device="cuda")
+    capi.check(L.scp_conv_weight_planes(P(wt), wt.stride(0), wt.stride(1), wt.stride(2), wt.stride(3), cout, cin, 3, P(fwd), P(dgr),
+                                        capi.current_stream()), "conv_weight_planes")
+    dx = torch.full((n, h, w, cin), float("nan"), device="cuda")
+    capi.check(L.scp_conv_nhwc_dgrad_stride2(P(dy.permute(0, 2, 3, 1).contiguous()), P(dgr), P(dx), n, h // 2, w // 2, cout, cin,
+                                             capi.current_stream()), "conv_nhwc_dgrad_stride2")
+    err = (dx.double() - dx_ref.permute(0, 2, 3, 1)).abs().max().item()
+    assert err <= 1e-5 * dx_ref.abs().max().item(), err
+
+
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 16, 16), (3, 128, 128, 8, 8), (2, 64, 256, 8, 8), (32, 64, 64, 64, 64),
                                            (32, 256, 256, 16, 16), (31, 512, 512, 8, 8)])   # the last two: split-K + fold epilogue
 def test_conv_epilogues(n, cin, cout, h, w):
@@ -115,6 +141,32 @@ def test_conv_weight_gradient_vs_float64(n, cin, cout, h, w):
     for _ in range(2):           # twice: the second call must not depend on what the first left in the workspace
         capi.check(L.scp_conv_nhwc_weight_grad(P(x), P(dy), P(dw), P(None), P(ws), ws_bytes, n, h, w, cin, cout, 3, 1,
                                                int(CORE == "split"), capi.current_stream()), "conv_nhwc_weight_grad")
+    err = (dw.double() - dw_ref.permute(0, 2, 3, 1)).abs().max().item()
+    assert err <= 2e-5 * dw_ref.abs().max().item(), (err, dw_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k", [(2, 64, 128, 32, 32, 3), (2, 64, 64, 16, 32, 3), (32, 64, 128, 64, 64, 3), (32, 128, 256, 32, 32, 3),
+                                             (32, 256, 512, 16, 16, 3), (4, 64, 128, 16, 16, 1), (32, 64, 128, 64, 64, 1), (32, 256, 512, 16, 16, 1),
+                                             (2, 128, 64, 32, 64, 1)])
+def test_stride2_weight_gradient_vs_float64(n, cin, cout, h, w, k, conv_core):
+    """the stride-2 layers of the trunk (3x3 pad 1 and the 1x1 projections) on the halo-block kernel with a strided block"""
+    if conv_core != "split":
+        pytest.skip("stride-2 weight gradients run on the split core only")
+    from scp_amd import capi
+    L = capi.lib()
+    g = torch.Generator().manual_seed(cin * 5 + cout + h + k)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    dy = torch.randn(n, h // 2, w // 2, cout, generator=g).cuda()
+    w64 = torch.zeros(cout, cin, k, k, dtype=torch.float64, device="cuda", requires_grad=True)
+    out = F.conv2d(x.permute(0, 3, 1, 2).double(), w64, None, 2, k // 2)
+    (dw_ref,) = torch.autograd.grad(out, w64, dy.permute(0, 3, 1, 2).double())
+    ws_bytes = L.scp_conv_nhwc_weight_grad_workspace(n, h, w, cin, cout, k, 2)
+    assert ws_bytes > 0
+    ws = torch.empty(ws_bytes // 4, device="cuda")
+    dw = torch.full((cout, k, k, cin), float("nan"), device="cuda")
+    for _ in range(2):
+        capi.check(L.scp_conv_nhwc_weight_grad(P(x), P(dy), P(dw), P(None), P(ws), ws_bytes, n, h, w, cin, cout, k, 2, 1,
+                                               capi.current_stream()), "conv_nhwc_weight_grad")
     err = (dw.double() - dw_ref.permute(0, 2, 3, 1)).abs().max().item()
     assert err <= 2e-5 * dw_ref.abs().max().item(), (err, dw_ref.abs().max().item())
 

@@ -1,7 +1,7 @@
 """tools/conv_bench.py -- the encoder's convolution layers at B=32, 256x256 (model/module/network/image_encoder.py:119-193): own
 NHWC implicit-GEMM kernels (csrc/conv_igemm.hip forward / input gradient, csrc/conv_wgrad.hip weight gradient) against MIOpen
 through F.conv2d / autograd (cudnn.benchmark, channels_last), device time per launch and TFLOP/s, per layer and summed per
-encoder pass.  Layers the own kernels do not cover (7x7 stem, stride-2 backward) are listed with MIOpen only."""
+encoder pass.  Layers the own kernels do not cover are listed with MIOpen only."""
 import ctypes
 import os
 import sys
@@ -71,13 +71,24 @@ for name, cin, cout, k, s, h, cnt in LAYERS:
             dxo = torch.empty(B, h, h, cin, device="cuda")
             od = t(lambda: capi.check(L.scp_conv_nhwc_forward(P(gn), P(None if SPLIT else wt), P(wt3), P(None), P(dxo), P(None), B, h, h, cout, cin, k, 1, 0, 0.0, P(skd), skd_b,
                                                               capi.current_stream()), "dgrad"))
-            if k == 3:
-                ws_bytes = L.scp_conv_nhwc_weight_grad_workspace(B, h, h, cin, cout, 3, 1)
-                if ws_bytes:
-                    ws = torch.empty(ws_bytes // 4, device="cuda")
-                    dw = torch.empty(cout, 3, 3, cin, device="cuda")
-                    ow = t(lambda: capi.check(L.scp_conv_nhwc_weight_grad(P(xn), P(gn), P(dw), P(None), P(ws), ws_bytes, B, h, h, cin, cout,
-                                                                          3, 1, int(WSPLIT), capi.current_stream()), "wgrad"))
+        elif SPLIT and k == 3:
+            # stride 2: the parity-class input gradient on the `dgrad` planes of scp_conv_weight_planes
+            wd = w.detach()
+            pf = torch.empty(fused_conv.tiled_planes_numel(cout, 9 * cin), dtype=torch.bfloat16, device="cuda")
+            pd = torch.empty(fused_conv.tiled_planes_numel(cin, 9 * cout), dtype=torch.bfloat16, device="cuda")
+            capi.check(L.scp_conv_weight_planes(P(wd), wd.stride(0), wd.stride(1), wd.stride(2), wd.stride(3), cout, cin, 3, P(pf), P(pd),
+                                                capi.current_stream()), "planes")
+            dxo = torch.empty(B, h, h, cin, device="cuda")
+            od = t(lambda: capi.check(L.scp_conv_nhwc_dgrad_stride2(P(gn), P(pd), P(dxo), B, ho, ho, cout, cin, capi.current_stream()), "dgrad s2"))
+            (dx_ref,) = torch.autograd.grad(y, x, g, retain_graph=True)
+            assert os.environ.get("SCP_BENCH_NOCHECK") or (dxo - dx_ref.permute(0, 2, 3, 1)).abs().max() <= 2e-4 * dx_ref.abs().max()
+        if (k == 3 and s == 1) or (s == 2 and WSPLIT):
+            ws_bytes = L.scp_conv_nhwc_weight_grad_workspace(B, h, h, cin, cout, k, s)
+            if ws_bytes:
+                ws = torch.empty(ws_bytes // 4, device="cuda")
+                dw = torch.empty(cout, k, k, cin, device="cuda")
+                ow = t(lambda: capi.check(L.scp_conv_nhwc_weight_grad(P(xn), P(gn), P(dw), P(None), P(ws), ws_bytes, B, h, h, cin, cout,
+                                                                      k, s, int(WSPLIT), capi.current_stream()), "wgrad"))
     for key, v in (("mf", mf), ("md", md), ("mw", mw), ("of", of), ("od", od), ("ow", ow)):
         # a layer the own kernels do not cover counts with MIOpen's time on both sides (that is what the encoder runs)
         alt = {"of": mf, "od": md, "ow": mw}.get(key)
