@@ -327,6 +327,22 @@ size_t scp_conv_nhwc_splitk_workspace(int N, int H, int W, int Cin, int Cout, in
  * NULL = not wanted), one launch */
 int scp_conv_weight_planes(const float* w, long long s_co, long long s_ci, long long s_ky, long long s_kx, int Cout, int Cin, int ksize,
                            void* planes_fwd, void* planes_dgrad, void* stream);
+/* ---- encoder stem: 7x7 / stride 2 / pad 3, 3 -> 64 channels (torchvision ResNet18 conv1 + bn1, image_encoder.py:122-124) -------
+ * csrc/conv_stem.hip, fp32 matrix cores.  x [N,3,H,W] NCHW contiguous (H, W even), w [64,3,7,7] with element strides ws_*,
+ * y [N,H/2,W/2,64] NHWC raw convolution.  workspace != NULL: also the batch statistics of the BatchNorm that follows, exactly as
+ * scp_conv_nhwc_forward_bn (workspace >= 2 * scp_stem_conv_tiles(N,H,W) * 64 floats, ticket a zeroed device word); NULL: convolution only.
+ * scp_stem_conv_weight_grad: dw[64,3,7,7] (element strides ds_*) = sum over output pixels of dy[N,H/2,W/2,64] (x) x-patches;
+ * workspace >= scp_stem_conv_weight_grad_workspace bytes (per-workgroup partial blocks, added in a fixed order: deterministic).
+ * The image carries no gradient: there is no input-gradient entry. */
+int scp_stem_conv_tiles(int N, int H, int W);
+int scp_stem_conv_forward_bn(const float* x, const float* w, long long ws_co, long long ws_ci, long long ws_ky, long long ws_kx, float* y,
+                             int N, int H, int W, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             long long* batches_tracked, float momentum, float eps, float* save_mean, float* save_invstd,
+                             float* save_scale, float* save_shift, void* workspace, size_t workspace_bytes, unsigned* ticket,
+                             void* stream);
+size_t scp_stem_conv_weight_grad_workspace(int N, int H, int W);
+int scp_stem_conv_weight_grad(const float* x, const float* dy, float* dw, long long ds_co, long long ds_ci, long long ds_ky,
+                              long long ds_kx, void* workspace, size_t workspace_bytes, int N, int H, int W, void* stream);
 /* input gradient of a 3x3 / stride-2 / pad-1 convolution (torchvision BasicBlock conv1 of layer2..4, image_encoder.py:128-134):
  * dy [N,Ho,Wo,Cout] -> dx [N,2 Ho,2 Wo,Cin]; w_dgrad_planes = the planes_dgrad of scp_conv_weight_planes.  The input pixels are
  * taken by parity class (1, 2, 2, 4 contributing taps), each an implicit GEMM over the dy grid on the split main loop; every dx

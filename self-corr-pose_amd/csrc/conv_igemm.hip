@@ -23,6 +23,7 @@
 // tools/probes/gemm_v3.hip); algorithmic flops 2 M Cout taps Cin; algorithmic bytes 4 (M_in Cin + taps Cin Cout + M Cout).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <utility>
 
 #include "bn_common.h"
@@ -271,8 +272,7 @@ __global__ __launch_bounds__(FCFG::THREADS, 2) void conv_igemm_kernel(const Conv
 // a tap reading dy at (a + [k == 0], b + [k == 0]) -- beyond the grid: zeros through the buffer descriptor, as in the forward kernel.
 // 9 tap-products per 4 pixels instead of the 36 a "forward kernel on a zero-stuffed dy" would do, and no zeros written or read.
 // The W operand is the `dgrad` plane set of conv_weight_planes_kernel (rows = ci, K = (flipped tap, co)): the class walks the chunks
-// of ITS taps (SplitGemmCore's w_chunk hook).  All four classes in one launch, interleaved tile by tile so that every XCD gets the
-// same mix and the four tiles that read one dy panel run next to each other.
+// of ITS taps (SplitGemmCore's w_chunk hook).  All four classes in one launch (see the kernel for how they are dealt to workgroups).
 template <class CFG>
 struct Dgrad2ASource {
     __amdgpu_buffer_rsrc_t rsrc;
@@ -331,35 +331,48 @@ __global__ __launch_bounds__(FCFG::THREADS, 2) void conv_dgrad_s2_kernel(const C
     using CFG = SplitOf<FCFG>;
     __shared__ __attribute__((aligned(16))) float lds[CFG::LDS_BYTES / 4];
     using Core = scp::SplitGemmCore<CFG, Dgrad2ASource<CFG>>;
-    const int total = 4 * g.tiles_m_kernel * g.nblk_n;
+    // two kinds of workgroups per tile of the dy grid: one takes the 4-tap class, the other the 2 + 2 + 1-tap classes one after the
+    // other -- 4 and 5 tap-products each, so that a launch of ~one workgroup per CU is balanced (one class per workgroup left the
+    // CUs that drew 4-tap tiles with 4x the work of those that drew the centre tap: 64 us against the forward's 46 for equal flops)
+    // g.ksplit = workgroups per tile: 2 (the two kinds above) or 4 (one class each: more, smaller workgroups for the layers whose
+    // launch would otherwise be one 4-wavefront workgroup per CU -- too few wavefronts to cover the DMA latency)
+    const int per_tile = g.ksplit;
+    const int total = per_tile * g.tiles_m_kernel * g.nblk_n;
     const int per_xcd = (total + 7) >> 3;
     const int lid0 = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (lid0 >= total) return;
-    const int cls = __builtin_amdgcn_readfirstlane(3 - (lid0 & 3)), lid = lid0 >> 2;             // the 4-tap class first
-    const int py = cls >> 1, px = cls & 1;
+    const int sub = __builtin_amdgcn_readfirstlane(lid0 % per_tile), lid = lid0 / per_tile;
+    const int ncls = per_tile == 4 ? 1 : (sub ? 3 : 1), cls0 = per_tile == 4 ? 3 - sub : (sub ? 2 : 3);
     const int bm = lid / g.nblk_n, bn = lid - bm * g.nblk_n;
     const int m0 = bm * CFG::BM, n0 = bn * CFG::BN;
     Core core(lds);
-    core.asrc.set(g, py, px, m0, core.wave, core.lane);
     core.set_w_rows(g.w_split, g.Cout, 9 * g.Cin, [&](int r) { return min(n0 + r, g.Cout - 1); });
-    typename Core::Acc acc;
-    core.run(acc, ((1 + py) * (1 + px)) << g.lg_cpt);
-
     const int half = core.lane >> 5, l31 = core.lane & 31;
     const int hw = g.H * g.W;
+#pragma nounroll
+    for (int c = 0; c < ncls; c++) {
+        const int cls = cls0 - c;
+        const int py = cls >> 1, px = cls & 1;
+        if (c) __syncthreads();                         // the previous class's last fragment reads are done in every wavefront
+        core.asrc.set(g, py, px, m0, core.wave, core.lane);
+        typename Core::Acc acc;
+        core.run(acc, ((1 + py) * (1 + px)) << g.lg_cpt);
+        int m0v = m0;
+        asm volatile("" : "+v"(m0v));                   // the row -> pixel divisions below are class-invariant: not hoisted (64 x 4 VGPRs)
 #pragma unroll
-    for (int i = 0; i < CFG::WM; i++) {
-        const int mb = m0 + core.row_base() + 32 * i;
+        for (int i = 0; i < CFG::WM; i++) {
+            const int mb = m0v + core.row_base() + 32 * i;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int m = mb + scp::acc_row(r, half);
-            const int img = m / hw, rem = m - img * hw;
-            const int a = rem / g.W, b = rem - a * g.W;
-            const size_t orow = ((size_t)(img * 2 * g.H + 2 * a + py) * (2 * g.W) + 2 * b + px) * g.Cout;
+            for (int r = 0; r < 16; r++) {
+                const int m = mb + scp::acc_row(r, half);
+                const int img = m / hw, rem = m - img * hw;
+                const int a = rem / g.W, b = rem - a * g.W;
+                const size_t orow = ((size_t)(img * 2 * g.H + 2 * a + py) * (2 * g.W) + 2 * b + px) * g.Cout;
 #pragma unroll
-            for (int j = 0; j < CFG::WN; j++) {
-                const int n = n0 + core.col_base() + 32 * j + l31;
-                if (m < g.M && n < g.Cout) g.y[orow + n] = acc.t[i * CFG::WN + j][r];
+                for (int j = 0; j < CFG::WN; j++) {
+                    const int n = n0 + core.col_base() + 32 * j + l31;
+                    if (m < g.M && n < g.Cout) g.y[orow + n] = acc.t[i * CFG::WN + j][r];
+                }
             }
         }
     }
@@ -650,11 +663,26 @@ extern "C" int scp_conv_nhwc_dgrad_stride2(const float* dy, const void* w_dgrad_
         using CFG = decltype(cfg_tag);
         g.nblk_n = (g.Cout + CFG::BN - 1) / CFG::BN;
         g.tiles_m = g.tiles_m_kernel = (g.M + CFG::BM - 1) / CFG::BM;
-        const int total = 4 * g.tiles_m * g.nblk_n;
+        const int total = g.ksplit * g.tiles_m * g.nblk_n;
         hipLaunchKernelGGL((conv_dgrad_s2_kernel<CFG>), dim3(((total + 7) >> 3) << 3), dim3(CFG::THREADS), 0, st, g);
     };
-    if (Cin <= 64) launch(Cfg256x64{});
-    else if (4 * ((M + 127) / 128) * ((Cin + 127) / 128) >= 256) launch(Cfg128x128{});
+    // the largest tile that still gives ~one workgroup per CU with two workgroups per tile; tools/conv_bench.py (SCP_DGRAD2_PLAN=
+    // "<tile 0..3><workgroups per tile 2|4>" overrides, for sweeps)
+    auto wgs = [&](long bm, long bn) { return 2 * ((M + bm - 1) / bm) * ((Cin + bn - 1) / bn); };
+    // measured (B = 32, 256^2: layer2.0 / 3.0 / 4.0 at 66 / 62 / 78 us, MIOpen 65 / 69 / 73): 256 x 64 tiles, one class per workgroup
+    // for the 64-channel input; else two workgroups per tile while that fills the machine, and four 64 x 128 workgroups per tile
+    // for the smallest maps
+    int cfg = Cin <= 64 ? 0 : wgs(128, 128) >= 200 ? 3 : 1;
+    g.ksplit = (Cin <= 64 || (cfg == 1 && wgs(64, 128) < 200)) ? 4 : 2;
+    if (const char* e = getenv("SCP_DGRAD2_PLAN")) {
+        if (e[0] >= '0' && e[0] <= '3' && (e[1] == '2' || e[1] == '4')) {
+            if (Cin > 64 || e[0] == '0' || e[0] == '2') cfg = e[0] - '0';
+            g.ksplit = e[1] - '0';
+        }
+    }
+    if (cfg == 0) launch(Cfg256x64{});
+    else if (cfg == 3) launch(Cfg128x128{});
+    else if (cfg == 1) launch(Cfg64x128{});
     else launch(Cfg64x64{});
     return scp::check_launch("conv_nhwc_dgrad_stride2");
 }

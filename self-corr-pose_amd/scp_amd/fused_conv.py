@@ -11,7 +11,7 @@ model/module/network/image_encoder.py:119-139.  ONE autograd op:
 (net_blocks.py:336-359 with_bn=False); bias and activation live in the convolution's epilogue.
 
 What the own kernels do not cover goes to MIOpen through ATen, layer by layer and direction by direction, never silently for a
-whole network: the 7x7 stem (Cin = 3).  The stride-2 layers' backward runs on the split main loop (round 4: input gradient by
+whole network.  The 7x7 stem (Cin = 3) has its own kernels (csrc/conv_stem.hip, `stem_conv_bn_act`).  The stride-2 layers' backward runs on the split main loop (round 4: input gradient by
 parity class, scp_conv_nhwc_dgrad_stride2; weight gradient of the 3x3 and of the 1x1 projections by the halo-block kernel with a
 strided block); with SCP_CONV_GEMM=fp32 / SCP_CONV_WGRAD=fp32 those directions fall back to `aten.convolution_backward` / one
 gather + library GEMM.  The 1x1 projections' input gradient is an own 1x1 product scattered to the even pixels.  CPU tensors, eval-mode BatchNorm, SyncBatchNorm and non-fp32 activations (configs[4] bf16
@@ -288,6 +288,77 @@ class _ConvBNAct(Function):
             dskip = dy
         dx, dw = _conv_backward(x, weight, dconv, stride, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.planes)
         return dx, dw, (dskip if has_skip else None), dgamma, dbeta, None, None, None, None
+
+
+class _StemConvBNAct(Function):
+    """relu(bn(conv7x7s2(x))) of the ResNet stem (image_encoder.py:122-124) on csrc/conv_stem.hip: the convolution leaves the batch
+    statistics (one launch), one apply pass; backward = the BatchNorm(+ReLU) backward and the stem's weight gradient.  The image
+    carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, bn, relu):
+        L = capi.lib()
+        x = x.contiguous()                                  # NCHW: the kernel reads image rows
+        n, _, h, w = x.shape
+        cout = weight.shape[0]
+        conv = torch.empty((n, cout, h // 2, w // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        rows = n * (h // 2) * (w // 2)
+        stats = torch.empty(4, cout, dtype=torch.float32, device=x.device)
+        ws = torch.empty(2 * L.scp_stem_conv_tiles(n, h, w) * cout, dtype=torch.float32, device=x.device)
+        momentum = 0.1 if bn.momentum is None else bn.momentum
+        wd = weight.detach()
+        capi.check(L.scp_stem_conv_forward_bn(
+            _ptr(x), _ptr(wd), wd.stride(0), wd.stride(1), wd.stride(2), wd.stride(3), _ptr(conv), n, h, w, _ptr(gamma), _ptr(beta),
+            _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(bn.num_batches_tracked if bn.track_running_stats else None),
+            float(momentum), float(bn.eps), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(ws), ws.numel() * 4,
+            capi.ticket(x.device), capi.current_stream()), "stem_conv_forward_bn")
+        y = torch.empty_like(conv)
+        capi.check(L.scp_batchnorm_apply(_ptr(conv), _ptr(None), _ptr(stats[2]), _ptr(stats[3]), rows, cout, int(relu), _ptr(y),
+                                         capi.current_stream()), "batchnorm_apply")
+        ctx.save_for_backward(x, weight, conv, stats)
+        ctx.cfg = (rows, cout, bool(relu), gamma is not None, beta is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = capi.lib()
+        x, weight, conv, stats = ctx.saved_tensors
+        rows, c, relu, has_w, has_b = ctx.cfg
+        dy = _nhwc(dy)
+        dconv = torch.empty_like(conv)
+        want_g = has_w and ctx.needs_input_grad[2]
+        want_b = has_b and ctx.needs_input_grad[3]
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device) if want_g else None
+        dbeta = torch.empty(c, dtype=torch.float32, device=x.device) if want_b else None
+        ws_bytes = L.scp_batchnorm_workspace(rows, c)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+        capi.check(L.scp_batchnorm_act_backward(
+            _ptr(dy), _ptr(conv), _ptr(None), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), rows, c, int(relu),
+            0, 1, _ptr(dconv), _ptr(None), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws_bytes, capi.ticket(x.device),
+            capi.current_stream()), "batchnorm_act_backward")
+        dw = None
+        if ctx.needs_input_grad[1]:
+            n, _, h, w = x.shape
+            dw = torch.empty_like(weight)
+            wg_bytes = L.scp_stem_conv_weight_grad_workspace(n, h, w)
+            wg = torch.empty(wg_bytes // 4, dtype=torch.float32, device=x.device)
+            capi.check(L.scp_stem_conv_weight_grad(_ptr(x), _ptr(dconv), _ptr(dw), dw.stride(0), dw.stride(1), dw.stride(2), dw.stride(3),
+                                                   _ptr(wg), wg_bytes, n, h, w, capi.current_stream()), "stem_conv_weight_grad")
+        return None, dw, dgamma, dbeta, None, None
+
+
+def stem_conv_bn_act(x, conv, bn, relu=True):
+    """relu(bn(conv(x))) for the 7x7 / stride-2 / pad-3 stem of the ResNet trunk; anything else (CPU, eval-mode BatchNorm, autocast,
+    an image that needs a gradient, odd sizes) takes the stock composition"""
+    from .fused_bn import bn_act
+    w = conv.weight
+    if (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 4 and tuple(w.shape) == (64, 3, 7, 7)
+            and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+            and x.shape[1] == 3 and x.shape[2] % 2 == 0 and x.shape[3] % 4 == 0 and x.shape[2] >= 8 and x.shape[3] >= 8
+            and not x.requires_grad and type(bn) is nn.BatchNorm2d and (bn.training or bn.running_mean is None)
+            and not torch.is_autocast_enabled() and os.environ.get("SCP_STEM", "own") == "own"):
+        return _StemConvBNAct.apply(x, w, bn.weight, bn.bias, bn, relu)
+    return bn_act(conv(x), bn, relu=relu)
 
 
 class _ConvBiasLeaky(Function):

@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .fused_bn import bn_act, maxpool3x3s2
-from .fused_conv import conv_bias_leaky, conv_bn_act
+from .fused_conv import conv_bias_leaky, conv_bn_act, stem_conv_bn_act
 
 
 # ------------------------------------------------------------------------------------------------
@@ -99,7 +99,7 @@ class ResNet_Encoder(nn.Module):
 
     def forward(self, x):
         r = self.resnet
-        x = maxpool3x3s2(bn_act(r.conv1(x), r.bn1, relu=True), r.maxpool)
+        x = maxpool3x3s2(stem_conv_bn_act(x, r.conv1, r.bn1, relu=True), r.maxpool)
         c2 = r.layer1(x)
         c3 = r.layer2(c2)
         c4 = r.layer3(c3)

@@ -116,7 +116,15 @@ def test_convolution_launch_plans_host_side():
     # the weight-gradient workspace: ~256 workgroups' partial [Cout, 9, Cin] blocks
     ws = L.scp_conv_nhwc_weight_grad_workspace(32, 64, 64, 64, 64, 3, 1)
     assert ws > 0 and ws % (64 * 9 * 64 * 4) == 0 and 200 <= ws // (64 * 9 * 64 * 4) <= 256
-    assert L.scp_conv_nhwc_weight_grad_workspace(32, 64, 64, 64, 64, 3, 2) == 0          # stride 2: not covered
+    # stride 2 (split core): 3x3 and 1x1 on even maps with a power-of-two output map; 16 x 16 output here
+    ws2 = L.scp_conv_nhwc_weight_grad_workspace(32, 32, 32, 128, 256, 3, 2)
+    assert ws2 > 0 and ws2 % (256 * 9 * 128 * 4) == 0
+    ws1 = L.scp_conv_nhwc_weight_grad_workspace(32, 32, 32, 128, 256, 1, 2)
+    assert ws1 > 0 and ws1 * 9 == ws2
+    assert L.scp_conv_nhwc_weight_grad_workspace(32, 30, 30, 128, 256, 3, 2) == 0           # 15 x 15 output: not a power of two
+    assert L.scp_conv_nhwc_weight_grad_workspace(32, 32, 32, 128, 256, 1, 1) == 0           # 1x1 stride 1: a plain GEMM, not here
+    assert L.scp_stem_conv_tiles(32, 256, 256) == 32 * 128 and L.scp_stem_conv_tiles(2, 512, 512) == 2 * 256 * 2
+    assert L.scp_stem_conv_weight_grad_workspace(32, 256, 256) == 512 * 64 * 160 * 4
     # the attention's operand planes + tail-query records
     n_pad = 1056
     assert L.scp_vit_attention_split_workspace(32, 1025, 6) == 9 * 32 * 6 * n_pad * 64 * 2 + 32 * 6 * 8 * 8 * 66 * 4

@@ -86,6 +86,51 @@ def test_conv_bn_act_vs_float64(n, cin, cout, h, k, stride, skip, relu):
     assert int(bn.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("n,h,w,channels_last", [(2, 32, 32, False), (3, 64, 48, True), (2, 256, 256, False), (32, 256, 256, False),
+                                                (1, 512, 512, False), (2, 40, 264, False)])
+def test_stem_conv_bn_act_vs_float64(n, h, w, channels_last):
+    """the 7x7 / stride-2 stem + BatchNorm + ReLU on csrc/conv_stem.hip: output, running statistics, weight / gamma / beta gradients"""
+    from scp_amd import fused_conv
+    g = torch.Generator().manual_seed(n + h + w)
+    conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False).cuda()
+    if channels_last:
+        conv = conv.to(memory_format=torch.channels_last)
+    bn = nn.BatchNorm2d(64).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * torch.randn(64, generator=g))
+        bn.bias.copy_(0.3 * torch.randn(64, generator=g))
+    x = torch.rand(n, 3, h, w, generator=g).cuda()          # an image: all positive
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(n, 64, h // 2, w // 2, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    conv64, bn64 = nn.Conv2d(3, 64, 7, 2, 3, bias=False).cuda().double(), nn.BatchNorm2d(64).cuda().double()
+    conv64.weight.data.copy_(conv.weight.double())
+    bn64.weight.data.copy_(bn.weight.double()); bn64.bias.data.copy_(bn.bias.double())
+    y = fused_conv.stem_conv_bn_act(x, conv, bn, relu=True)
+    assert y.grad_fn is not None and "StemConvBNAct" in type(y.grad_fn).__name__, "the fused op must be the one that runs"
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(dy)
+    r = bn64(conv64(x.double()))
+    _close(y, F.relu(r), 2e-5, "output")
+    r = r * (y.detach() > 0).double()
+    r.backward(dy.double())
+    _close_grad(conv.weight.grad, conv64.weight.grad, 5e-5, "dw")
+    _close_grad(bn.weight.grad, bn64.weight.grad, 5e-5, "dgamma")
+    _close_grad(bn.bias.grad, bn64.bias.grad, 5e-5, "dbeta")
+    _close(bn.running_mean, bn64.running_mean, 1e-5, "running_mean")
+    _close(bn.running_var, bn64.running_var, 1e-5, "running_var")
+    assert int(bn.num_batches_tracked) == 1
+    # deterministic: a second run reproduces the first bit for bit
+    conv.weight.grad = None
+    y2 = fused_conv.stem_conv_bn_act(x, conv, bn, relu=True)
+    y2.backward(dy)
+    assert torch.equal(y2, y)
+    g1 = conv.weight.grad.clone()
+    conv.weight.grad = None
+    fused_conv.stem_conv_bn_act(x, conv, bn, relu=True).backward(dy)
+    assert torch.equal(conv.weight.grad, g1)
+
+
 @pytest.mark.parametrize("n,cin,cout,h,stride", [(2, 128, 64, 16, 1), (2, 512, 256, 8, 1), (2, 128, 64, 16, 2), (32, 128, 64, 64, 1)])
 def test_conv_bias_leaky_vs_float64(n, cin, cout, h, stride):
     from scp_amd import fused_conv

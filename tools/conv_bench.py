@@ -44,7 +44,10 @@ def t(fn, n=20):
 
 tot = {k: 0.0 for k in ("mf", "md", "mw", "of", "od", "ow")}
 print("%-20s %3s %7s | MIOpen us fwd dgrad wgrad | own us fwd dgrad wgrad | own TFLOP/s fwd dgrad wgrad | MIOpen TFLOP/s" % ("layer", "cnt", "GFLOP"))
+ONLY = os.environ.get("SCP_BENCH_ONLY")          # substring filter on the layer name (sweeps)
 for name, cin, cout, k, s, h, cnt in LAYERS:
+    if ONLY and ONLY not in name:
+        continue
     x = torch.randn(B, cin, h, h, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
     w = (torch.randn(cout, cin, k, k, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     y = F.conv2d(x, w, None, s, k // 2)
@@ -57,6 +60,24 @@ for name, cin, cout, k, s, h, cnt in LAYERS:
     of = od = ow = float("nan")
     xn, wn, gn = x.detach().permute(0, 2, 3, 1), w.detach().permute(0, 2, 3, 1), g.permute(0, 2, 3, 1)      # NHWC views of the same storage
     assert xn.is_contiguous() and wn.is_contiguous() and gn.is_contiguous()
+    if k == 7:
+        # the stem: csrc/conv_stem.hip on the NCHW image (convolution + BatchNorm statistics in the forward launch)
+        xs, wd = x.detach().contiguous(), w.detach()
+        yo = torch.empty(B, ho, ho, cout, device="cuda")
+        st = torch.empty(4, cout, device="cuda")
+        rm, rv = torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda")
+        wsb = torch.empty(2 * L.scp_stem_conv_tiles(B, h, h) * cout, device="cuda")
+        of = t(lambda: capi.check(L.scp_stem_conv_forward_bn(P(xs), P(wd), wd.stride(0), wd.stride(1), wd.stride(2), wd.stride(3), P(yo), B, h, h,
+                                                             P(None), P(None), P(rm), P(rv), P(None), 0.1, 1e-5, P(st[0]), P(st[1]), P(st[2]), P(st[3]),
+                                                             P(wsb), wsb.numel() * 4, capi.ticket(xs.device), capi.current_stream()), "stem fwd"))
+        assert os.environ.get("SCP_BENCH_NOCHECK") or (yo - y.detach().permute(0, 2, 3, 1)).abs().max() <= 2e-4 * y.abs().max()
+        wgb = L.scp_stem_conv_weight_grad_workspace(B, h, h)
+        wg = torch.empty(wgb // 4, device="cuda")
+        dw = torch.empty_like(wd)
+        ow = t(lambda: capi.check(L.scp_stem_conv_weight_grad(P(xs), P(gn), P(dw), dw.stride(0), dw.stride(1), dw.stride(2), dw.stride(3), P(wg), wgb,
+                                                              B, h, h, capi.current_stream()), "stem wgrad"))
+        (dw_ref,) = torch.autograd.grad(y, w, g, retain_graph=True)
+        assert os.environ.get("SCP_BENCH_NOCHECK") or (dw - dw_ref).abs().max() <= 2e-4 * dw_ref.abs().max()
     if k in (1, 3) and cin >= 32:
         wn3 = fused_conv.split_planes_tiled(wn) if SPLIT else None
         skf, skf_b = fused_conv._splitk(B, h, h, cin, cout, k, s, SPLIT, "cuda")
