@@ -410,9 +410,11 @@ Plan make_plan(int N, int H, int W, int Cin, int Cout) {
 }  // namespace
 
 namespace {
-// which (ksize, stride) the kernels take: 3x3 stride 1 (both cores); 3x3 stride 2 and 1x1 stride 2 (split core; H, W even)
+// which (ksize, stride) the kernels take: 3x3 stride 1 (both cores); on the split core also 3x3 stride 2 and 1x1 stride 2 (H, W even)
+// and 1x1 stride 1
 bool shape_ok(int H, int W, int ksize, int stride, int split) {
     if (ksize == 3 && stride == 1) return true;
+    if (split && ksize == 1 && stride == 1) return true;
     return split && stride == 2 && (ksize == 3 || ksize == 1) && H % 2 == 0 && W % 2 == 0;
 }
 }  // namespace
@@ -429,7 +431,7 @@ extern "C" int scp_conv_nhwc_weight_grad(const float* x, const float* dy, float*
                                          int split, void* stream) {
     if (!x || !dy || !dw || !workspace) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: null argument");
     if (!shape_ok(H, W, ksize, stride, split))
-        return scp::fail(hipErrorInvalidValue, "conv_weight_grad: 3x3 / stride 1, or (split core) 3x3 and 1x1 / stride 2 on even maps");
+        return scp::fail(hipErrorInvalidValue, "conv_weight_grad: 3x3 / stride 1, or (split core) 1x1 / stride 1 and 3x3, 1x1 / stride 2 on even maps");
     if (dbias) return scp::fail(hipErrorInvalidValue, "conv_weight_grad: the bias gradient comes from scp_bias_leaky_relu_backward");
     const int Ho = H / stride, Wo = W / stride, nt = ksize * ksize;
     const Plan p = make_plan(N, Ho, Wo, Cin, Cout);
@@ -453,6 +455,9 @@ extern "C" int scp_conv_nhwc_weight_grad(const float* x, const float* dy, float*
     } else if (stride == 2) {
         if (wide) hipLaunchKernelGGL((conv_wgrad_kernel<16, true, 2, 1>), grid, dim3(THREADS), 0, st, g);
         else hipLaunchKernelGGL((conv_wgrad_kernel<8, true, 2, 1>), grid, dim3(THREADS), 0, st, g);
+    } else if (ksize == 1) {
+        if (wide) hipLaunchKernelGGL((conv_wgrad_kernel<16, true, 1, 1>), grid, dim3(THREADS), 0, st, g);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<8, true, 1, 1>), grid, dim3(THREADS), 0, st, g);
     } else if (split) {
         if (wide) hipLaunchKernelGGL((conv_wgrad_kernel<16, true>), grid, dim3(THREADS), 0, st, g);
         else hipLaunchKernelGGL((conv_wgrad_kernel<8, true>), grid, dim3(THREADS), 0, st, g);

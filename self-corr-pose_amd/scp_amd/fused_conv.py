@@ -52,10 +52,12 @@ def _own_dgrad_ok(weight, stride):
 
 
 def _own_wgrad_ok(x_shape, weight, stride):
-    """3x3 stride 1; on the split core also the stride-2 layers of the trunk (3x3 conv1 and the 1x1 projection of layer2..4)"""
+    """3x3 stride 1; on the split core also the stride-2 layers of the trunk (3x3 conv1 and the 1x1 projection of layer2..4) and 1x1
+    stride 1 (the decoder's feature projection)"""
     n, cin, h, w = x_shape
     k = weight.shape[2]
-    if not ((stride == 1 and k == 3) or (stride == 2 and k in (1, 3) and WGRAD_MODE == "split" and h % 2 == 0 and w % 2 == 0)):
+    if not ((stride == 1 and k == 3) or (WGRAD_MODE == "split" and k == 1 and stride == 1)
+            or (stride == 2 and k in (1, 3) and WGRAD_MODE == "split" and h % 2 == 0 and w % 2 == 0)):
         return False
     ho, wo = h // stride, w // stride
     return (ho >= 8 and wo >= 8 and _pow2(ho) and _pow2(wo) and cin % 64 == 0 and weight.shape[0] % 64 == 0

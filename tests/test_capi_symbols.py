@@ -122,7 +122,7 @@ def test_convolution_launch_plans_host_side():
     ws1 = L.scp_conv_nhwc_weight_grad_workspace(32, 32, 32, 128, 256, 1, 2)
     assert ws1 > 0 and ws1 * 9 == ws2
     assert L.scp_conv_nhwc_weight_grad_workspace(32, 30, 30, 128, 256, 3, 2) == 0           # 15 x 15 output: not a power of two
-    assert L.scp_conv_nhwc_weight_grad_workspace(32, 32, 32, 128, 256, 1, 1) == 0           # 1x1 stride 1: a plain GEMM, not here
+    assert L.scp_conv_nhwc_weight_grad_workspace(32, 32, 32, 128, 256, 1, 1) * 9 == L.scp_conv_nhwc_weight_grad_workspace(32, 32, 32, 128, 256, 3, 1)
     assert L.scp_stem_conv_tiles(32, 256, 256) == 32 * 128 and L.scp_stem_conv_tiles(2, 512, 512) == 2 * 256 * 2
     assert L.scp_stem_conv_weight_grad_workspace(32, 256, 256) == 512 * 64 * 160 * 4
     # the attention's operand planes + tail-query records

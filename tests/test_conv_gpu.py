@@ -145,6 +145,26 @@ def test_conv_weight_gradient_vs_float64(n, cin, cout, h, w):
     assert err <= 2e-5 * dw_ref.abs().max().item(), (err, dw_ref.abs().max().item())
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 16, 16), (32, 64, 64, 64, 64), (3, 128, 64, 8, 32)])
+def test_1x1_weight_gradient_vs_float64(n, cin, cout, h, w, conv_core):
+    """1x1 / stride 1 (the decoder's feature projection) on the halo-block kernel with a one-pixel block (split core)"""
+    if conv_core != "split":
+        pytest.skip("split core only")
+    from scp_amd import capi
+    L = capi.lib()
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    dy = torch.randn(n, h, w, cout, generator=g).cuda()
+    dw_ref = torch.einsum("nhwo,nhwi->oi", dy.double(), x.double())
+    ws_bytes = L.scp_conv_nhwc_weight_grad_workspace(n, h, w, cin, cout, 1, 1)
+    assert ws_bytes > 0
+    ws = torch.empty(ws_bytes // 4, device="cuda")
+    dw = torch.full((cout, 1, 1, cin), float("nan"), device="cuda")
+    capi.check(L.scp_conv_nhwc_weight_grad(P(x), P(dy), P(dw), P(None), P(ws), ws_bytes, n, h, w, cin, cout, 1, 1, 1, capi.current_stream()), "wgrad 1x1")
+    err = (dw.reshape(cout, cin).double() - dw_ref).abs().max().item()
+    assert err <= 2e-5 * dw_ref.abs().max().item(), (err, dw_ref.abs().max().item())
+
+
 @pytest.mark.parametrize("n,cin,cout,h,w,k", [(2, 64, 128, 32, 32, 3), (2, 64, 64, 16, 32, 3), (32, 64, 128, 64, 64, 3), (32, 128, 256, 32, 32, 3),
                                              (32, 256, 512, 16, 16, 3), (4, 64, 128, 16, 16, 1), (32, 64, 128, 64, 64, 1), (32, 256, 512, 16, 16, 1),
                                              (2, 128, 64, 32, 64, 1)])

@@ -103,7 +103,7 @@ for name, cin, cout, k, s, h, cnt in LAYERS:
             od = t(lambda: capi.check(L.scp_conv_nhwc_dgrad_stride2(P(gn), P(pd), P(dxo), B, ho, ho, cout, cin, capi.current_stream()), "dgrad s2"))
             (dx_ref,) = torch.autograd.grad(y, x, g, retain_graph=True)
             assert os.environ.get("SCP_BENCH_NOCHECK") or (dxo - dx_ref.permute(0, 2, 3, 1)).abs().max() <= 2e-4 * dx_ref.abs().max()
-        if (k == 3 and s == 1) or (s == 2 and WSPLIT):
+        if (k == 3 and s == 1) or ((s == 2 or k == 1) and WSPLIT):
             ws_bytes = L.scp_conv_nhwc_weight_grad_workspace(B, h, h, cin, cout, k, s)
             if ws_bytes:
                 ws = torch.empty(ws_bytes // 4, device="cuda")
