@@ -179,9 +179,17 @@ class ResNet_Decoder(nn.Module):
         c3 = self.iconv3(torch.cat((c3, self.upconv4(self._up(c4, c3))), 1))
         if self.downsample != 4:
             feat = c3[:, :, ::2, ::2] if half_res else c3
-            return self.proj(feat) if self.is_proj else feat
+            return self._project(feat) if self.is_proj else feat
         c2 = self.iconv2(torch.cat((c2, self.upconv3(self._up(c3, c2))), 1), stride=2 if half_res else 1)
-        return self.proj(c2) if self.is_proj else c2
+        return self._project(c2) if self.is_proj else c2
+
+    def _project(self, feat):
+        """the 1x1 feature projection (a convolution with bias, no activation): on the GPU the own 1x1 kernel with the bias in its
+        epilogue -- LeakyReLU with slope 1 is the identity, exactly -- instead of a library GEMM + bias pass (forward and both
+        gradients)"""
+        if feat.is_cuda:
+            return conv_bias_leaky(feat, self.proj, 1.0)
+        return self.proj(feat)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -152,6 +152,28 @@ def test_conv_bias_leaky_vs_float64(n, cin, cout, h, stride):
     _close_grad(conv.bias.grad, b64.grad, 5e-5, "dbias")
 
 
+@pytest.mark.parametrize("n,cin,cout,h", [(2, 64, 64, 16), (32, 64, 64, 64), (3, 128, 16, 32)])
+def test_projection_1x1_with_bias_vs_float64(n, cin, cout, h):
+    """the decoder's 1x1 feature projection (ResNet_Decoder._project): conv + bias through the LeakyReLU epilogue with slope 1 --
+    the identity -- forward and all three gradients"""
+    from scp_amd import fused_conv
+    g = torch.Generator().manual_seed(n + cin + cout)
+    conv = nn.Conv2d(cin, cout, 1, bias=True).cuda().to(memory_format=torch.channels_last)
+    x = torch.randn(n, cin, h, h, generator=g).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x64 = x.detach().double().requires_grad_(True)
+    w64, b64 = conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+    y = fused_conv.conv_bias_leaky(x, conv, 1.0)
+    assert "ConvBiasLeaky" in type(y.grad_fn).__name__
+    r = F.conv2d(x64, w64, b64)
+    _close(y, r, 2e-5, "output")
+    dy = torch.randn(r.shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    r.backward(dy.double())
+    y.backward(dy)
+    _close(x.grad, x64.grad, 2e-5, "dx")
+    _close(conv.weight.grad, w64.grad, 5e-5, "dw")
+    _close(conv.bias.grad, b64.grad, 5e-5, "dbias")
+
+
 def test_encoder_with_own_convolutions_is_as_accurate_as_the_stock_path(monkeypatch):
     """the whole image encoder (ResNet18 trunk + U-decoder, B = 4, 256 x 256), forward features and the gradient of every
     parameter, three ways on the same weights: (a) own convolutions with fused BatchNorm statistics, (b) the MIOpen +
