@@ -349,6 +349,11 @@ int scp_stem_conv_weight_grad(const float* x, const float* dy, float* dw, long l
  * element is written exactly once.  Cout a power of two >= 32. */
 int scp_conv_nhwc_dgrad_stride2(const float* dy, const void* w_dgrad_planes, float* dx, int N, int Ho, int Wo, int Cout, int Cin,
                                 void* stream);
+/* input gradient of a 1x1 / stride-2 convolution (the downsample projections of layer2..4, image_encoder.py:128-134):
+ * dy [N,Ho,Wo,Cout], w_t [Cin][Cout] fp32 or w_t_split its tiled planes (planes_dgrad of scp_conv_weight_planes) ->
+ * dx [N,2 Ho,2 Wo,Cin]: the 1x1 product on the even pixels, zeros elsewhere, every element written once by the epilogue. */
+int scp_conv1x1_nhwc_dgrad_stride2(const float* dy, const float* w_t, const void* w_t_split, float* dx, int N, int Ho, int Wo, int Cout,
+                                   int Cin, void* stream);
 int scp_conv_nhwc_partial_rows(int N, int H, int W, int Cin, int Cout, int ksize, int stride, int split, int* tiles_m,
                                int* rows_per_tile);
 /* convolution (no bias) + the batch statistics of the nn.BatchNorm2d that follows it (training mode), one launch: the per-tile

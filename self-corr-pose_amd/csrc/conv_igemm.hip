@@ -53,6 +53,7 @@ struct ConvArgs {
     int tiles_m_kernel;    // row tiles of the convolution kernel's grid
     unsigned x_bytes;
     float slope;
+    int scatter2;          // 1x1 input gradient of a stride-2 projection: row m = dy pixel (a, b) -> dx pixel (2a, 2b), its three neighbours zeros
 };
 
 // one LDS-DMA piece through a buffer descriptor: lanes whose offset is beyond the descriptor read zeros
@@ -229,7 +230,20 @@ __global__ __launch_bounds__(FCFG::THREADS, 2) void conv_igemm_kernel(const Conv
                     v += b;
                     v = v > 0.f ? v : v * g.slope;
                 }
-                if (live) yout[(size_t)m * g.Cout + n] = v;
+                if (EPI == EPI_RAW && !STATS && TAPS == 1 && g.scatter2) {
+                    // dx of a 1x1 / stride-2 convolution: the product lands on the even pixel, the other three of its 2 x 2 cell
+                    // get no contribution -- written here as zeros (no memset of dx, no strided copy)
+                    if (live) {
+                        const int hw = g.Ho * g.Wo, img = m / hw, rem = m - img * hw, a = rem / g.Wo, b = rem - a * g.Wo;
+                        float* o = yout + (((size_t)img * 2 * g.Ho + 2 * a) * (2 * g.Wo) + 2 * b) * g.Cout + n;
+                        o[0] = v;
+                        o[g.Cout] = 0.f;
+                        o[(size_t)2 * g.Wo * g.Cout] = 0.f;
+                        o[(size_t)(2 * g.Wo + 1) * g.Cout] = 0.f;
+                    }
+                } else if (live) {
+                    yout[(size_t)m * g.Cout + n] = v;
+                }
             }
         }
     }
@@ -558,7 +572,7 @@ extern "C" size_t scp_conv_nhwc_splitk_workspace(int N, int H, int W, int Cin, i
 namespace {
 int conv_forward_impl(const float* x, const float* w, const void* w_split, const float* bias, float* y, float* partials, unsigned* ticket,
                       const scp_bn::FwdFinalize* fin, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int leaky,
-                      float slope, void* splitk_ws, size_t splitk_bytes, void* stream) {
+                      float slope, void* splitk_ws, size_t splitk_bytes, void* stream, int scatter2 = 0) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return scp::fail(hipErrorInvalidValue, "conv_nhwc: empty problem");
     if (!x || (!w && !w_split) || !y || (leaky && !bias)) return scp::fail(hipErrorInvalidValue, "conv_nhwc: null argument");
     if (ksize != 1 && ksize != 3) return scp::fail(hipErrorInvalidValue, "conv_nhwc: kernel size must be 1 or 3");
@@ -569,7 +583,7 @@ int conv_forward_impl(const float* x, const float* w, const void* w_split, const
     const int pad = ksize / 2;
     ConvArgs g{};
     g.x = x; g.w = w; g.w_split = w_split; g.bias = bias; g.y = y; g.partials = partials; g.ticket = ticket;
-    g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.stride = stride; g.slope = slope;
+    g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.stride = stride; g.slope = slope; g.scatter2 = scatter2;
     g.Ho = (H + 2 * pad - ksize) / stride + 1;
     g.Wo = (W + 2 * pad - ksize) / stride + 1;
     const long M = (long)N * g.Ho * g.Wo, in_bytes = (long)N * H * W * Cin * 4;
@@ -644,6 +658,14 @@ extern "C" int scp_conv_nhwc_forward_bn(const float* x, const float* w, const vo
                                   save_scale, save_shift};
     return conv_forward_impl(x, w, w_split, nullptr, y, static_cast<float*>(workspace), ticket, &fin, N, H, W, Cin, Cout, ksize, stride, 0, 0.f,
                              splitk_ws, splitk_bytes, stream);
+}
+
+extern "C" int scp_conv1x1_nhwc_dgrad_stride2(const float* dy, const float* w_t, const void* w_t_split, float* dx, int N, int Ho, int Wo, int Cout,
+                                              int Cin, void* stream) {
+    if (!dy || (!w_t && !w_t_split) || !dx) return scp::fail(hipErrorInvalidValue, "conv1x1_nhwc_dgrad_stride2: null argument");
+    if ((long)N * 4 * Ho * Wo * Cin >= (1l << 31)) return scp::fail(hipErrorInvalidValue, "conv1x1_nhwc_dgrad_stride2: tensor larger than 2^31 elements");
+    // the 1x1 product at the dy resolution (dy as input, w_t = [Cin][Cout]), scattered by the epilogue
+    return conv_forward_impl(dy, w_t, w_t_split, nullptr, dx, nullptr, nullptr, nullptr, N, Ho, Wo, Cout, Cin, 1, 1, 0, 0.f, nullptr, 0, stream, 1);
 }
 
 extern "C" int scp_conv_nhwc_dgrad_stride2(const float* dy, const void* w_dgrad_planes, float* dx, int N, int Ho, int Wo, int Cout, int Cin,

@@ -93,17 +93,25 @@ __global__ __launch_bounds__(THREADS, 2) void stem_forward_kernel(const StemArgs
     __shared__ float wl[2 * NSTEP * WL_STRIDE];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    // weights, in step order: wl[2 s + h][co] = w[co][k(s, h)]
-    for (int idx = threadIdx.x; idx < 2 * NSTEP * CO; idx += THREADS) {
-        const int s2 = idx % (2 * NSTEP), co = idx / (2 * NSTEP);
-        const int s = s2 >> 1, h = s2 & 1;
-        const int row = step_row(s, h), kx = step_kx(s, h);
-        float v = 0.f;
-        if (row < KROWS) {
-            const int ci = row / 7, ky = row - ci * 7;
-            v = g.w[co * g.ws_co + ci * g.ws_ci + ky * g.ws_ky + kx * g.ws_kx];
+    // weights, in step order: wl[2 s + h][co] = w[co][k(s, h)]; 37 elements per thread, their loads issued together
+    {
+        constexpr int PER = (2 * NSTEP * CO + THREADS - 1) / THREADS;
+        float v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int idx = threadIdx.x + THREADS * i;
+            const int s2 = idx % (2 * NSTEP), co = min(idx / (2 * NSTEP), CO - 1);
+            const int s = s2 >> 1, h = s2 & 1;
+            const int row = step_row(s, h), kx = step_kx(s, h);
+            const int rowc = min(row, KROWS - 1), ci = rowc / 7, ky = rowc - ci * 7;
+            const float t = g.w[co * g.ws_co + ci * g.ws_ci + ky * g.ws_ky + kx * g.ws_kx];
+            v[i] = row < KROWS ? t : 0.f;
         }
-        wl[s2 * WL_STRIDE + co] = v;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int idx = threadIdx.x + THREADS * i;
+            if (idx < 2 * NSTEP * CO) wl[(idx % (2 * NSTEP)) * WL_STRIDE + idx / (2 * NSTEP)] = v[i];
+        }
     }
     for (int idx = KROWS * HW + threadIdx.x; idx < HALO_FLOATS; idx += THREADS) halo[idx] = 0.f;
     // halo column of (pixel p, tap kx) = 2 p + kx + 1 (the block starts one column left of the first tap: float4 alignment)
@@ -339,7 +347,7 @@ extern "C" int scp_stem_conv_forward_bn(const float* x, const float* w, long lon
         g.fin = scp_bn::FwdFinalize{(long)N * g.Ho * g.Wo, gamma, beta, running_mean, running_var, batches_tracked, momentum, eps,
                                     save_mean, save_invstd, save_scale, save_shift};
     }
-    const int grid = g.tiles < 1024 ? g.tiles : 1024;
+    const int grid = g.tiles < 512 ? g.tiles : 512;          // two resident workgroups per CU, each fills its weight block once
     hipLaunchKernelGGL(stem_forward_kernel, dim3(grid), dim3(THREADS), 0, static_cast<hipStream_t>(stream), g);
     return scp::check_launch("stem_conv_forward");
 }

@@ -99,6 +99,7 @@ SYMBOLS = {
                                                 ctypes.c_float, _P, _P, _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "scp_stem_conv_weight_grad_workspace": (ctypes.c_size_t, [_I, _I, _I]),
     "scp_stem_conv_weight_grad": (ctypes.c_int, [_P, _P, _P, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, ctypes.c_size_t, _I, _I, _I, _P]),
+    "scp_conv1x1_nhwc_dgrad_stride2": (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "scp_conv_nhwc_partial_rows": (ctypes.c_int, [_I, _I, _I, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "scp_conv_nhwc_weight_grad_workspace": (ctypes.c_size_t, [_I, _I, _I, _I, _I, _I, _I]),
     "scp_conv_nhwc_weight_grad": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -200,15 +200,20 @@ def _conv_backward(x, weight, g, stride, need_dx, need_dw, planes=None):
         wt3 = planes.get("dgrad") if planes else None
         wt = None if wt3 is not None else weight.flip(2, 3).permute(1, 2, 3, 0).contiguous()
         ho, wo = g.shape[2], g.shape[3]
-        # stride 2 (1x1 only): the same product at the output resolution, then scattered to the even pixels of a zero gradient
-        dense = torch.empty((n, cin, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-        sk, sk_bytes = _splitk(n, ho, wo, cout, cin, k, 1, wt3 is not None, x.device)
-        capi.check(L.scp_conv_nhwc_forward(_ptr(g), _ptr(wt), _ptr(wt3), _ptr(None), _ptr(dense), _ptr(None), n, ho, wo, cout, cin, k, 1,
-                                           0, 0.0, _ptr(sk), sk_bytes, capi.current_stream()), "conv_nhwc_forward (input gradient)")
+        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         if stride == 1:
-            dx = dense
-        else:
-            dx = torch.empty(x.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last).zero_()
+            sk, sk_bytes = _splitk(n, ho, wo, cout, cin, k, 1, wt3 is not None, x.device)
+            capi.check(L.scp_conv_nhwc_forward(_ptr(g), _ptr(wt), _ptr(wt3), _ptr(None), _ptr(dx), _ptr(None), n, ho, wo, cout, cin, k, 1,
+                                               0, 0.0, _ptr(sk), sk_bytes, capi.current_stream()), "conv_nhwc_forward (input gradient)")
+        elif h == 2 * ho and w == 2 * wo:
+            # stride 2 (1x1 only): the same product at the output resolution, written to the even pixels by the epilogue, zeros between
+            capi.check(L.scp_conv1x1_nhwc_dgrad_stride2(_ptr(g), _ptr(wt), _ptr(wt3), _ptr(dx), n, ho, wo, cout, cin, capi.current_stream()),
+                       "conv1x1_nhwc_dgrad_stride2")
+        else:                                            # odd maps: the product, then a strided copy into a zero gradient
+            dense = torch.empty((n, cin, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+            capi.check(L.scp_conv_nhwc_forward(_ptr(g), _ptr(wt), _ptr(wt3), _ptr(None), _ptr(dense), _ptr(None), n, ho, wo, cout, cin, k, 1,
+                                               0, 0.0, _ptr(None), 0, capi.current_stream()), "conv_nhwc_forward (input gradient)")
+            dx.zero_()
             dx[:, :, ::2, ::2] = dense
     if own_dw:
         ws_bytes = L.scp_conv_nhwc_weight_grad_workspace(n, h, w, cin, cout, k, stride)
