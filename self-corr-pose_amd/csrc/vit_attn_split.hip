@@ -75,7 +75,8 @@ __device__ __forceinline__ Pair3 split_pair(float x0, float x1) {
 // grid (Npad / 32, B H), 256 threads: thread = (token t = tid >> 3, 8 dims d0 = 8 (tid & 7)) for Q and K;
 // for V the 32 x 64 tile goes through LDS and thread = (d = tid >> 2, slot group g = tid & 3) writes 8 keys of one dimension.
 __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict__ qkv, __bf16* __restrict__ Qp, __bf16* __restrict__ Kp,
-                                                        __bf16* __restrict__ Vt, int N, int Npad, int H, float scale_log2e) {
+                                                        __bf16* __restrict__ Vt, int N, int Npad, int H, float scale_log2e, int v_only) {
+    // v_only: Q / K planes were written by the qkv projection's epilogue (csrc/vit_gemm.hip scp_vit_linear_qkv); only V^T is made here
     __shared__ float vt[KT][HD + 1];
     const int tile = blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int tid = threadIdx.x;
@@ -89,8 +90,11 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict_
             const float* src = qkv + ((size_t)b * N + tok) * row_stride + (size_t)h * HD + d0;
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                const float4 a = *reinterpret_cast<const float4*>(src + 4 * i);
-                const float4 c = *reinterpret_cast<const float4*>(src + (size_t)H * HD + 4 * i);
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+                if (!v_only) {
+                    a = *reinterpret_cast<const float4*>(src + 4 * i);
+                    c = *reinterpret_cast<const float4*>(src + (size_t)H * HD + 4 * i);
+                }
                 const float4 e = *reinterpret_cast<const float4*>(src + (size_t)2 * H * HD + 4 * i);
                 q[4 * i] = a.x * scale_log2e; q[4 * i + 1] = a.y * scale_log2e; q[4 * i + 2] = a.z * scale_log2e; q[4 * i + 3] = a.w * scale_log2e;
                 k[4 * i] = c.x; k[4 * i + 1] = c.y; k[4 * i + 2] = c.z; k[4 * i + 3] = c.w;
@@ -102,20 +106,22 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict_
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) vt[t][d0 + i] = v[i];
-        u32x4 qh, qm, ql, kh, km, kl;
+        if (!v_only) {
+            u32x4 qh, qm, ql, kh, km, kl;
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const Pair3 a = split_pair(q[2 * p], q[2 * p + 1]), c = split_pair(k[2 * p], k[2 * p + 1]);
-            qh[p] = a.h; qm[p] = a.m; ql[p] = a.l;
-            kh[p] = c.h; km[p] = c.m; kl[p] = c.l;
+            for (int p = 0; p < 4; p++) {
+                const Pair3 a = split_pair(q[2 * p], q[2 * p + 1]), c = split_pair(k[2 * p], k[2 * p + 1]);
+                qh[p] = a.h; qm[p] = a.m; ql[p] = a.l;
+                kh[p] = c.h; km[p] = c.m; kl[p] = c.l;
+            }
+            const size_t o = ((size_t)bh * Npad + tok) * HD + d0;
+            *reinterpret_cast<u32x4*>(Qp + o) = qh;
+            *reinterpret_cast<u32x4*>(Qp + plane_qk + o) = qm;
+            *reinterpret_cast<u32x4*>(Qp + 2 * plane_qk + o) = ql;
+            *reinterpret_cast<u32x4*>(Kp + o) = kh;
+            *reinterpret_cast<u32x4*>(Kp + plane_qk + o) = km;
+            *reinterpret_cast<u32x4*>(Kp + 2 * plane_qk + o) = kl;
         }
-        const size_t o = ((size_t)bh * Npad + tok) * HD + d0;
-        *reinterpret_cast<u32x4*>(Qp + o) = qh;
-        *reinterpret_cast<u32x4*>(Qp + plane_qk + o) = qm;
-        *reinterpret_cast<u32x4*>(Qp + 2 * plane_qk + o) = ql;
-        *reinterpret_cast<u32x4*>(Kp + o) = kh;
-        *reinterpret_cast<u32x4*>(Kp + plane_qk + o) = km;
-        *reinterpret_cast<u32x4*>(Kp + 2 * plane_qk + o) = kl;
     }
     __syncthreads();
     {
@@ -388,8 +394,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attention_split_kernel(cons
 // (max, sum, partial output[64]); a second tiny kernel merges the chunks.
 constexpr int TAIL_CHUNKS = 8, TAIL_REC = 2 + HD;
 
+// Qp != nullptr: Q (pre-scaled) and K come from the operand planes (x = h + m + l exactly: the sum reproduces the fp32 value the
+// qkv tensor would hold, so both sources give the same bits); V always from the qkv tensor
+__device__ __forceinline__ float4 planes4(const __bf16* p, size_t plane) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const bf16x4 h = *reinterpret_cast<const bf16x4*>(p), m = *reinterpret_cast<const bf16x4*>(p + plane),
+                 l = *reinterpret_cast<const bf16x4*>(p + 2 * plane);
+    return make_float4(((float)h[0] + (float)m[0]) + (float)l[0], ((float)h[1] + (float)m[1]) + (float)l[1],
+                       ((float)h[2] + (float)m[2]) + (float)l[2], ((float)h[3] + (float)m[3]) + (float)l[3]);
+}
+
 __global__ __launch_bounds__(256) void attention_tail_partial_kernel(const float* __restrict__ qkv, float* __restrict__ partial, int N, int H,
-                                                                     float scale_log2e, int first_query, int chunk_keys) {
+                                                                     float scale_log2e, int first_query, int chunk_keys,
+                                                                     const __bf16* __restrict__ Qp, const __bf16* __restrict__ Kp, size_t plane,
+                                                                     int Npad) {
     __shared__ __attribute__((aligned(16))) float p_lds[256];
     __shared__ __attribute__((aligned(16))) float o_lds[16 * HD];
     __shared__ float red[8];
@@ -401,14 +419,25 @@ __global__ __launch_bounds__(256) void attention_tail_partial_kernel(const float
     const int k0 = c * chunk_keys, nk = max(0, min(chunk_keys, N - k0));
     float s = -INFINITY;
     if (tid < nk) {
-        const float4* qp = reinterpret_cast<const float4*>(base + (size_t)q * row_stride);
-        const float4* kp = reinterpret_cast<const float4*>(base + (size_t)(k0 + tid) * row_stride + (size_t)H * HD);
         float a = 0.f;
+        if (Qp) {
+            const __bf16* qp = Qp + ((size_t)bh * Npad + q) * HD;
+            const __bf16* kp = Kp + ((size_t)bh * Npad + k0 + tid) * HD;
 #pragma unroll
-        for (int i = 0; i < HD / 4; i++) {
-            const float4 u = qp[i], t = kp[i];
-            a = fmaf(u.x * scale_log2e, t.x, a); a = fmaf(u.y * scale_log2e, t.y, a);
-            a = fmaf(u.z * scale_log2e, t.z, a); a = fmaf(u.w * scale_log2e, t.w, a);
+            for (int i = 0; i < HD / 4; i++) {
+                const float4 u = planes4(qp + 4 * i, plane), t = planes4(kp + 4 * i, plane);
+                a = fmaf(u.x, t.x, a); a = fmaf(u.y, t.y, a);
+                a = fmaf(u.z, t.z, a); a = fmaf(u.w, t.w, a);
+            }
+        } else {
+            const float4* qp = reinterpret_cast<const float4*>(base + (size_t)q * row_stride);
+            const float4* kp = reinterpret_cast<const float4*>(base + (size_t)(k0 + tid) * row_stride + (size_t)H * HD);
+#pragma unroll
+            for (int i = 0; i < HD / 4; i++) {
+                const float4 u = qp[i], t = kp[i];
+                a = fmaf(u.x * scale_log2e, t.x, a); a = fmaf(u.y * scale_log2e, t.y, a);
+                a = fmaf(u.z * scale_log2e, t.z, a); a = fmaf(u.w * scale_log2e, t.w, a);
+            }
         }
         s = a;
     }
@@ -474,9 +503,23 @@ extern "C" size_t scp_vit_attention_split_workspace(int B, int N, int H) {
     return (size_t)9 * B * H * npad * HD * sizeof(__bf16) + (size_t)B * H * 8 * TAIL_CHUNKS * TAIL_REC * sizeof(float);
 }
 
+namespace {
+int attention_split_impl(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale, const int* q_rows, const int* q_count,
+                         int exact, int presplit_qk, void* workspace, size_t workspace_bytes, void* stream);
+}
 extern "C" int scp_vit_attention_split_forward(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale,
                                                const int* q_rows, const int* q_count, int exact, void* workspace,
                                                size_t workspace_bytes, void* stream) {
+    return attention_split_impl(qkv, out, B, N, H, head_dim, scale, q_rows, q_count, exact, 0, workspace, workspace_bytes, stream);
+}
+extern "C" int scp_vit_attention_split_forward_presplit(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale,
+                                                        const int* q_rows, const int* q_count, void* workspace, size_t workspace_bytes,
+                                                        void* stream) {
+    return attention_split_impl(qkv, out, B, N, H, head_dim, scale, q_rows, q_count, 1, 1, workspace, workspace_bytes, stream);
+}
+namespace {
+int attention_split_impl(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale, const int* q_rows, const int* q_count,
+                         int exact, int presplit_qk, void* workspace, size_t workspace_bytes, void* stream) {
     if (B <= 0 || N <= 0 || H <= 0) return scp::fail(hipErrorInvalidValue, "vit_attention_split: empty problem");
     if (head_dim != HD) return scp::fail(hipErrorInvalidValue, "vit_attention_split: head_dim must be 64");
     if (!qkv || !out || !workspace || (q_rows == nullptr) != (q_count == nullptr))
@@ -491,7 +534,7 @@ extern "C" int scp_vit_attention_split_forward(const float* qkv, float* out, int
     __bf16* Vt = Kp + plane3;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float sl = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(qkv_split_kernel, dim3(npad / KT, B * H), dim3(256), 0, st, qkv, Qp, Kp, Vt, N, npad, H, sl);
+    hipLaunchKernelGGL(qkv_split_kernel, dim3(npad / KT, B * H), dim3(256), 0, st, qkv, Qp, Kp, Vt, N, npad, H, sl, presplit_qk);
     // four wavefronts per workgroup, two workgroups per CU = two wavefronts per SIMD (three per workgroup fit 1025 tokens without
     // an idle wavefront, but leave every other SIMD with a single wavefront and nothing to cover its stalls: 400 vs 368 us)
     int qtiles = (N + 31) / 32;
@@ -509,8 +552,9 @@ extern "C" int scp_vit_attention_split_forward(const float* qkv, float* out, int
     if (split_tail) {
         float* partial = reinterpret_cast<float*>(Vt + plane3);
         hipLaunchKernelGGL(attention_tail_partial_kernel, dim3(TAIL_CHUNKS, tail, B * H), dim3(256), 0, st, qkv, partial, N, H, sl, N - tail,
-                           chunk_keys);
+                           chunk_keys, presplit_qk ? Qp : nullptr, Kp, plane3 / 3, npad);
         hipLaunchKernelGGL(attention_tail_merge_kernel, dim3(tail, B * H), dim3(HD), 0, st, partial, out, N, H, N - tail);
     }
     return scp::check_launch("vit_attention_split");
 }
+}  // namespace

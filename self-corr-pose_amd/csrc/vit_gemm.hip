@@ -84,6 +84,12 @@ struct GemmArgs {
     const int* a_rows;     // optional: GEMM row m reads A row a_rows[m] ...
     const int* c_rows;     // ... and its rowstat / resid / C row is c_rows[m] (row gather / scatter without a copy)
     unsigned long long* clock;   // optional (scp_kernel_clock_begin): [0] = min start, [1] = max end over the workgroups, 100 MHz ticks
+    // optional (EPI_LN, the qkv projection): the Q and K thirds of the result ALSO go out as the attention kernel's operand planes
+    // (csrc/vit_attn_split.hip: Qp / Kp [3][B H][Npad][64] bf16, Q pre-multiplied by scale * log2 e) -- round 4, VERDICT r3 item 3
+    __bf16* QK;            // Qp; Kp = QK + 3 * qk_plane
+    size_t qk_plane;       // elements per plane = B * H * Npad * 64
+    int qk_tok, qk_npad, qk_heads, qk_keep_fp32;   // tokens per image, their padding to 32, heads; also store fp32 Q / K columns
+    float qk_scale;
 };
 
 // kernel-duration clock: first workgroup start to last workgroup end -- what rocprofv3's kernel trace reports as the launch's
@@ -169,9 +175,15 @@ __device__ __forceinline__ void run_tile(const GemmArgs& g, float* lds, int M, i
         }
 #pragma unroll
         for (int j = 0; j < CFG::WN; j++) {
-            const int n = n0 + core.col_base() + 32 * j + l31;
+            const int nt0 = n0 + core.col_base() + 32 * j;         // wavefront-uniform: first column of this 32-column tile
+            const int n = nt0 + l31;
             const bool n_ok = n < g.N;
             const int nc = min(n, g.N - 1);
+            // qkv projection with attention planes: which third (0 = q, 1 = k, 2 = v) this tile belongs to; q / k then leave as
+            // planes and (unless asked for) not as fp32
+            int which = 3;
+            if (EPI == SCP_GEMM_LN && !INDEXED && g.QK) which = nt0 / (g.qk_heads * 64);
+            const bool qk_only = which < 2 && !g.qk_keep_fp32;
             const float v0 = g.vec0[nc];
             float v1 = 0.f;
             if (EPI == SCP_GEMM_LN || EPI == SCP_GEMM_LN_GELU) v1 = g.vec1[nc];
@@ -192,8 +204,45 @@ __device__ __forceinline__ void run_tile(const GemmArgs& g, float* lds, int M, i
                     x += v0;
                     if (EPI == SCP_GEMM_BIAS_RESIDUAL) x += res[r];
                 }
-                if (g.C && m < M && n_ok) g.C[(size_t)orow(r) * g.N + n] = x;
+                if (g.C && m < M && n_ok && !qk_only) g.C[(size_t)orow(r) * g.N + n] = x;
                 xv[r >> 3][r & 7] = x;
+            }
+            if constexpr (EPI == SCP_GEMM_LN && !INDEXED) {
+                if (g.QK && which < 2) {
+                    // Q / K as the attention's planes: token (b, t) of head hd, dims d .. -- same pair exchange as the tiled planes
+                    // below (even lanes store row r's (d, d + 1), odd lanes row r + 1's (d - 1, d)): 64 B contiguous per row
+                    const bool odd = l31 & 1;
+                    const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+                    const int hd = (nt0 - which * g.qk_heads * 64) >> 6, d = (nt0 & 63) + l31 - (odd ? 1 : 0);
+                    __bf16* base = g.QK + (size_t)which * 3 * g.qk_plane;
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        scp::f32x8 xs = xv[q];
+                        if (which == 0) {
+#pragma unroll
+                            for (int e = 0; e < 8; e++) xs[e] *= g.qk_scale;
+                        }
+                        const scp::Split3 sp = scp::split3(xs);
+                        const scp::u32x4 ph = __builtin_bit_cast(scp::u32x4, sp.h), pm = __builtin_bit_cast(scp::u32x4, sp.m),
+                                         pl = __builtin_bit_cast(scp::u32x4, sp.l);
+#pragma unroll
+                        for (int pr = 0; pr < 4; pr++) {
+                            const int r = 8 * q + 2 * pr + (odd ? 1 : 0);
+                            const int m = mb + scp::acc_row(r, half);
+                            const int mc = min(m, M - 1), bimg = mc / g.qk_tok, tok = mc - bimg * g.qk_tok;
+                            __bf16* dst = base + ((size_t)(bimg * g.qk_heads + hd) * g.qk_npad + tok) * 64 + d;
+                            const bool ok = m < M && n_ok;
+                            auto put = [&](unsigned own, __bf16* at) {
+                                const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xF, 0xF, true);
+                                const unsigned v = __builtin_amdgcn_perm(nb, own, sel);
+                                if (ok) *reinterpret_cast<unsigned*>(at) = v;
+                            };
+                            put(ph[pr], dst);
+                            put(pm[pr], dst + g.qk_plane);
+                            put(pl[pr], dst + 2 * g.qk_plane);
+                        }
+                    }
+                }
             }
             if (g.C3) {
                 // the result as three bf16 planes (x = h + m + l exactly) in the TILED layout of csrc/gemm_core_split.h -- the
@@ -436,7 +485,8 @@ int dispatch(const GemmArgs& g, int epilogue, hipStream_t st) {
 
 int vit_linear_impl(const float* A, const void* W, const float* vec0, const float* vec1, const float* rowstat, const float* resid,
                     float* C, int M, const int* m_dev, const int* a_rows, const int* c_rows, int N, int K, int epilogue, void* stream,
-                    const void* A3 = nullptr, int a_rows_total = 0, void* C3 = nullptr, int c_rows_total = 0) {
+                    const void* A3 = nullptr, int a_rows_total = 0, void* C3 = nullptr, int c_rows_total = 0, void* qk_ws = nullptr, int qk_tok = 0,
+                    int qk_heads = 0, float qk_scale = 0.f, int qk_keep_fp32 = 0) {
     if (M <= 0 || N <= 0 || K <= 0) return scp::fail(hipErrorInvalidValue, "vit_linear: empty problem");
     if (!A && !A3) return scp::fail(hipErrorInvalidValue, "vit_linear: no A operand");
     if (!C && !C3) return scp::fail(hipErrorInvalidValue, "vit_linear: no output");
@@ -462,6 +512,14 @@ int vit_linear_impl(const float* A, const void* W, const float* vec0, const floa
     g.nblk_n = (N + BN - 1) / BN;
     g.slots = device_slots();
     g.clock = (g_clock_slots && g_clock_i < g_clock_n) ? g_clock_slots + 2 * (g_clock_i++) : nullptr;
+    if (qk_ws) {
+        if (epilogue != SCP_GEMM_LN || m_dev || a_rows || c_rows || qk_tok <= 0 || qk_heads <= 0 || M % qk_tok || N != 3 * qk_heads * 64)
+            return scp::fail(hipErrorInvalidValue, "vit_linear_qkv: needs the plain SCP_GEMM_LN epilogue, M = images x tokens and N = 3 x heads x 64");
+        g.QK = static_cast<__bf16*>(qk_ws);
+        g.qk_tok = qk_tok; g.qk_heads = qk_heads; g.qk_scale = qk_scale; g.qk_keep_fp32 = qk_keep_fp32;
+        g.qk_npad = (qk_tok + 31) / 32 * 32;
+        g.qk_plane = (size_t)(M / qk_tok) * qk_heads * g.qk_npad * 64;
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int bad = (split && A3) ? dispatch<3>(g, epilogue, st) : split ? dispatch<1>(g, epilogue, st) : bf16 ? dispatch<2>(g, epilogue, st) : dispatch<0>(g, epilogue, st);
     if (bad) return bad;
@@ -486,6 +544,14 @@ extern "C" int scp_vit_linear_planes(const float* A, const void* A_planes, int a
                                      int max_rows, const int* a_rows, const int* c_rows, int N, int K, int epilogue, void* stream) {
     return vit_linear_impl(A, W, vec0, vec1, rowstat, resid, C, max_rows, rows_dev, a_rows, c_rows, N, K, epilogue, stream, A_planes, a_rows_total,
                            C_planes, c_rows_total);
+}
+
+extern "C" int scp_vit_linear_qkv(const float* A, const void* A_planes, int a_rows_total, const void* W, const float* vec0, const float* vec1,
+                                  const float* rowstat, float* C, int M, int N, int K, int epilogue, void* attn_workspace, int tokens, int heads,
+                                  float scale, int keep_fp32_qk, void* stream) {
+    if (!attn_workspace) return scp::fail(hipErrorInvalidValue, "vit_linear_qkv: null attention workspace");
+    return vit_linear_impl(A, W, vec0, vec1, rowstat, nullptr, C, M, nullptr, nullptr, nullptr, N, K, epilogue, stream, A_planes, a_rows_total,
+                           nullptr, 0, attn_workspace, tokens, heads, scale * 1.4426950408889634f, keep_fp32_qk);
 }
 
 extern "C" int scp_row_mean_rstd(const float* x, float* stats, int rows, int C, float eps, void* stream) {

@@ -99,7 +99,14 @@ def gemm_mode():
     return "bf16" if MIXED_BF16 else GEMM_MODE
 
 
-def fused_attention(qkv, b, n, heads, head_dim, scale, q_rows=None, q_count=None, mode=None):
+def attention_workspace(b, n, heads, device):
+    """the operand-plane workspace of the split attention (scp_vit_attention_split_workspace bytes); the qkv projection can write the
+    Q / K planes into it (vit_linear(..., qk_planes=...)) and hand it to fused_attention(presplit=...)"""
+    from . import capi
+    return torch.empty(capi.lib().scp_vit_attention_split_workspace(b, n, heads), dtype=torch.uint8, device=device)
+
+
+def fused_attention(qkv, b, n, heads, head_dim, scale, q_rows=None, q_count=None, mode=None, presplit=None):
     """HIP flash-style attention on the matrix cores (csrc/vit_attn_split.hip / csrc/vit_attn.hip, see ATTN_MODE): qkv
     [b,n,3*heads*head_dim] as produced by the qkv Linear -> [b, n, heads*head_dim].  Forward only (the DINO ViT is frozen and
     always evaluated under no_grad); GPU tensors only, no CPU fallback.
@@ -118,11 +125,22 @@ def fused_attention(qkv, b, n, heads, head_dim, scale, q_rows=None, q_count=None
         for t, name, numel in ((q_rows, "q_rows", b * n), (q_count, "q_count", b)):
             if not (t is not None and t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and t.numel() == numel):
                 raise RuntimeError("fused_attention: %s must be a contiguous int32 device tensor of %d entries" % (name, numel))
+    if presplit is not None and mode != "split":
+        raise RuntimeError("fused_attention: pre-split Q / K planes belong to the split attention (mode %r)" % (mode,))
     if mode in ("split", "bf16"):
         L = capi.lib()
         ws_bytes = L.scp_vit_attention_split_workspace(b, n, heads)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device)
         ip = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+        if presplit is not None:
+            # Q / K planes already in the workspace (written by the qkv GEMM's epilogue); the kernel re-lays V only
+            if not (presplit.is_cuda and presplit.dtype == torch.uint8 and presplit.numel() >= ws_bytes):
+                raise RuntimeError("fused_attention: presplit must be attention_workspace(b, n, heads, device)")
+            capi.check(L.scp_vit_attention_split_forward_presplit(capi.dev_ptr(qkv, "qkv"), capi.dev_ptr(out, "out"), b, n, heads, head_dim,
+                                                                  float(scale), ip(q_rows), ip(q_count), ctypes.c_void_p(presplit.data_ptr()),
+                                                                  presplit.numel(), capi.current_stream()),
+                       "scp_vit_attention_split_forward_presplit")
+            return out
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device)
         capi.check(L.scp_vit_attention_split_forward(capi.dev_ptr(qkv, "qkv"), capi.dev_ptr(out, "out"), b, n, heads, head_dim,
                                                      float(scale), ip(q_rows), ip(q_count), int(mode == "split"),
                                                      ctypes.c_void_p(ws.data_ptr()), ws_bytes,
@@ -183,6 +201,8 @@ GEMM_MODE = os.environ.get("SCP_VIT_GEMM", "split")
 # split mode: activations reach the next GEMM pre-split (bf16 planes written by the producing epilogue; csrc/vit_gemm.hip CORE 3).
 # SCP_VIT_PRESPLIT=0: every GEMM splits its fp32 A operand in registers, as in round 3 (A/B switch).
 PRESPLIT_ACTIVATIONS = os.environ.get("SCP_VIT_PRESPLIT", "1") == "1"
+# the qkv projection's epilogue writes the split attention's Q / K operand planes (round 4; "0": the re-layout kernel makes all three)
+QK_FROM_EPILOGUE = os.environ.get("SCP_VIT_QK_EPILOGUE", "1") == "1"
 
 
 def split_weight(w):
@@ -228,7 +248,7 @@ def split_tiled(x):
 
 
 def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilogue=GEMM_BIAS, rows=None, a_rows=None, c_rows=None,
-               max_rows=None, mode=None, w_split=None, a_planes=None, out_planes=None, fp32_out=True):
+               max_rows=None, mode=None, w_split=None, a_planes=None, out_planes=None, fp32_out=True, qk_planes=None):
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T) on the matrix cores (csrc/vit_gemm.hip, include/scp_hip.h scp_vit_linear);
     `resid` may be `out` itself (in-place residual stream).  Forward only, GPU tensors only.  `mode` (default GEMM_MODE):
     "split" = bf16 matrix cores on exactly split operands (`w_split` = split_weight(w) if the caller keeps it), "fp32" = fp32
@@ -239,7 +259,10 @@ def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilog
     Pre-split operands (split mode only, scp_vit_linear_planes): `a_planes` = TiledPlanes [rows, K], the A operand as the producing
     layer's epilogue left it (`a` may then be None; the main loop has no VALU split; `w_split` must then be the TiledPlanes of w);
     `out_planes` = TiledPlanes [rows, N] receives the result split the same way (the next layer's a_planes); `fp32_out=False` with
-    out_planes: the fp32 result is not stored at all."""
+    out_planes: the fp32 result is not stored at all.
+    `qk_planes` = (attention_workspace, tokens_per_image, heads, scale[, keep_fp32]) (split mode, the qkv projection with the
+    GEMM_LN epilogue, scp_vit_linear_qkv): the Q and K thirds of the result are written as the split attention's operand planes into
+    that workspace (and, unless keep_fp32, NOT as fp32: those columns of `out` stay uninitialised)."""
     from . import capi
     if torch.is_grad_enabled() and ((a is not None and a.requires_grad) or w.requires_grad):
         raise RuntimeError("scp_amd.dino.vit_linear is forward-only (frozen ViT)")
@@ -277,7 +300,7 @@ def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilog
         w_ptr = capi.dev_ptr(w, "w")
     else:
         raise RuntimeError("vit_linear: unknown mode %r" % (mode,))
-    if a_planes is not None or out_planes is not None:
+    if a_planes is not None or out_planes is not None or qk_planes is not None:
         if mode != "split":
             raise RuntimeError("vit_linear: operand planes need the split main loop (mode %r)" % (mode,))
         for t, name, cols in ((a_planes, "a_planes", k), (out_planes, "out_planes", n)):
@@ -294,6 +317,16 @@ def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilog
         bp = lambda t: ctypes.c_void_p(0 if t is None else t.blob.data_ptr())
         if rows is not None and max_rows is None:
             max_rows = m
+        if qk_planes is not None:
+            ws, tokens, heads, scale = qk_planes[:4]
+            if rows is not None or a_rows is not None or c_rows is not None or out_planes is not None or resid is not None:
+                raise RuntimeError("vit_linear: qk_planes goes with the plain qkv projection (no row selection, no output planes)")
+            code = L.scp_vit_linear_qkv(ip(a if a_planes is None else None), bp(a_planes), 0 if a_planes is None else a_planes.rows_pad, w_ptr,
+                                        capi.dev_ptr(vec0, "vec0"), capi.opt_ptr(vec1, "vec1"), capi.opt_ptr(rowstat, "rowstat"), ip(out),
+                                        m, n, k, epilogue, ctypes.c_void_p(ws.data_ptr()), int(tokens), int(heads), float(scale),
+                                        int(len(qk_planes) > 4 and bool(qk_planes[4])), capi.current_stream())
+            capi.check(code, "scp_vit_linear_qkv")
+            return out
         code = L.scp_vit_linear_planes(ip(a if a_planes is None else None), bp(a_planes), 0 if a_planes is None else a_planes.rows_pad, w_ptr,
                                        capi.dev_ptr(vec0, "vec0"), capi.opt_ptr(vec1, "vec1"), capi.opt_ptr(rowstat, "rowstat"),
                                        capi.opt_ptr(resid, "resid"), ip(out), bp(out_planes),
@@ -394,9 +427,11 @@ class _Block(nn.Module):
         a = self.attn
         sp = self._planes
         pl = x3 is not None and gemm_mode() == "split"
+        # the qkv projection's epilogue writes the attention's Q / K operand planes itself (the re-layout pass then moves V only)
+        ws = attention_workspace(b, n, a.num_heads, x2d.device) if (pl and attn_mode() == "split" and QK_FROM_EPILOGUE) else None
         qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN, w_split=sp["qkv_t" if pl else "qkv"],
-                         a_planes=x3 if pl else None)
-        y = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, x2d.shape[1] // a.num_heads, a.scale)
+                         a_planes=x3 if pl else None, qk_planes=None if ws is None else (ws, n, a.num_heads, a.scale))
+        y = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, x2d.shape[1] // a.num_heads, a.scale, presplit=ws)
         vit_linear(y.view(b * n, -1), a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["proj"],
                    out_planes=x3 if pl else None)
         if pl:
@@ -424,14 +459,15 @@ class _Block(nn.Module):
         c = x2d.shape[1]
         sp = self._planes
         pl = x3 is not None and gemm_mode() == "split"
+        ws = attention_workspace(b, n, a.num_heads, x2d.device) if (pl and attn_mode() == "split" and QK_FROM_EPILOGUE) else None
         qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN, w_split=sp["qkv_t" if pl else "qkv"],
-                         a_planes=x3 if pl else None)
+                         a_planes=x3 if pl else None, qk_planes=None if ws is None else (ws, n, a.num_heads, a.scale))
         # attention: keys / values of all tokens, queries only for the kept ones (per image, compacted to the front of the
         # query slots; their outputs land on their own rows)
         k8 = keep.to(torch.uint8)
         q_rows = torch.argsort(k8, dim=1, descending=True, stable=True).to(torch.int32)
         q_count = keep.sum(1, dtype=torch.int32)
-        y = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, c // a.num_heads, a.scale, q_rows, q_count).view(b * n, c)
+        y = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, c // a.num_heads, a.scale, q_rows, q_count, presplit=ws).view(b * n, c)
         flat = keep.reshape(-1)
         idx = torch.argsort(flat.to(torch.uint8), descending=True, stable=True).to(torch.int32)   # kept rows first, original order
         rows = flat.sum(dtype=torch.int32).reshape(1)

@@ -305,6 +305,50 @@ def test_vit_linear_with_presplit_operands(M, K, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(2, 1025), (3, 197), (2, 200), (1, 70), (2, 64), (5, 33)])
+def test_qkv_epilogue_planes_give_the_same_attention_bit_for_bit(B, N):
+    """scp_vit_linear_qkv + scp_vit_attention_split_forward_presplit (round 4): the qkv projection's epilogue writes the attention's
+    Q / K operand planes, the re-layout pass handles V only and the leftover-query kernel reads Q / K from the planes -- the same
+    bits as splitting the fp32 qkv tensor, so the attention output is IDENTICAL; also with a query selection, from fp32 A and from
+    A planes, and with the fp32 Q / K columns kept."""
+    from scp_amd import dino
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    H, C = 6, 384
+    x = (torch.randn(B * N, C, generator=g) * 1.2 + 0.1).cuda()
+    w = (torch.randn(3 * C, C, generator=g) * 0.06).cuda()
+    v0, v1 = (torch.randn(3 * C, generator=g) * 0.1).cuda(), (torch.randn(3 * C, generator=g) * 0.1).cuda()
+    st = dino.row_mean_rstd(x, 1e-6)
+    scale = 64 ** -0.5
+    x3, w3t, w3 = dino.split_tiled(x), dino.split_tiled(w), dino.split_weight(w)
+    kw = dict(vec1=v1, rowstat=st, epilogue=dino.GEMM_LN, mode="split")
+    qkv = dino.vit_linear(x, w, v0, w_split=w3, **kw)
+    ref = dino.fused_attention(qkv.view(B, N, -1), B, N, H, 64, scale, mode="split")
+    keep = torch.rand(B, N, generator=g) < 0.3
+    keep[:, 0] = True
+    q_rows = torch.argsort(keep.to(torch.uint8), dim=1, descending=True, stable=True).to(torch.int32).cuda()
+    q_count = keep.sum(1, dtype=torch.int32).cuda()
+    ref_rows = dino.fused_attention(qkv.view(B, N, -1), B, N, H, 64, scale, q_rows, q_count, mode="split")
+    for a, a3, ws_, keep_fp32 in ((x, None, w3, False), (None, x3, w3t, False), (None, x3, w3t, True)):
+        ws = dino.attention_workspace(B, N, H, "cuda")
+        ws.fill_(0xFF)                                   # NaN patterns: whatever is read must have been written
+        out = torch.full((B * N, 3 * C), float("nan"), device="cuda")
+        got = dino.vit_linear(a, w, v0, w_split=ws_, a_planes=a3, out=out, qk_planes=(ws, N, H, scale, keep_fp32), **kw)
+        assert torch.equal(got[:, 2 * C:], qkv[:, 2 * C:])                       # V third: fp32 as before
+        if keep_fp32:
+            assert torch.equal(got, qkv)
+        else:
+            assert bool(torch.isnan(got[:, :2 * C]).all())                       # Q / K thirds were not stored
+        y = dino.fused_attention(got.view(B, N, -1), B, N, H, 64, scale, mode="split", presplit=ws)
+        assert torch.equal(y, ref)
+        ws2 = dino.attention_workspace(B, N, H, "cuda")
+        ws2.fill_(0xFF)
+        got2 = dino.vit_linear(a, w, v0, w_split=ws_, a_planes=a3, qk_planes=(ws2, N, H, scale), **kw)
+        y2 = dino.fused_attention(got2.view(B, N, -1), B, N, H, 64, scale, q_rows, q_count, mode="split", presplit=ws2)
+        sel = keep.cuda()
+        assert torch.equal(y2[sel], ref_rows[sel])
+
+
+@pytest.mark.gpu
 def test_vit_linear_with_device_row_count(gemm_mode):
     """scp_vit_linear_rows: only the first rows[0] rows are computed (bitwise equal to the full launch), the rest is untouched"""
     from scp_amd import dino
