@@ -199,8 +199,12 @@ def isolated_gemms(M, C=384, iters=20):
             a_in = None if name == "proj" else dino_mod.split_tiled(a)                     # proj reads the attention's fp32 output
             o3 = None if name == "qkv" else dino_mod.TiledPlanes(M, N, "cuda")              # qkv feeds the attention in fp32
             w3 = dino_mod.split_weight(w) if name == "proj" else dino_mod.split_tiled(w)
-            run = lambda: dino_mod.vit_linear(a if a_in is None else None, w, v0, v1, st, out, out=None if name == "fc1" else out, epilogue=epi,
-                                              w_split=w3, a_planes=a_in, out_planes=o3, fp32_out=name != "fc1")
+            qk = None
+            if name == "qkv" and dino_mod.QK_FROM_EPILOGUE and dino_mod.attn_mode() == "split" and M % 1025 == 0:
+                # as the block runs it: the epilogue writes the attention's Q / K planes, only the V third leaves as fp32
+                qk = (dino_mod.attention_workspace(M // 1025, 1025, C // 64, "cuda"), 1025, C // 64, 0.125)
+            run = lambda: dino_mod.vit_linear(a if a_in is None else None, w, v0, v1, st, None if qk else out, out=None if name == "fc1" else out,
+                                              epilogue=epi, w_split=w3, a_planes=a_in, out_planes=o3, fp32_out=name != "fc1", qk_planes=qk)
         else:
             w3 = dino_mod.split_weight(w) if dino_mod.gemm_mode() == "split" else None      # bf16 / fp32 modes: vit_linear prepares W itself
             run = lambda: dino_mod.vit_linear(a, w, v0, v1, st, out, out=out, epilogue=epi, w_split=w3)

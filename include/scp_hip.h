@@ -485,15 +485,16 @@ size_t scp_vit_attention_split_workspace(int B, int N, int H);
 int scp_vit_attention_split_forward(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale, const int* q_rows,
                                     const int* q_count, int exact, void* workspace, size_t workspace_bytes, void* stream);
 /* The same with the Q and K planes ALREADY in `workspace`, written there by the qkv projection's epilogue (scp_vit_linear_qkv on the
- * same workspace, same B / N / H / scale): only V^T is re-laid here and the fp32 qkv tensor is read for its V third alone (its Q / K
- * thirds may be uninitialised).  Exact split only. */
+ * same workspace, same B / N / H / scale): only V^T is re-laid here and the fp32 qkv tensor is read for its V third -- and, when N % 32 is
+ * in 1..8 and no query selection is given, for its K third by the leftover-query kernel (keep_fp32_qk bit 1 of scp_vit_linear_qkv); its Q
+ * third may be uninitialised.  Exact split only. */
 int scp_vit_attention_split_forward_presplit(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale,
                                              const int* q_rows, const int* q_count, void* workspace, size_t workspace_bytes, void* stream);
 /* The qkv projection qkv = LN1(x) Wqkv^T + b (scp_vit_linear / scp_vit_linear_planes with SCP_GEMM_LN | SCP_GEMM_W_SPLIT3; A fp32 or
  * A_planes) whose epilogue ALSO writes the attention's Q / K operand planes into `attn_workspace` (layout of
  * scp_vit_attention_split_workspace(M / tokens, tokens, heads): Q pre-multiplied by scale * log2 e, then split exactly like
- * scp_vit_attention_split_forward does) -- the re-layout pass then handles V only.  keep_fp32_qk == 0: the Q / K thirds of C are not
- * stored at all.  M = images x tokens, N = 3 x heads x 64 (vision_transformer_flexible.py:85-101). */
+ * scp_vit_attention_split_forward does) -- the re-layout pass then handles V only.  keep_fp32_qk: bit 0 / bit 1 = the Q / K third of C is
+ * ALSO stored as fp32 (0: neither is stored at all; 2 is what the attention's leftover-query kernel needs).  M = images x tokens, N = 3 x heads x 64 (vision_transformer_flexible.py:85-101). */
 int scp_vit_linear_qkv(const float* A, const void* A_planes, int a_rows_total, const void* W, const float* vec0, const float* vec1,
                        const float* rowstat, float* C, int M, int N, int K, int epilogue, void* attn_workspace, int tokens, int heads,
                        float scale, int keep_fp32_qk, void* stream);

@@ -394,8 +394,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attention_split_kernel(cons
 // (max, sum, partial output[64]); a second tiny kernel merges the chunks.
 constexpr int TAIL_CHUNKS = 8, TAIL_REC = 2 + HD;
 
-// Qp != nullptr: Q (pre-scaled) and K come from the operand planes (x = h + m + l exactly: the sum reproduces the fp32 value the
-// qkv tensor would hold, so both sources give the same bits); V always from the qkv tensor
+// Qp != nullptr: Q (pre-scaled) comes from the operand planes (x = h + m + l exactly: the sum reproduces the fp32 value q * scale the
+// other branch computes, so both give the same bits); K and V always from the qkv tensor
 __device__ __forceinline__ float4 planes4(const __bf16* p, size_t plane) {
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     const bf16x4 h = *reinterpret_cast<const bf16x4*>(p), m = *reinterpret_cast<const bf16x4*>(p + plane),
@@ -421,11 +421,13 @@ __global__ __launch_bounds__(256) void attention_tail_partial_kernel(const float
     if (tid < nk) {
         float a = 0.f;
         if (Qp) {
+            // pre-split: the query row (one per workgroup, pre-scaled) from its planes, the keys from the fp32 K third that the qkv
+            // projection keeps for this kernel (a key row as three 128-B plane rows was twice as slow: 48 small loads per thread)
             const __bf16* qp = Qp + ((size_t)bh * Npad + q) * HD;
-            const __bf16* kp = Kp + ((size_t)bh * Npad + k0 + tid) * HD;
+            const float4* kp = reinterpret_cast<const float4*>(base + (size_t)(k0 + tid) * row_stride + (size_t)H * HD);
 #pragma unroll
             for (int i = 0; i < HD / 4; i++) {
-                const float4 u = planes4(qp + 4 * i, plane), t = planes4(kp + 4 * i, plane);
+                const float4 u = planes4(qp + 4 * i, plane), t = kp[i];
                 a = fmaf(u.x, t.x, a); a = fmaf(u.y, t.y, a);
                 a = fmaf(u.z, t.z, a); a = fmaf(u.w, t.w, a);
             }

@@ -88,7 +88,7 @@ struct GemmArgs {
     // (csrc/vit_attn_split.hip: Qp / Kp [3][B H][Npad][64] bf16, Q pre-multiplied by scale * log2 e) -- round 4, VERDICT r3 item 3
     __bf16* QK;            // Qp; Kp = QK + 3 * qk_plane
     size_t qk_plane;       // elements per plane = B * H * Npad * 64
-    int qk_tok, qk_npad, qk_heads, qk_keep_fp32;   // tokens per image, their padding to 32, heads; also store fp32 Q / K columns
+    int qk_tok, qk_npad, qk_heads, qk_keep_fp32;   // tokens per image, their padding to 32, heads; bits 0 / 1: also store the fp32 Q / K columns
     float qk_scale;
 };
 
@@ -183,7 +183,7 @@ __device__ __forceinline__ void run_tile(const GemmArgs& g, float* lds, int M, i
             // planes and (unless asked for) not as fp32
             int which = 3;
             if (EPI == SCP_GEMM_LN && !INDEXED && g.QK) which = nt0 / (g.qk_heads * 64);
-            const bool qk_only = which < 2 && !g.qk_keep_fp32;
+            const bool qk_only = which < 2 && !((g.qk_keep_fp32 >> which) & 1);          // bit 0: keep fp32 Q, bit 1: keep fp32 K
             const float v0 = g.vec0[nc];
             float v1 = 0.f;
             if (EPI == SCP_GEMM_LN || EPI == SCP_GEMM_LN_GELU) v1 = g.vec1[nc];

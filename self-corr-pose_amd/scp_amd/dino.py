@@ -262,7 +262,8 @@ def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilog
     out_planes: the fp32 result is not stored at all.
     `qk_planes` = (attention_workspace, tokens_per_image, heads, scale[, keep_fp32]) (split mode, the qkv projection with the
     GEMM_LN epilogue, scp_vit_linear_qkv): the Q and K thirds of the result are written as the split attention's operand planes into
-    that workspace (and, unless keep_fp32, NOT as fp32: those columns of `out` stay uninitialised)."""
+    that workspace; keep_fp32 bit 0 / 1: the Q / K third is ALSO stored as fp32 (default 2: K only, which the attention's
+    leftover-query kernel reads; the Q columns of `out` stay uninitialised)."""
     from . import capi
     if torch.is_grad_enabled() and ((a is not None and a.requires_grad) or w.requires_grad):
         raise RuntimeError("scp_amd.dino.vit_linear is forward-only (frozen ViT)")
@@ -324,7 +325,7 @@ def vit_linear(a, w, vec0, vec1=None, rowstat=None, resid=None, out=None, epilog
             code = L.scp_vit_linear_qkv(ip(a if a_planes is None else None), bp(a_planes), 0 if a_planes is None else a_planes.rows_pad, w_ptr,
                                         capi.dev_ptr(vec0, "vec0"), capi.opt_ptr(vec1, "vec1"), capi.opt_ptr(rowstat, "rowstat"), ip(out),
                                         m, n, k, epilogue, ctypes.c_void_p(ws.data_ptr()), int(tokens), int(heads), float(scale),
-                                        int(len(qk_planes) > 4 and bool(qk_planes[4])), capi.current_stream())
+                                        int(qk_planes[4]) if len(qk_planes) > 4 else 2, capi.current_stream())
             capi.check(code, "scp_vit_linear_qkv")
             return out
         code = L.scp_vit_linear_planes(ip(a if a_planes is None else None), bp(a_planes), 0 if a_planes is None else a_planes.rows_pad, w_ptr,

@@ -328,16 +328,17 @@ def test_qkv_epilogue_planes_give_the_same_attention_bit_for_bit(B, N):
     q_rows = torch.argsort(keep.to(torch.uint8), dim=1, descending=True, stable=True).to(torch.int32).cuda()
     q_count = keep.sum(1, dtype=torch.int32).cuda()
     ref_rows = dino.fused_attention(qkv.view(B, N, -1), B, N, H, 64, scale, q_rows, q_count, mode="split")
-    for a, a3, ws_, keep_fp32 in ((x, None, w3, False), (None, x3, w3t, False), (None, x3, w3t, True)):
+    for a, a3, ws_, keep_fp32 in ((x, None, w3, 2), (None, x3, w3t, 2), (None, x3, w3t, 3)):
         ws = dino.attention_workspace(B, N, H, "cuda")
         ws.fill_(0xFF)                                   # NaN patterns: whatever is read must have been written
         out = torch.full((B * N, 3 * C), float("nan"), device="cuda")
         got = dino.vit_linear(a, w, v0, w_split=ws_, a_planes=a3, out=out, qk_planes=(ws, N, H, scale, keep_fp32), **kw)
         assert torch.equal(got[:, 2 * C:], qkv[:, 2 * C:])                       # V third: fp32 as before
-        if keep_fp32:
+        assert torch.equal(got[:, C:2 * C], qkv[:, C:2 * C])                     # K third kept (bit 1)
+        if keep_fp32 == 3:
             assert torch.equal(got, qkv)
         else:
-            assert bool(torch.isnan(got[:, :2 * C]).all())                       # Q / K thirds were not stored
+            assert bool(torch.isnan(got[:, :C]).all())                           # the Q third was not stored
         y = dino.fused_attention(got.view(B, N, -1), B, N, H, 64, scale, mode="split", presplit=ws)
         assert torch.equal(y, ref)
         ws2 = dino.attention_workspace(B, N, H, "cuda")
