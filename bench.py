@@ -220,8 +220,12 @@ def isolated_gemms(M, C=384, iters=20):
         ms_total += e0.elapsed_time(e1) / iters
         fl_total += 2.0 * M * N * K
     tf = fl_total / (ms_total * 1e-3) / 1e12
+    qk_epi = bool(planes and dino_mod.QK_FROM_EPILOGUE and dino_mod.attn_mode() == "split" and M % 1025 == 0)
     return {"block_ms": ms_total, "achieved": tf, "frac": tf / gemm_peak_tf(), "vs_fp32_mfma_peak": tf / FP32_VALU_PEAK_TF,
-            "operands": "pre-split tiled planes" if planes else "fp32 A split in registers"}
+            "operands": "pre-split tiled planes" if planes else "fp32 A split in registers",
+            "qkv_epilogue_writes_attention_planes": qk_epi,
+            "note": ("the qkv launch also does the Q / K half of the attention's re-layout pass (its epilogue splits and stores the planes): "
+                     "+0.05 ms on these four launches, -0.036 ms on qkv_split_kernel per block, which is not among them (DESIGN 4.4a)") if qk_epi else ""}
 
 
 def fused_conv_mode():
