@@ -148,6 +148,11 @@ __device__ __forceinline__ void run_tile(const GemmArgs& g, float* lds, int M, i
     else core.set_rows(g.A, g.W, g.N, g.K, a_row, w_row);
     typename Core::Acc acc;
     core.run(acc, g.K / CFG::BK);
+    // per-wavefront staging block of the plane epilogues, carved out of the operand ring: every wavefront must be through with the
+    // ring first
+    constexpr int STAGE_STRIDE = 36, STAGE_WORDS = 32 * STAGE_STRIDE;
+    float* stage = lds;
+    if (g.C3 || g.QK) __syncthreads();
 
     // ---- epilogue.  MFMA layout: A rows -> accumulator rows acc_row(reg, half), W rows (= output columns) -> lane & 31: a
     // lane holds C[m][n = n_base + l31] for 16 rows m -> 32 consecutive floats per row per half-wave.  All loads of a 32 x 32
@@ -192,7 +197,13 @@ __device__ __forceinline__ void run_tile(const GemmArgs& g, float* lds, int M, i
 #pragma unroll
                 for (int r = 0; r < 16; r++) res[r] = g.resid[(size_t)orow(r) * g.N + nc];
             }
-            scp::f32x8 xv[2];
+            // With plane outputs (C3: the next GEMM's tiled A planes; QK: the attention's Q / K planes) the tile goes through a
+            // per-wavefront LDS block (the operand ring is idle now) and is read back ROW-wise: a lane then holds 8 consecutive columns
+            // of one row -- one split3, three 16-byte stores per 8 values (a KiB per store instruction in the tiled layout), and the fp32
+            // copy leaves as float4 rows.  Round 4, second half: the column-per-lane form of this epilogue (pairs exchanged with the
+            // neighbouring lane by DPP, 24 dword stores + ~350 VALU per 32 x 32 tile) cost 25 % of the proj GEMM and ~20 % of a block.
+            const bool staged = g.C3 != nullptr || which < 2;
+            float* st = stage + core.wave * STAGE_WORDS;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = mb + scp::acc_row(r, half);
@@ -204,76 +215,74 @@ __device__ __forceinline__ void run_tile(const GemmArgs& g, float* lds, int M, i
                     x += v0;
                     if (EPI == SCP_GEMM_BIAS_RESIDUAL) x += res[r];
                 }
-                if (g.C && m < M && n_ok && !qk_only) g.C[(size_t)orow(r) * g.N + n] = x;
-                xv[r >> 3][r & 7] = x;
+                if (staged) st[scp::acc_row(r, half) * STAGE_STRIDE + l31] = x;
+                else if (g.C && m < M && n_ok) g.C[(size_t)orow(r) * g.N + n] = x;
             }
-            if constexpr (EPI == SCP_GEMM_LN && !INDEXED) {
-                if (g.QK && which < 2) {
-                    // Q / K as the attention's planes: token (b, t) of head hd, dims d .. -- same pair exchange as the tiled planes
-                    // below (even lanes store row r's (d, d + 1), odd lanes row r + 1's (d - 1, d)): 64 B contiguous per row
-                    const bool odd = l31 & 1;
-                    const unsigned sel = odd ? 0x03020706u : 0x05040100u;
-                    const int hd = (nt0 - which * g.qk_heads * 64) >> 6, d = (nt0 & 63) + l31 - (odd ? 1 : 0);
-                    __bf16* base = g.QK + (size_t)which * 3 * g.qk_plane;
+            if (staged) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int lane = core.lane;
+                auto orow_l = [&](int rl) {
+                    const int m = min(mb + rl, M - 1);
+                    return (INDEXED && g.c_rows) ? g.c_rows[m] : m;
+                };
+                auto row8 = [&](int rl, int c8) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(st + rl * STAGE_STRIDE + c8);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(st + rl * STAGE_STRIDE + c8 + 4);
+                    return scp::f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                };
+                if (g.C && !qk_only) {
+                    // fp32: lane = (row lane >> 3 (+ 8 it), 4 columns): 128 B per row, 16-byte stores
 #pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        scp::f32x8 xs = xv[q];
-                        if (which == 0) {
+                    for (int it = 0; it < 4; it++) {
+                        const int rl = (lane >> 3) + 8 * it, c4 = 4 * (lane & 7);
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(st + rl * STAGE_STRIDE + c4);
+                        if (mb + rl < M && nt0 + c4 < g.N) *reinterpret_cast<f32x4*>(g.C + (size_t)orow_l(rl) * g.N + nt0 + c4) = v;
+                    }
+                }
+                if (g.C3) {
+                    // tiled planes: lane = (row lane >> 1, half of a 16-column chunk): every store instruction one contiguous KiB
+                    const int rl = lane >> 1;
+                    const int kch = g.N >> 4;                              // the planes are the next layer's A operand: its K = this N
 #pragma unroll
-                            for (int e = 0; e < 8; e++) xs[e] *= g.qk_scale;
-                        }
-                        const scp::Split3 sp = scp::split3(xs);
-                        const scp::u32x4 ph = __builtin_bit_cast(scp::u32x4, sp.h), pm = __builtin_bit_cast(scp::u32x4, sp.m),
-                                         pl = __builtin_bit_cast(scp::u32x4, sp.l);
-#pragma unroll
-                        for (int pr = 0; pr < 4; pr++) {
-                            const int r = 8 * q + 2 * pr + (odd ? 1 : 0);
-                            const int m = mb + scp::acc_row(r, half);
-                            const int mc = min(m, M - 1), bimg = mc / g.qk_tok, tok = mc - bimg * g.qk_tok;
-                            __bf16* dst = base + ((size_t)(bimg * g.qk_heads + hd) * g.qk_npad + tok) * 64 + d;
-                            const bool ok = m < M && n_ok;
-                            auto put = [&](unsigned own, __bf16* at) {
-                                const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xF, 0xF, true);
-                                const unsigned v = __builtin_amdgcn_perm(nb, own, sel);
-                                if (ok) *reinterpret_cast<unsigned*>(at) = v;
-                            };
-                            put(ph[pr], dst);
-                            put(pm[pr], dst + g.qk_plane);
-                            put(pl[pr], dst + 2 * g.qk_plane);
+                    for (int c = 0; c < 2; c++) {
+                        const int c8 = 16 * c + 8 * (lane & 1);
+                        const scp::Split3 sp = scp::split3(row8(rl, c8));
+                        __bf16* dst = g.C3 + scp::tiled_plane_offset(orow_l(rl), nt0 + c8, 0, kch);
+                        if (mb + rl < M && nt0 + c8 < g.N) {
+                            *reinterpret_cast<scp::bf16x8*>(dst) = sp.h;
+                            *reinterpret_cast<scp::bf16x8*>(dst + 512) = sp.m;
+                            *reinterpret_cast<scp::bf16x8*>(dst + 1024) = sp.l;
                         }
                     }
                 }
-            }
-            if (g.C3) {
-                // the result as three bf16 planes (x = h + m + l exactly) in the TILED layout of csrc/gemm_core_split.h -- the
-                // pre-split A operand of the next GEMM, every LDS-DMA piece of it one contiguous KiB.  A lane holds
-                // ONE column: rows are taken in pairs (r, r + 1), split together (packed bf16 pairs), and exchanged with the
-                // neighbouring column's lane so that even lanes store row r's pair (n, n + 1) and odd lanes row r + 1's pair
-                // (n - 1, n): dword stores, 64 B contiguous per row and half-wavefront.
-                const bool odd = l31 & 1;
-                const unsigned sel = odd ? 0x03020706u : 0x05040100u;
-                const int kch = g.N >> 4;                                  // the planes are the next layer's A operand: its K = this N
+                if constexpr (EPI == SCP_GEMM_LN && !INDEXED) {
+                    if (g.QK && which < 2) {
+                        // Q / K as the attention's planes [plane][(image H + head) Npad + token][64]: lane = (row lane >> 2 (+ 16 it), 8
+                        // of the tile's 32 dims): 64 B contiguous per row and store instruction
+                        const int hd = (nt0 - which * g.qk_heads * 64) >> 6;
+                        __bf16* base = g.QK + (size_t)which * 3 * g.qk_plane;
 #pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const scp::Split3 sp = scp::split3(xv[q]);
-                    const scp::u32x4 ph = __builtin_bit_cast(scp::u32x4, sp.h), pm = __builtin_bit_cast(scp::u32x4, sp.m),
-                                     pl = __builtin_bit_cast(scp::u32x4, sp.l);
+                        for (int it = 0; it < 2; it++) {
+                            const int rl = (lane >> 2) + 16 * it, c8 = 8 * (lane & 3);
+                            scp::f32x8 xs = row8(rl, c8);
+                            if (which == 0) {
 #pragma unroll
-                    for (int pr = 0; pr < 4; pr++) {
-                        const int r = 8 * q + 2 * pr + (odd ? 1 : 0);
-                        const int m = mb + scp::acc_row(r, half);
-                        __bf16* dst = g.C3 + scp::tiled_plane_offset(orow(r), n - (odd ? 1 : 0), 0, kch);
-                        const bool ok = m < M && n_ok;
-                        auto put = [&](unsigned own, __bf16* at) {
-                            const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xF, 0xF, true);
-                            const unsigned v = __builtin_amdgcn_perm(nb, own, sel);
-                            if (ok) *reinterpret_cast<unsigned*>(at) = v;
-                        };
-                        put(ph[pr], dst);
-                        put(pm[pr], dst + 512);
-                        put(pl[pr], dst + 1024);
+                                for (int e = 0; e < 8; e++) xs[e] *= g.qk_scale;
+                            }
+                            const scp::Split3 sp = scp::split3(xs);
+                            const int mc = min(mb + rl, M - 1), bimg = mc / g.qk_tok, tok = mc - bimg * g.qk_tok;
+                            __bf16* dst = base + ((size_t)(bimg * g.qk_heads + hd) * g.qk_npad + tok) * 64 + (nt0 & 63) + c8;
+                            if (mb + rl < M && nt0 + c8 < g.N) {
+                                *reinterpret_cast<scp::bf16x8*>(dst) = sp.h;
+                                *reinterpret_cast<scp::bf16x8*>(dst + g.qk_plane) = sp.m;
+                                *reinterpret_cast<scp::bf16x8*>(dst + 2 * g.qk_plane) = sp.l;
+                            }
+                        }
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();                           // the block is rewritten by the next tile
             }
         }
     }
@@ -288,6 +297,7 @@ __global__ __launch_bounds__(THREADS, 2) void vit_gemm_kernel(const GemmArgs g) 
     using BigCore = std::conditional_t<CORE == 0, scp::GemmCore<BigCfg>, scp::SplitGemmCore<Big>>;
     using QtrCore = std::conditional_t<CORE == 0, scp::GemmCore<QtrCfg>, scp::SplitGemmCore<Qtr>>;
     __shared__ __attribute__((aligned(16))) float lds[Big::LDS_BYTES / 4];
+    static_assert(4 * 32 * 36 * 4 <= Big::LDS_BYTES, "the plane epilogue's four staging blocks (run_tile) fit the big tile's ring");
     // row count: host value, or read from the device (rows selected by an earlier kernel, no host round trip)
     int M = g.M;
     if (g.m_dev) M = min(max(__builtin_amdgcn_readfirstlane(*g.m_dev), 0), g.M);
