@@ -196,9 +196,10 @@ def isolated_gemms(M, C=384, iters=20):
         st = torch.rand(M, 2, device="cuda")
         out = torch.randn(M, N, device="cuda")
         if planes:
-            a_in = None if name == "proj" else dino_mod.split_tiled(a)                     # proj reads the attention's fp32 output
-            o3 = None if name == "qkv" else dino_mod.TiledPlanes(M, N, "cuda")              # qkv feeds the attention in fp32
-            w3 = dino_mod.split_weight(w) if name == "proj" else dino_mod.split_tiled(w)
+            attn_planes = dino_mod.QK_FROM_EPILOGUE and dino_mod.attn_mode() == "split"    # the attention then writes proj's A as planes
+            a_in = None if (name == "proj" and not attn_planes) else dino_mod.split_tiled(a)
+            o3 = None if name == "qkv" else dino_mod.TiledPlanes(M, N, "cuda")              # qkv feeds the attention (planes + fp32 K / V)
+            w3 = dino_mod.split_weight(w) if a_in is None else dino_mod.split_tiled(w)
             qk = None
             if name == "qkv" and dino_mod.QK_FROM_EPILOGUE and dino_mod.attn_mode() == "split" and M % 1025 == 0:
                 # as the block runs it: the epilogue writes the attention's Q / K planes, only the V third leaves as fp32

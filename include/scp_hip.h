@@ -488,7 +488,9 @@ int scp_vit_attention_split_forward(const float* qkv, float* out, int B, int N, 
  * same workspace, same B / N / H / scale): only V^T is re-laid here and the fp32 qkv tensor is read for its V third -- and, when N % 32 is
  * in 1..8 and no query selection is given, for its K third by the leftover-query kernel (keep_fp32_qk bit 1 of scp_vit_linear_qkv); its Q
  * third may be uninitialised.  Exact split only. */
-int scp_vit_attention_split_forward_presplit(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale,
+/* out_planes (or NULL): the result ALSO (or, with out == NULL, ONLY) as the TILED bf16 planes of the [B N][H 64] matrix (see
+ * scp_vit_linear_planes): the pre-split A operand of the proj GEMM, (B N rounded up to 32) x H 64 x 3 elements. */
+int scp_vit_attention_split_forward_presplit(const float* qkv, float* out, void* out_planes, int B, int N, int H, int head_dim, float scale,
                                              const int* q_rows, const int* q_count, void* workspace, size_t workspace_bytes, void* stream);
 /* The qkv projection qkv = LN1(x) Wqkv^T + b (scp_vit_linear / scp_vit_linear_planes with SCP_GEMM_LN | SCP_GEMM_W_SPLIT3; A fp32 or
  * A_planes) whose epilogue ALSO writes the attention's Q / K operand planes into `attn_workspace` (layout of

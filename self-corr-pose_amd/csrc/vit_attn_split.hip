@@ -146,7 +146,8 @@ template <int WAVES, bool EXACT>
 __global__ __launch_bounds__(WAVES * 64, 2) void vit_attention_split_kernel(const __bf16* __restrict__ Qp, const __bf16* __restrict__ Kp,
                                                                          const __bf16* __restrict__ Vt, float* __restrict__ out, int N,
                                                                          int Npad, int H, const int* __restrict__ q_rows,
-                                                                         const int* __restrict__ q_count, int n_main) {
+                                                                         const int* __restrict__ q_count, int n_main,
+                                                                         __bf16* __restrict__ out3) {
     // per buffer: K planes 3 x [32 keys][64 d] bf16 (128 B rows), V^T planes 3 x [64 d][32 keys] bf16 (64 B rows)
     __shared__ __attribute__((aligned(16))) char k_lds[2][3 * 4096];
     __shared__ __attribute__((aligned(16))) char v_lds[2][3 * 4096];
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attention_split_kernel(cons
     const float l_tot = l_run + other_half(l_run);
     const float inv = 1.f / l_tot;
     const int qslot = q0 + l31;
-    if (qslot < n_query) {
+    if (out && qslot < n_query) {
         const int q = q_rows ? q_rows[(size_t)b * N + qslot] : qslot;
         float* op = out + ((size_t)b * N + q) * (H * HD) + (size_t)h * HD;
 #pragma unroll
@@ -380,6 +381,49 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attention_split_kernel(cons
             const int d = acc_row(r, half);
             op[d] = o_lo[r] * inv;
             op[d + 32] = o_hi[r] * inv;
+        }
+    }
+    if (out3) {
+        // the result as the proj GEMM's pre-split A operand (TILED planes [rows / 32][H 64 / 16][3][32][16] bf16 of the [B N][H 64]
+        // matrix, csrc/gemm_core_split.h): the wavefront's O^T block goes through LDS (the K / V buffers are idle: every wavefront
+        // left the tile loop through its closing barrier) and is read back query-row-wise -- 8 consecutive dims per lane, one exact
+        // split, three 16-byte stores.
+        constexpr int OS = 68;                                   // row stride in floats: 16-byte aligned rows, conflict-free b128 writes
+        float* st = reinterpret_cast<float*>(wave < 2 ? k_lds[0] : v_lds[0]) + (wave & 1) * (32 * OS);
+        static_assert(2 * 32 * OS * 4 <= 2 * 3 * 4096, "two staging blocks per buffer pair");
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+            // registers 4 g4 .. 4 g4 + 3 = dims 8 g4 + 4 half + (0..3) of the lane's query
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            const f32x4_t lo = {o_lo[4 * g4] * inv, o_lo[4 * g4 + 1] * inv, o_lo[4 * g4 + 2] * inv, o_lo[4 * g4 + 3] * inv};
+            const f32x4_t hi = {o_hi[4 * g4] * inv, o_hi[4 * g4 + 1] * inv, o_hi[4 * g4 + 2] * inv, o_hi[4 * g4 + 3] * inv};
+            *reinterpret_cast<f32x4_t*>(st + l31 * OS + 8 * g4 + 4 * half) = lo;
+            *reinterpret_cast<f32x4_t*>(st + l31 * OS + 32 + 8 * g4 + 4 * half) = hi;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int ql = lane >> 1, qs = q0 + ql;
+        if (qs < n_query) {
+            const int q = q_rows ? q_rows[(size_t)b * N + qs] : qs;
+            const int row = b * N + q, kch = (H * HD) >> 4;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int d8 = 16 * c + 8 * (lane & 1);
+                typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                const f32x4_t a = *reinterpret_cast<const f32x4_t*>(st + ql * OS + d8), e = *reinterpret_cast<const f32x4_t*>(st + ql * OS + d8 + 4);
+                u32x4 ph, pm, pl;
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const Pair3 s0 = split_pair(a[2 * p], a[2 * p + 1]), s1 = split_pair(e[2 * p], e[2 * p + 1]);
+                    ph[p] = s0.h; pm[p] = s0.m; pl[p] = s0.l;
+                    ph[2 + p] = s1.h; pm[2 + p] = s1.m; pl[2 + p] = s1.l;
+                }
+                const int k = h * HD + d8;
+                __bf16* dst = out3 + ((((size_t)(row >> 5) * kch + (k >> 4)) * 3) << 9) + ((row & 31) << 4) + (k & 15);
+                *reinterpret_cast<u32x4*>(dst) = ph;
+                *reinterpret_cast<u32x4*>(dst + 512) = pm;
+                *reinterpret_cast<u32x4*>(dst + 1024) = pl;
+            }
         }
     }
 }
@@ -481,7 +525,7 @@ __global__ __launch_bounds__(256) void attention_tail_partial_kernel(const float
 }
 
 __global__ __launch_bounds__(HD) void attention_tail_merge_kernel(const float* __restrict__ partial, float* __restrict__ out, int N, int H,
-                                                                  int first_query) {
+                                                                  int first_query, __bf16* __restrict__ out3) {
     const int qi = blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh - b * H, d = threadIdx.x;
     const float* rec = partial + ((size_t)bh * gridDim.x + qi) * TAIL_CHUNKS * TAIL_REC;
     float m = -INFINITY;
@@ -494,7 +538,16 @@ __global__ __launch_bounds__(HD) void attention_tail_merge_kernel(const float* _
         l = fmaf(rec[c * TAIL_REC + 1], w, l);
         o = fmaf(rec[c * TAIL_REC + 2 + d], w, o);
     }
-    out[((size_t)b * N + first_query + qi) * (H * HD) + (size_t)h * HD + d] = o / l;
+    const float y = o / l;
+    if (out) out[((size_t)b * N + first_query + qi) * (H * HD) + (size_t)h * HD + d] = y;
+    if (out3) {                                                   // the same element of the tiled planes (see the main kernel)
+        const int row = b * N + first_query + qi, k = h * HD + d, kch = (H * HD) >> 4;
+        const __bf16 yh = (__bf16)y;
+        const float r1 = y - (float)yh;
+        const __bf16 ym = (__bf16)r1;
+        __bf16* dst = out3 + ((((size_t)(row >> 5) * kch + (k >> 4)) * 3) << 9) + ((row & 31) << 4) + (k & 15);
+        dst[0] = yh; dst[512] = ym; dst[1024] = (__bf16)(r1 - (float)ym);
+    }
 }
 
 }  // namespace
@@ -507,25 +560,28 @@ extern "C" size_t scp_vit_attention_split_workspace(int B, int N, int H) {
 
 namespace {
 int attention_split_impl(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale, const int* q_rows, const int* q_count,
-                         int exact, int presplit_qk, void* workspace, size_t workspace_bytes, void* stream);
+                         int exact, int presplit_qk, void* workspace, size_t workspace_bytes, void* stream, void* out_planes = nullptr);
 }
 extern "C" int scp_vit_attention_split_forward(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale,
                                                const int* q_rows, const int* q_count, int exact, void* workspace,
                                                size_t workspace_bytes, void* stream) {
     return attention_split_impl(qkv, out, B, N, H, head_dim, scale, q_rows, q_count, exact, 0, workspace, workspace_bytes, stream);
 }
-extern "C" int scp_vit_attention_split_forward_presplit(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale,
-                                                        const int* q_rows, const int* q_count, void* workspace, size_t workspace_bytes,
-                                                        void* stream) {
-    return attention_split_impl(qkv, out, B, N, H, head_dim, scale, q_rows, q_count, 1, 1, workspace, workspace_bytes, stream);
+extern "C" int scp_vit_attention_split_forward_presplit(const float* qkv, float* out, void* out_planes, int B, int N, int H, int head_dim,
+                                                        float scale, const int* q_rows, const int* q_count, void* workspace,
+                                                        size_t workspace_bytes, void* stream) {
+    return attention_split_impl(qkv, out, B, N, H, head_dim, scale, q_rows, q_count, 1, 1, workspace, workspace_bytes, stream, out_planes);
 }
 namespace {
 int attention_split_impl(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale, const int* q_rows, const int* q_count,
-                         int exact, int presplit_qk, void* workspace, size_t workspace_bytes, void* stream) {
+                         int exact, int presplit_qk, void* workspace, size_t workspace_bytes, void* stream, void* out_planes) {
     if (B <= 0 || N <= 0 || H <= 0) return scp::fail(hipErrorInvalidValue, "vit_attention_split: empty problem");
     if (head_dim != HD) return scp::fail(hipErrorInvalidValue, "vit_attention_split: head_dim must be 64");
-    if (!qkv || !out || !workspace || (q_rows == nullptr) != (q_count == nullptr))
+    if (!qkv || (!out && !out_planes) || !workspace || (q_rows == nullptr) != (q_count == nullptr))
         return scp::fail(hipErrorInvalidValue, "vit_attention_split: null argument");
+    if (out_planes && (!exact || (size_t)3 * (((size_t)B * N + 31) / 32 * 32) * H * HD >= (1ull << 31)))
+        return scp::fail(hipErrorInvalidValue, "vit_attention_split: output planes need the exact split and < 2^31 elements");
+    __bf16* out3 = static_cast<__bf16*>(out_planes);
     if (workspace_bytes < scp_vit_attention_split_workspace(B, N, H))
         return scp::fail(hipErrorInvalidValue, "vit_attention_split: workspace too small");
     const int npad = ((N + KT - 1) / KT) * KT;
@@ -549,13 +605,13 @@ int attention_split_impl(const float* qkv, float* out, int B, int N, int H, int 
     const dim3 grid((qtiles + 3) / 4, B * H);
     // n_query of the main kernel: with the tail split off only the full tiles' queries
     const int n_main = split_tail ? N - tail : N;
-    if (exact) hipLaunchKernelGGL((vit_attention_split_kernel<4, true>), grid, dim3(256), 0, st, Qp, Kp, Vt, out, N, npad, H, q_rows, q_count, n_main);
-    else hipLaunchKernelGGL((vit_attention_split_kernel<4, false>), grid, dim3(256), 0, st, Qp, Kp, Vt, out, N, npad, H, q_rows, q_count, n_main);
+    if (exact) hipLaunchKernelGGL((vit_attention_split_kernel<4, true>), grid, dim3(256), 0, st, Qp, Kp, Vt, out, N, npad, H, q_rows, q_count, n_main, out3);
+    else hipLaunchKernelGGL((vit_attention_split_kernel<4, false>), grid, dim3(256), 0, st, Qp, Kp, Vt, out, N, npad, H, q_rows, q_count, n_main, out3);
     if (split_tail) {
         float* partial = reinterpret_cast<float*>(Vt + plane3);
         hipLaunchKernelGGL(attention_tail_partial_kernel, dim3(TAIL_CHUNKS, tail, B * H), dim3(256), 0, st, qkv, partial, N, H, sl, N - tail,
                            chunk_keys, presplit_qk ? Qp : nullptr, Kp, plane3 / 3, npad);
-        hipLaunchKernelGGL(attention_tail_merge_kernel, dim3(tail, B * H), dim3(HD), 0, st, partial, out, N, H, N - tail);
+        hipLaunchKernelGGL(attention_tail_merge_kernel, dim3(tail, B * H), dim3(HD), 0, st, partial, out, N, H, N - tail, out3);
     }
     return scp::check_launch("vit_attention_split");
 }

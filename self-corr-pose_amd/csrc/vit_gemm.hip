@@ -202,7 +202,7 @@ __device__ __forceinline__ void run_tile(const GemmArgs& g, float* lds, int M, i
             // of one row -- one split3, three 16-byte stores per 8 values (a KiB per store instruction in the tiled layout), and the fp32
             // copy leaves as float4 rows.  Round 4, second half: the column-per-lane form of this epilogue (pairs exchanged with the
             // neighbouring lane by DPP, 24 dword stores + ~350 VALU per 32 x 32 tile) cost 25 % of the proj GEMM and ~20 % of a block.
-            const bool staged = g.C3 != nullptr || which < 2;
+            const bool staged = g.C3 != nullptr || which < 3;          // which < 3: every tile of a qkv projection with attention planes
             float* st = stage + core.wave * STAGE_WORDS;
 #pragma unroll
             for (int r = 0; r < 16; r++) {

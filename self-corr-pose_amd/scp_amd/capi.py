@@ -127,7 +127,7 @@ SYMBOLS = {
     "scp_texture_loss_forward": (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "scp_texture_loss_backward": (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "scp_vit_attention_split_workspace": (ctypes.c_size_t, [_I, _I, _I]),
-    "scp_vit_attention_split_forward_presplit": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P, ctypes.c_size_t, _P]),
+    "scp_vit_attention_split_forward_presplit": (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, ctypes.c_size_t, _P]),
     "scp_vit_linear_qkv": (ctypes.c_int, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _F, _I, _P]),
     "scp_vit_attention_split_forward": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, ctypes.c_size_t, _P]),
     "scp_dual_softmax_backward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _F,

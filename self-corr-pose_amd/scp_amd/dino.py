@@ -106,18 +106,26 @@ def attention_workspace(b, n, heads, device):
     return torch.empty(capi.lib().scp_vit_attention_split_workspace(b, n, heads), dtype=torch.uint8, device=device)
 
 
-def fused_attention(qkv, b, n, heads, head_dim, scale, q_rows=None, q_count=None, mode=None, presplit=None):
+def fused_attention(qkv, b, n, heads, head_dim, scale, q_rows=None, q_count=None, mode=None, presplit=None, out_planes=None):
     """HIP flash-style attention on the matrix cores (csrc/vit_attn_split.hip / csrc/vit_attn.hip, see ATTN_MODE): qkv
     [b,n,3*heads*head_dim] as produced by the qkv Linear -> [b, n, heads*head_dim].  Forward only (the DINO ViT is frozen and
     always evaluated under no_grad); GPU tensors only, no CPU fallback.
     Query selection (scp_vit_attention_forward_rows): q_rows [b,n] int32 = token index of query slot j per image, q_count [b]
     int32 = number of slots; only those tokens' outputs are produced (at their own rows; the other rows stay uninitialised),
-    keys and values are always all n tokens."""
+    keys and values are always all n tokens.
+    `presplit` (split mode): attention_workspace(...) into which the qkv projection already wrote the Q / K planes.  `out_planes` (with
+    presplit): TiledPlanes [b*n, heads*head_dim] that receive the result as the proj GEMM's pre-split A operand; the fp32 result is then
+    not produced at all and the planes are returned."""
     from . import capi
     if torch.is_grad_enabled() and qkv.requires_grad:
         raise RuntimeError("scp_amd.dino.fused_attention is forward-only (frozen ViT)")
     qkv = qkv.contiguous()
-    out = torch.empty(b, n, heads * head_dim, dtype=torch.float32, device=qkv.device)
+    if out_planes is not None:
+        if presplit is None or not (isinstance(out_planes, TiledPlanes) and (out_planes.rows, out_planes.cols) == (b * n, heads * head_dim)):
+            raise RuntimeError("fused_attention: out_planes must be TiledPlanes [b*n, heads*head_dim] and goes with presplit")
+        out = None
+    else:
+        out = torch.empty(b, n, heads * head_dim, dtype=torch.float32, device=qkv.device)
     mode = attn_mode() if mode is None else mode
     if mode not in ("split", "fp32", "bf16"):
         raise RuntimeError("fused_attention: unknown mode %r" % (mode,))
@@ -135,11 +143,12 @@ def fused_attention(qkv, b, n, heads, head_dim, scale, q_rows=None, q_count=None
             # Q / K planes already in the workspace (written by the qkv GEMM's epilogue); the kernel re-lays V only
             if not (presplit.is_cuda and presplit.dtype == torch.uint8 and presplit.numel() >= ws_bytes):
                 raise RuntimeError("fused_attention: presplit must be attention_workspace(b, n, heads, device)")
-            capi.check(L.scp_vit_attention_split_forward_presplit(capi.dev_ptr(qkv, "qkv"), capi.dev_ptr(out, "out"), b, n, heads, head_dim,
-                                                                  float(scale), ip(q_rows), ip(q_count), ctypes.c_void_p(presplit.data_ptr()),
-                                                                  presplit.numel(), capi.current_stream()),
+            capi.check(L.scp_vit_attention_split_forward_presplit(capi.dev_ptr(qkv, "qkv"), ip(out),
+                                                                  ctypes.c_void_p(0 if out_planes is None else out_planes.blob.data_ptr()),
+                                                                  b, n, heads, head_dim, float(scale), ip(q_rows), ip(q_count),
+                                                                  ctypes.c_void_p(presplit.data_ptr()), presplit.numel(), capi.current_stream()),
                        "scp_vit_attention_split_forward_presplit")
-            return out
+            return out if out_planes is None else out_planes
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device)
         capi.check(L.scp_vit_attention_split_forward(capi.dev_ptr(qkv, "qkv"), capi.dev_ptr(out, "out"), b, n, heads, head_dim,
                                                      float(scale), ip(q_rows), ip(q_count), int(mode == "split"),
@@ -407,7 +416,7 @@ class _Block(nn.Module):
                                         proj=split_weight(self.attn.proj.weight), fc2=split_weight(self.mlp.fc2.weight))
                     if PRESPLIT_ACTIVATIONS:     # tiled planes: the W operand of the layers whose A operand arrives pre-split
                         self._planes.update(qkv_t=split_tiled(wq), k_t=split_tiled(wq[c:2 * c].contiguous()), fc1_t=split_tiled(w1),
-                                            fc2_t=split_tiled(self.mlp.fc2.weight))
+                                            fc2_t=split_tiled(self.mlp.fc2.weight), proj_t=split_tiled(self.attn.proj.weight))
                 elif gemm_mode() == "bf16" and wq.is_cuda:
                     rnd = lambda t: t.detach().to(torch.bfloat16).contiguous()
                     self._planes = dict(qkv=rnd(wq), k=rnd(wq[c:2 * c]), fc1=rnd(w1), proj=rnd(self.attn.proj.weight),
@@ -432,9 +441,16 @@ class _Block(nn.Module):
         ws = attention_workspace(b, n, a.num_heads, x2d.device) if (pl and attn_mode() == "split" and QK_FROM_EPILOGUE) else None
         qkv = vit_linear(x2d, wq, sq, tq, row_mean_rstd(x2d, self.norm1.eps), epilogue=GEMM_LN, w_split=sp["qkv_t" if pl else "qkv"],
                          a_planes=x3 if pl else None, qk_planes=None if ws is None else (ws, n, a.num_heads, a.scale))
-        y = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, x2d.shape[1] // a.num_heads, a.scale, presplit=ws)
-        vit_linear(y.view(b * n, -1), a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["proj"],
-                   out_planes=x3 if pl else None)
+        if ws is not None:
+            # the attention writes its result as the proj GEMM's pre-split A operand (no fp32 copy at all)
+            y3 = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, x2d.shape[1] // a.num_heads, a.scale, presplit=ws,
+                                 out_planes=TiledPlanes(b * n, x2d.shape[1], x2d.device))
+            vit_linear(None, a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["proj_t"], a_planes=y3,
+                       out_planes=x3)
+        else:
+            y = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, x2d.shape[1] // a.num_heads, a.scale)
+            vit_linear(y.view(b * n, -1), a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["proj"],
+                       out_planes=x3 if pl else None)
         if pl:
             h3 = TiledPlanes(b * n, w1.shape[0], x2d.device)
             vit_linear(None, w1, s1, t1, row_mean_rstd(x2d, self.norm2.eps), epilogue=GEMM_LN_GELU, w_split=sp["fc1_t"], a_planes=x3,
@@ -468,7 +484,12 @@ class _Block(nn.Module):
         k8 = keep.to(torch.uint8)
         q_rows = torch.argsort(k8, dim=1, descending=True, stable=True).to(torch.int32)
         q_count = keep.sum(1, dtype=torch.int32)
-        y = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, c // a.num_heads, a.scale, q_rows, q_count, presplit=ws).view(b * n, c)
+        y3 = None
+        if ws is not None:
+            y3 = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, c // a.num_heads, a.scale, q_rows, q_count, presplit=ws,
+                                 out_planes=TiledPlanes(b * n, c, x2d.device))
+        else:
+            y = fused_attention(qkv.view(b, n, -1), b, n, a.num_heads, c // a.num_heads, a.scale, q_rows, q_count).view(b * n, c)
         flat = keep.reshape(-1)
         idx = torch.argsort(flat.to(torch.uint8), descending=True, stable=True).to(torch.int32)   # kept rows first, original order
         rows = flat.sum(dtype=torch.int32).reshape(1)
@@ -476,8 +497,12 @@ class _Block(nn.Module):
         sel = dict(rows=rows, max_rows=m, a_rows=idx, c_rows=idx)
         # x[idx] += proj(y[idx]);  h = gelu(fc1(LN2 x[idx]));  x[idx] += fc2(h);  k[idx] = Wk LN1(x[idx]) -- rows addressed
         # through the index list inside the GEMM (no gather / scatter copies); statistics are taken for all rows (11 us)
-        vit_linear(y, a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["proj"],
-                   out_planes=x3 if pl else None, **sel)
+        if y3 is not None:
+            vit_linear(None, a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["proj_t"], a_planes=y3,
+                       out_planes=x3, **sel)
+        else:
+            vit_linear(y, a.proj.weight, a.proj.bias, resid=x2d, out=x2d, epilogue=GEMM_BIAS_RESIDUAL, w_split=sp["proj"],
+                       out_planes=x3 if pl else None, **sel)
         (kq, ks, kt), _ = key_block._folded()
         k = torch.zeros(m, c, dtype=torch.float32, device=x2d.device)
         if pl:

@@ -341,12 +341,21 @@ def test_qkv_epilogue_planes_give_the_same_attention_bit_for_bit(B, N):
             assert bool(torch.isnan(got[:, :C]).all())                           # the Q third was not stored
         y = dino.fused_attention(got.view(B, N, -1), B, N, H, 64, scale, mode="split", presplit=ws)
         assert torch.equal(y, ref)
+        # ... and as the proj GEMM's pre-split A operand: tiled planes whose three terms add up to the fp32 result exactly
+        y3 = dino.TiledPlanes(B * N, C, "cuda")
+        y3.blob.fill_(float("nan"))
+        r3 = dino.fused_attention(got.view(B, N, -1), B, N, H, 64, scale, mode="split", presplit=ws, out_planes=y3)
+        assert r3 is y3 and torch.equal(y3.untile().float().double().sum(0), ref.view(B * N, C).double())
+        assert torch.equal(y3.untile(), dino.split_weight(ref.view(B * N, C)))
         ws2 = dino.attention_workspace(B, N, H, "cuda")
         ws2.fill_(0xFF)
         got2 = dino.vit_linear(a, w, v0, w_split=ws_, a_planes=a3, qk_planes=(ws2, N, H, scale), **kw)
         y2 = dino.fused_attention(got2.view(B, N, -1), B, N, H, 64, scale, q_rows, q_count, mode="split", presplit=ws2)
         sel = keep.cuda()
         assert torch.equal(y2[sel], ref_rows[sel])
+        y3 = dino.TiledPlanes(B * N, C, "cuda")
+        dino.fused_attention(got2.view(B, N, -1), B, N, H, 64, scale, q_rows, q_count, mode="split", presplit=ws2, out_planes=y3)
+        assert torch.equal(y3.untile().float().double().sum(0).view(B, N, C)[sel], ref_rows[sel].double())
 
 
 @pytest.mark.gpu
