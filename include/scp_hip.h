@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SCP_ABI_VERSION 2
+#define SCP_ABI_VERSION 3
 
 /* enum values = the integer ids the reference passes (functional/soft_rasterize.py:22-25) */
 enum { SCP_DIST_HARD = 0, SCP_DIST_BARYCENTRIC = 1, SCP_DIST_EUCLIDEAN = 2 };
@@ -128,6 +128,22 @@ int scp_fvm_backward(const float* img_feat, const float* mesh_feat, const float*
                      const float* match, const float* imatch, const float* rowstat, const float* colstat,
                      const float* g_match, const float* g_imatch, const float* g_pooled, float* g_img_feat,
                      float* g_mesh_feat, void* stream);
+
+/* ---- pixel <-> pixel soft-argmax of the rotation-cycle loss without the score tensor (csrc/corr_pp.hip) --------------------
+ * Replaces model/module/correspondence.py:105-110 (pc = src_feat^T @ tgt_feat [N,P,Q], masked to -1e5 where the source or the
+ * target pixel is background, softmax over the source pixels, cycle_match = grid @ softmax) and its backward; the reference
+ * materialises pc (134 MB at N = 32, P = Q = 1024).  Restrictions: C = 64, P and Q multiples of 32.
+ *   src_feat [N,64,P], tgt_feat [N,64,Q], src_mask [N,P] / tgt_mask [N,Q] (> 0 = foreground; NULL = all), grid [2,P] or,
+ *   with grid_batched != 0, [N,2,P]
+ *   forward  -> out [N,2,Q], colstats [N,2,Q] (max of tau * score over P, sum of exp; for the backward)
+ *   backward -> g_src_feat [N,64,P], g_tgt_feat [N,64,Q] (each may be NULL = not needed) from g_out [N,2,Q]; scores are recomputed
+ *               on the matrix cores. */
+int scp_pp_softargmax_forward(const float* src_feat, const float* tgt_feat, const float* src_mask, const float* tgt_mask,
+                              const float* grid, int grid_batched, float tau, int N, int C, int P, int Q, float* out,
+                              float* colstats, void* stream);
+int scp_pp_softargmax_backward(const float* src_feat, const float* tgt_feat, const float* src_mask, const float* tgt_mask,
+                               const float* grid, int grid_batched, float tau, int N, int C, int P, int Q, const float* out,
+                               const float* colstats, const float* g_out, float* g_src_feat, float* g_tgt_feat, void* stream);
 
 /* ---- DINO ViT-S/8 linear layers on the fp32 matrix cores, LayerNorm / bias / GELU / residual fused (csrc/vit_gemm.hip) ----
  * Replaces the nn.Linear calls of third-party/zsp/zsp/method/vision_transformer_flexible.py:54-70 (Mlp: fc1, GELU, fc2),

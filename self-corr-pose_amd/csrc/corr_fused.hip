@@ -144,30 +144,59 @@ __device__ __forceinline__ void load_pixel_operand(const FvmArgs& a, int b, int 
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
+// both orientations of one 32 x 32 score tile from the same operands: accT[r] = S[v = acc_row(r, half)][p = l31] (lane = pixel) and
+// accP[r] = S[p = acc_row(r, half)][v = l31] (lane = vertex).  A and B operands of v_mfma_f32_32x32x2_f32 share one register
+// layout (lane (l31, half) holds row / column l31 at k = half), so the second product is the first with its operands swapped:
+// no second load, and each orientation makes one of the two softmaxes lane local.
+__device__ __forceinline__ void score_tile_both(const float* mt, const float* breg, int l31, int half, f32x16& accT, f32x16& accP) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) { accT[r] = 0.f; accP[r] = 0.f; }
+    const float* mrow = mt + l31 * MROW + 4 * half;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const float4 m = *reinterpret_cast<const float4*>(mrow + 8 * t);
+        accT = __builtin_amdgcn_mfma_f32_32x32x2f32(m.x, breg[4 * t + 0], accT, 0, 0, 0);
+        accP = __builtin_amdgcn_mfma_f32_32x32x2f32(breg[4 * t + 0], m.x, accP, 0, 0, 0);
+        accT = __builtin_amdgcn_mfma_f32_32x32x2f32(m.y, breg[4 * t + 1], accT, 0, 0, 0);
+        accP = __builtin_amdgcn_mfma_f32_32x32x2f32(breg[4 * t + 1], m.y, accP, 0, 0, 0);
+        accT = __builtin_amdgcn_mfma_f32_32x32x2f32(m.z, breg[4 * t + 2], accT, 0, 0, 0);
+        accP = __builtin_amdgcn_mfma_f32_32x32x2f32(breg[4 * t + 2], m.z, accP, 0, 0, 0);
+        accT = __builtin_amdgcn_mfma_f32_32x32x2f32(m.w, breg[4 * t + 3], accT, 0, 0, 0);
+        accP = __builtin_amdgcn_mfma_f32_32x32x2f32(breg[4 * t + 3], m.w, accP, 0, 0, 0);
+    }
+}
+
 __global__ __launch_bounds__(256) void fvm_forward_kernel(const FvmArgs a) {
     __shared__ __attribute__((aligned(16))) float mt[2][32 * MROW];
     __shared__ __attribute__((aligned(16))) float vt[2][32 * 4];
     __shared__ __attribute__((aligned(16))) float colred[2][4][32][4];
+    __shared__ __attribute__((aligned(8))) float pixgrid[4][32][2];          // per wavefront pixel: grid x, y
 
     const int blk = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int p = strip_pixel(blk, wave, l31);
     const bool masked = !(a.mask[(size_t)b * a.P + p] > 0.f);
-    const float gx = a.grid[p], gy = a.grid[a.P + p];
     float breg[32];
     load_pixel_operand(a, b, p, half, breg);
+    if (half == 0) *reinterpret_cast<float2*>(&pixgrid[wave][l31][0]) = make_float2(a.grid[p], a.grid[a.P + p]);
+    // pixels of the lane = vertex orientation: register r <-> the wavefront's pixel acc_row(r, half); their mask bits
+    const unsigned long long mball = __ballot(masked && half == 0);          // bit l31 = pixel l31 of this wavefront is masked
+    unsigned mbits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) mbits |= (unsigned)((mball >> acc_row(r, half)) & 1ull) << r;
 
     float m_run = -INFINITY, l_run = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;     // row softmax over vertices (this half's share)
-    const int p2 = blk * (WF / 2) + 8 * wave + (l31 >> 2);                   // pooled pixel of the lane's 2x2 cell
-    float* pooled_row = a.pooled + ((size_t)b * (a.P / 4) + p2) * a.V;
+    // pooled cells of the lane = vertex orientation: registers 4j..4j+3 are the 2x2 cell 2j + half of the wavefront
+    float* pooled_col = a.pooled + ((size_t)b * (a.P / 4) + blk * (WF / 2) + 8 * wave + half) * a.V + l31;
 
     stage_vertex_tile(a, b, 0, mt[0], vt[0]);
     __syncthreads();
     for (int tv = 0; tv < a.ntile; tv++) {
         const int buf = tv & 1, v0 = 32 * tv;
         if (tv + 1 < a.ntile) stage_vertex_tile(a, b, v0 + 32, mt[buf ^ 1], vt[buf ^ 1]);
-        f32x16 acc = score_tile(mt[buf], breg, l31, half);
-        // ---- row softmax (lane local): running max / sum / weighted vertex sum over this half's 16 vertices of the tile
+        f32x16 acc, accP;
+        score_tile_both(mt[buf], breg, l31, half, acc, accP);
+        // ---- row softmax (lane = pixel, lane local): running max / sum / weighted vertex sum over this half's 16 vertices
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -191,33 +220,43 @@ __global__ __launch_bounds__(256) void fvm_forward_kernel(const FvmArgs a) {
                 a0 += e * vv.x; a1 += e * vv.y; a2 += e * vv.z;
             }
         }
-        // ---- column statistics over the wavefront's 32 pixels, one vertex (register) at a time; 2x2 pooling
+        // ---- column statistics (lane = vertex v0 + l31, lane local over the wavefront's 32 pixels = 16 registers x 2 halves)
+        //      and the 2x2 pooling (four consecutive registers)
+        float cm = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int vr = acc_row(r, half);
-            const float xs = a.tau_mesh * acc[r];
-            const float cm = max32(xs);
-            const float e = __expf(xs - cm);
-            const float se = sum32(e), sx = sum32(e * gx), sy = sum32(e * gy);
-            if (l31 == 0) *reinterpret_cast<float4*>(&colred[buf][wave][vr][0]) = make_float4(cm, se, sx, sy);
-            float q = acc[r];
-            q += dpp_get<DPP_XOR1>(q);
-            q += dpp_get<DPP_XOR2>(q);
-            if ((l31 & 3) == 0 && v0 + vr < a.V) pooled_row[v0 + vr] = 0.25f * q;
+            const float s = ((mbits >> r) & 1u) ? MASKED_SCORE : accP[r];
+            accP[r] = s;
+            cm = fmaxf(cm, a.tau_mesh * s);
+        }
+        cm = fmaxf(cm, other_half(cm));
+        float se = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float2 gxy = *reinterpret_cast<const float2*>(&pixgrid[wave][acc_row(r, half)][0]);
+            const float e = __expf(a.tau_mesh * accP[r] - cm);
+            se += e; sx += e * gxy.x; sy += e * gxy.y;
+        }
+        se += other_half(se); sx += other_half(sx); sy += other_half(sy);
+        if (half == 0) *reinterpret_cast<float4*>(&colred[buf][wave][l31][0]) = make_float4(cm, se, sx, sy);
+        if (v0 + l31 < a.V) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                pooled_col[(size_t)(2 * j) * a.V + v0] = 0.25f * ((accP[4 * j] + accP[4 * j + 1]) + (accP[4 * j + 2] + accP[4 * j + 3]));
         }
         __syncthreads();      // colred[buf] complete; next tile staged; everyone done reading mt[buf]
         if (tid < 32 && v0 + tid < a.V) {        // merge the four wavefronts' partials of vertex tid (fixed order)
             float M = -INFINITY;
 #pragma unroll
             for (int w = 0; w < 4; w++) M = fmaxf(M, colred[buf][w][tid][0]);
-            float se = 0.f, sx = 0.f, sy = 0.f;
+            float se4 = 0.f, sx4 = 0.f, sy4 = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 const float4 c4 = *reinterpret_cast<const float4*>(&colred[buf][w][tid][0]);
                 const float sc = __expf(c4.x - M);
-                se += c4.y * sc; sx += c4.z * sc; sy += c4.w * sc;
+                se4 += c4.y * sc; sx4 += c4.z * sc; sy4 += c4.w * sc;
             }
-            *reinterpret_cast<float4*>(a.colpart + (((size_t)b * a.nblk + blk) * a.V + v0 + tid) * 4) = make_float4(M, se, sx, sy);
+            *reinterpret_cast<float4*>(a.colpart + (((size_t)b * a.nblk + blk) * a.V + v0 + tid) * 4) = make_float4(M, se4, sx4, sy4);
         }
     }
     // ---- merge the two halves (disjoint vertex sets of the same pixel) and write match + row statistics
@@ -259,10 +298,20 @@ __global__ void fvm_col_merge_kernel(const float* __restrict__ colpart, int B, i
 // ------------------------------------------------------------------------------------------------------------------
 // backward A: lane = pixel, contraction over vertices -> g_img[B,64,P]
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fvm_backward_img_kernel(const FvmArgs a) {
+#ifndef FVM_IMG_WAVES
+#define FVM_IMG_WAVES 2
+#endif
+#ifndef FVM_MESH_WAVES
+#define FVM_MESH_WAVES 3
+#endif
+constexpr int GPROW = 40;    // LDS row stride of a wavefront's [8 pool cells][32 vertices] gradient tile: the b128 reads of the 8 cells x 2
+                             // halves fall on 16 distinct 4-bank groups
+
+__global__ __launch_bounds__(256, FVM_IMG_WAVES) void fvm_backward_img_kernel(const FvmArgs a) {
     __shared__ __attribute__((aligned(16))) float mt[2][32 * MROW];
     __shared__ __attribute__((aligned(16))) float vt[2][32 * 4];
     __shared__ __attribute__((aligned(16))) float ct[2][32 * 8];     // per vertex: cmax, 1/csum, gi0, gi1, d_c
+    __shared__ __attribute__((aligned(16))) float gpt[2][4][8 * GPROW];   // per wavefront: g_pooled of its 8 pool cells x the tile's vertices
 
     const int blk = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -279,8 +328,25 @@ __global__ __launch_bounds__(256) void fvm_backward_img_kernel(const FvmArgs a) 
         gm0 = gp[0]; gm1 = gp[1]; gm2 = gp[2];
         d_r = gm0 * mp[0] + gm1 * mp[1] + gm2 * mp[2];
     }
-    const int p2 = blk * (WF / 2) + 8 * wave + (l31 >> 2);
-    const float* gpool_row = a.g_pooled ? a.g_pooled + ((size_t)b * (a.P / 4) + p2) * a.V : nullptr;
+    // g_pooled[cell][v]: a lane needs the row of its pixel's 2x2 cell at the tile's vertices -- 16 scattered dwords per tile if read
+    // directly (16 cache lines per instruction).  Instead the wavefront loads its 8 cells x 32 vertices with 4 coalesced dword loads
+    // (element e = lane + 64 i: cell e >> 5, vertex e & 31), one tile ahead, and hands them over through LDS.
+    const bool with_pool = a.g_pooled != nullptr;
+    const float* gpool_wave = with_pool ? a.g_pooled + ((size_t)b * (a.P / 4) + blk * (WF / 2) + 8 * wave) * a.V : nullptr;
+    auto load_gpool = [&](int v0, float* q) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int e = lane + 64 * i, vv = v0 + (e & 31);
+            q[i] = (with_pool && vv < a.V) ? gpool_wave[(size_t)(e >> 5) * a.V + vv] : 0.f;
+        }
+    };
+    auto store_gpool = [&](const float* q, float* dst) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int e = lane + 64 * i;
+            dst[(e >> 5) * GPROW + (e & 31)] = q[i];
+        }
+    };
 
     auto stage_cols = [&](int v0, float* dst) {
         if (tid < 32) {
@@ -308,31 +374,46 @@ __global__ __launch_bounds__(256) void fvm_backward_img_kernel(const FvmArgs a) 
 
     stage_vertex_tile(a, b, 0, mt[0], vt[0]);
     stage_cols(0, ct[0]);
+    {
+        float q[4];
+        load_gpool(0, q);
+        store_gpool(q, gpt[0][wave]);
+    }
     __syncthreads();
     for (int tv = 0; tv < a.ntile; tv++) {
         const int buf = tv & 1, v0 = 32 * tv;
+        float gq[4];
         if (tv + 1 < a.ntile) {
+            load_gpool(v0 + 32, gq);
             stage_vertex_tile(a, b, v0 + 32, mt[buf ^ 1], vt[buf ^ 1]);
             stage_cols(v0 + 32, ct[buf ^ 1]);
         }
         f32x16 acc = score_tile(mt[buf], breg, l31, half);
         // ---- d S for the lane's pixel and the tile's vertices (zero on masked pixels and padding vertices)
+        const float* gprow = gpt[buf][wave] + (l31 >> 2) * GPROW + 4 * half;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int vr = acc_row(r, half);
-            float ds = 0.f;
-            if (!masked && v0 + vr < a.V) {
-                const float s = acc[r];
-                const float4 vv = *reinterpret_cast<const float4*>(vt[buf] + 4 * vr);
-                const float4 c0 = *reinterpret_cast<const float4*>(ct[buf] + 8 * vr);
-                const float dc = ct[buf][8 * vr + 4];
-                const float pr = __expf(a.tau_img * s - rmax) * rinv;
-                const float pc = __expf(a.tau_mesh * s - c0.x) * c0.y;
-                ds = a.tau_img * pr * (gm0 * vv.x + gm1 * vv.y + gm2 * vv.z - d_r) + a.tau_mesh * pc * (c0.z * gx + c0.w * gy - dc);
-                if (gpool_row) ds += 0.25f * gpool_row[v0 + vr];
+        for (int j = 0; j < 4; j++) {
+            const float4 gp4 = *reinterpret_cast<const float4*>(gprow + 8 * j);       // vertices acc_row(4j .. 4j+3, half)
+            const float gpv[4] = {gp4.x, gp4.y, gp4.z, gp4.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = 4 * j + i;
+                const int vr = acc_row(r, half);
+                float ds = 0.f;
+                if (!masked && v0 + vr < a.V) {
+                    const float s = acc[r];
+                    const float4 vv = *reinterpret_cast<const float4*>(vt[buf] + 4 * vr);
+                    const float4 c0 = *reinterpret_cast<const float4*>(ct[buf] + 8 * vr);
+                    const float dc = ct[buf][8 * vr + 4];
+                    const float pr = __expf(a.tau_img * s - rmax) * rinv;
+                    const float pc = __expf(a.tau_mesh * s - c0.x) * c0.y;
+                    ds = a.tau_img * pr * (gm0 * vv.x + gm1 * vv.y + gm2 * vv.z - d_r) + a.tau_mesh * pc * (c0.z * gx + c0.w * gy - dc);
+                    if (with_pool) ds += 0.25f * gpv[i];
+                }
+                acc[r] = ds;
             }
-            acc[r] = ds;
         }
+        if (tv + 1 < a.ntile) store_gpool(gq, gpt[buf ^ 1][wave]);
         // ---- g_img[c][p] += sum_v mesh[v][c] dS[v][p]: dS registers are the B operand; k-step r pairs the vertices
         //      acc_row(r, 0) and acc_row(r, 1), the A operand is mesh[acc_row(r, half)][c = l31 (+32)]
 #pragma unroll
@@ -357,10 +438,11 @@ __global__ __launch_bounds__(256) void fvm_backward_img_kernel(const FvmArgs a) 
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int IROW = 33;     // LDS row stride of an [64 channels][32 pixels] tile: conflict-free along channels and along pixels
 
-__global__ __launch_bounds__(256) void fvm_backward_mesh_kernel(const FvmArgs a) {
-    __shared__ __attribute__((aligned(16))) float it[4][C * IROW];      // per wavefront: image tile
+__global__ __launch_bounds__(256, FVM_MESH_WAVES) void fvm_backward_mesh_kernel(const FvmArgs a) {
+    static_assert(C * IROW >= 32 * 65, "the final cross-wavefront sum reuses the image tiles");
+    __shared__ __attribute__((aligned(16))) float it[4][C * IROW];      // per wavefront: image tile; at the end: the wavefront's partial sums
     __shared__ __attribute__((aligned(16))) float pt[4][32 * 12];       // per wavefront, per pixel: rmax, 1/rsum, gm0..2, d_r, gx, gy, live, p2
-    __shared__ __attribute__((aligned(16))) float red[4][32 * 65];      // final cross-wavefront sum
+    float (*red)[C * IROW] = it;
 
     const int tv = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -458,6 +540,7 @@ __global__ __launch_bounds__(256) void fvm_backward_mesh_kernel(const FvmArgs a)
         __builtin_amdgcn_wave_barrier();
     }
     // ---- sum the four wavefronts (fixed order) and store g_mesh[b][v][c]; lane holds [c = acc_row(r,half) (+32)][v = l31]
+    //      (red[wave] is the wavefront's own image tile, which only it reads: no barrier needed before overwriting it)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         red[wave][l31 * 65 + acc_row(r, half)] = g_lo[r];

@@ -12,7 +12,7 @@ import torch
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # SCP_HIP_LIB: an alternative build of the same library (A/B of kernel variants from tools/); the default is the in-tree build
 LIB_PATH = os.environ.get("SCP_HIP_LIB") or os.path.join(_PKG, "lib", "libscp_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class RasterParams(ctypes.Structure):
@@ -58,6 +58,8 @@ SYMBOLS = {
     "scp_fvm_workspace": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "scp_fvm_forward": (ctypes.c_int, [_P] * 5 + [ctypes.c_float] * 2 + [ctypes.c_int] * 5 + [_P] * 6 + [ctypes.c_size_t, _P]),
     "scp_fvm_backward": (ctypes.c_int, [_P] * 5 + [ctypes.c_float] * 2 + [ctypes.c_int] * 5 + [_P] * 10),
+    "scp_pp_softargmax_forward": (ctypes.c_int, [_P] * 5 + [_I, _F] + [_I] * 4 + [_P] * 3),
+    "scp_pp_softargmax_backward": (ctypes.c_int, [_P] * 5 + [_I, _F] + [_I] * 4 + [_P] * 6),
     "scp_kernel_clock_begin": (ctypes.c_int, [_P, _I]),
     "scp_kernel_clock_end": (ctypes.c_int, []),
     "scp_split_bf16x3": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P]),

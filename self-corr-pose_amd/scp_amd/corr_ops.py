@@ -210,6 +210,50 @@ class FeatureVertexMatchFused(Function):
         return g_img, g_mesh, None, None, None, None, None, None, None
 
 
+def pp_fusable(src_feat, tgt_feat):
+    """the fused pixel <-> pixel kernels (csrc/corr_pp.hip): 64 channels, pixel counts that are multiples of 32"""
+    return (src_feat.is_cuda and src_feat.dim() == 3 and tgt_feat.dim() == 3 and src_feat.shape[1] == 64 and tgt_feat.shape[1] == 64
+            and src_feat.shape[2] % 32 == 0 and tgt_feat.shape[2] % 32 == 0)
+
+
+class PixelPixelSoftArgmax(Function):
+    """out [N,2,Q] = grid @ softmax_P(tau * masked(src^T tgt)) (correspondence.py:105-110); the [N,P,Q] scores live in registers"""
+
+    @staticmethod
+    def forward(ctx, src_feat, tgt_feat, src_mask, tgt_mask, grid, tau):
+        src_feat, tgt_feat = src_feat.contiguous().float(), tgt_feat.contiguous().float()
+        src_mask, tgt_mask, grid = _c(src_mask), _c(tgt_mask), _c(grid)
+        n, c, p = src_feat.shape
+        q = tgt_feat.shape[2]
+        batched = 1 if grid.dim() == 3 else 0
+        if grid.shape[-2:] != (2, p) or (batched and grid.shape[0] != n):
+            raise RuntimeError("pixel_pixel_softargmax: grid must be [2,%d] or [%d,2,%d]" % (p, n, p))
+        out = torch.empty(n, 2, q, dtype=torch.float32, device=src_feat.device)
+        stats = torch.empty(n, 2, q, dtype=torch.float32, device=src_feat.device)
+        capi.check(capi.lib().scp_pp_softargmax_forward(
+            capi.dev_ptr(src_feat, "src_feat"), capi.dev_ptr(tgt_feat, "tgt_feat"), capi.opt_ptr(src_mask, "src_mask"),
+            capi.opt_ptr(tgt_mask, "tgt_mask"), capi.dev_ptr(grid, "grid"), batched, float(tau), n, c, p, q,
+            capi.dev_ptr(out, "out"), capi.dev_ptr(stats, "stats"), capi.current_stream()), "scp_pp_softargmax_forward")
+        ctx.save_for_backward(src_feat, tgt_feat, src_mask, tgt_mask, grid, out, stats)
+        ctx.cfg = (float(tau), batched)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        src_feat, tgt_feat, src_mask, tgt_mask, grid, out, stats = ctx.saved_tensors
+        tau, batched = ctx.cfg
+        n, c, p = src_feat.shape
+        q = tgt_feat.shape[2]
+        g_src = torch.empty_like(src_feat) if ctx.needs_input_grad[0] else None
+        g_tgt = torch.empty_like(tgt_feat) if ctx.needs_input_grad[1] else None
+        capi.check(capi.lib().scp_pp_softargmax_backward(
+            capi.dev_ptr(src_feat, "src_feat"), capi.dev_ptr(tgt_feat, "tgt_feat"), capi.opt_ptr(src_mask, "src_mask"),
+            capi.opt_ptr(tgt_mask, "tgt_mask"), capi.dev_ptr(grid, "grid"), batched, tau, n, c, p, q, capi.dev_ptr(out, "out"),
+            capi.dev_ptr(stats, "stats"), capi.dev_ptr(_c(g_out), "g_out"), capi.opt_ptr(g_src, "g_src"), capi.opt_ptr(g_tgt, "g_tgt"),
+            capi.current_stream()), "scp_pp_softargmax_backward")
+        return g_src, g_tgt, None, None, None, None
+
+
 class ColsSoftArgmax(Function):
     """out [N,2,Q] = grid @ softmax_P(tau * masked(scores))"""
 

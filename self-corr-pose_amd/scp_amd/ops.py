@@ -62,6 +62,8 @@ def nearest_vertex(points, verts):
 def pixel_pixel_softargmax(src_feat, tgt_feat, src_mask, tgt_mask, grid, tau):
     """src/tgt_feat [B,C,P], masks [B,P], grid [B,2,P] -> [B,2,P_tgt] = grid @ softmax_src(tau*pc)
     with pc = src^T tgt masked by src_mask x tgt_mask"""
+    if corr_ops.pp_fusable(src_feat, tgt_feat):           # the training shapes: scores stay in registers (csrc/corr_pp.hip)
+        return corr_ops.PixelPixelSoftArgmax.apply(src_feat, tgt_feat, src_mask, tgt_mask, grid, tau)
     pc = src_feat.transpose(1, 2).bmm(tgt_feat)
     return cols_softargmax(pc, src_mask, tgt_mask, grid, tau)
 
@@ -118,7 +120,11 @@ def vertex_bridge_match(pooled, src_idx, tgt_idx, tgt_pixels, keep, grid_half, t
     soft-argmax per unique image."""
     num_verts = pooled.shape[-1]
     mxy = cols_softargmax(pooled, None, None, grid_half, tau_mesh)                       # [B,2,V]
-    pc_tgt_sel = torch.gather(pooled[tgt_idx], 1, tgt_pixels[:, :, None].expand(-1, -1, num_verts))
+    # the K selected rows of each pair's target image, taken straight from pooled[B,P/4,V] (one row gather forward, one row
+    # scatter-add backward): no per-pair [N,P/4,V] copy of the pooled scores (168 MB at N = 64) and none of its gradient
+    n_pool = pooled.shape[1]
+    rows = (tgt_idx[:, None] * n_pool + tgt_pixels).reshape(-1)
+    pc_tgt_sel = pooled.reshape(-1, num_verts).index_select(0, rows).reshape(tgt_pixels.shape[0], tgt_pixels.shape[1], num_verts)
     p_img = torch.softmax(tau_img * pc_tgt_sel, dim=2)                                   # [N,K,V]
     both = (keep[src_idx] & keep[tgt_idx]).to(pooled.dtype)                              # [N,V]
     p_img = p_img * both[:, None, :]
