@@ -144,26 +144,21 @@ __device__ __forceinline__ void load_pixel_operand(const FvmArgs& a, int b, int 
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
-// both orientations of one 32 x 32 score tile from the same operands: accT[r] = S[v = acc_row(r, half)][p = l31] (lane = pixel) and
-// accP[r] = S[p = acc_row(r, half)][v = l31] (lane = vertex).  A and B operands of v_mfma_f32_32x32x2_f32 share one register
-// layout (lane (l31, half) holds row / column l31 at k = half), so the second product is the first with its operands swapped:
-// no second load, and each orientation makes one of the two softmaxes lane local.
-__device__ __forceinline__ void score_tile_both(const float* mt, const float* breg, int l31, int half, f32x16& accT, f32x16& accP) {
+// The second orientation of a 32 x 32 score tile: from accT[r] = S[v = acc_row(r, half)][p = l31] (lane = pixel, what the MFMA
+// produces with the vertex tile as A operand) to accP[r] = S[p = acc_row(r, half)][v = l31] (lane = vertex) through a wavefront-
+// private LDS tile (row stride 33: both the row-wise writes and the column-wise reads are conflict-free).  Each orientation makes
+// one of the two softmaxes lane local; 32 LDS instructions instead of a second set of 32 MFMAs (2048 matrix-pipe cycles).
+constexpr int TROW = 33;
+__device__ __forceinline__ f32x16 transpose_tile(const f32x16& accT, float* tt, int l31, int half) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) { accT[r] = 0.f; accP[r] = 0.f; }
-    const float* mrow = mt + l31 * MROW + 4 * half;
+    for (int r = 0; r < 16; r++) tt[acc_row(r, half) * TROW + l31] = accT[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    f32x16 accP;
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-        const float4 m = *reinterpret_cast<const float4*>(mrow + 8 * t);
-        accT = __builtin_amdgcn_mfma_f32_32x32x2f32(m.x, breg[4 * t + 0], accT, 0, 0, 0);
-        accP = __builtin_amdgcn_mfma_f32_32x32x2f32(breg[4 * t + 0], m.x, accP, 0, 0, 0);
-        accT = __builtin_amdgcn_mfma_f32_32x32x2f32(m.y, breg[4 * t + 1], accT, 0, 0, 0);
-        accP = __builtin_amdgcn_mfma_f32_32x32x2f32(breg[4 * t + 1], m.y, accP, 0, 0, 0);
-        accT = __builtin_amdgcn_mfma_f32_32x32x2f32(m.z, breg[4 * t + 2], accT, 0, 0, 0);
-        accP = __builtin_amdgcn_mfma_f32_32x32x2f32(breg[4 * t + 2], m.z, accP, 0, 0, 0);
-        accT = __builtin_amdgcn_mfma_f32_32x32x2f32(m.w, breg[4 * t + 3], accT, 0, 0, 0);
-        accP = __builtin_amdgcn_mfma_f32_32x32x2f32(breg[4 * t + 3], m.w, accP, 0, 0, 0);
-    }
+    for (int r = 0; r < 16; r++) accP[r] = tt[l31 * TROW + acc_row(r, half)];
+    __builtin_amdgcn_wave_barrier();
+    return accP;
 }
 
 __global__ __launch_bounds__(256) void fvm_forward_kernel(const FvmArgs a) {
@@ -171,6 +166,7 @@ __global__ __launch_bounds__(256) void fvm_forward_kernel(const FvmArgs a) {
     __shared__ __attribute__((aligned(16))) float vt[2][32 * 4];
     __shared__ __attribute__((aligned(16))) float colred[2][4][32][4];
     __shared__ __attribute__((aligned(8))) float pixgrid[4][32][2];          // per wavefront pixel: grid x, y
+    __shared__ float ttile[4][32 * TROW];                                     // per wavefront: the score tile on its way to the other orientation
 
     const int blk = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -194,8 +190,8 @@ __global__ __launch_bounds__(256) void fvm_forward_kernel(const FvmArgs a) {
     for (int tv = 0; tv < a.ntile; tv++) {
         const int buf = tv & 1, v0 = 32 * tv;
         if (tv + 1 < a.ntile) stage_vertex_tile(a, b, v0 + 32, mt[buf ^ 1], vt[buf ^ 1]);
-        f32x16 acc, accP;
-        score_tile_both(mt[buf], breg, l31, half, acc, accP);
+        f32x16 acc = score_tile(mt[buf], breg, l31, half);
+        f32x16 accP = transpose_tile(acc, ttile[wave], l31, half);
         // ---- row softmax (lane = pixel, lane local): running max / sum / weighted vertex sum over this half's 16 vertices
         float tmax = -INFINITY;
 #pragma unroll
