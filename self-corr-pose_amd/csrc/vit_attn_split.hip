@@ -461,31 +461,35 @@ __global__ __launch_bounds__(256) void attention_tail_partial_kernel(const float
     const size_t row_stride = (size_t)3 * H * HD;
     const float* base = qkv + (size_t)b * N * row_stride + (size_t)h * HD;
     const int k0 = c * chunk_keys, nk = max(0, min(chunk_keys, N - k0));
+    // scores of the chunk's keys: a key row (64 floats = 256 B) is read by the 16 lanes of a DPP row, one float4 each -- every load
+    // instruction covers four whole rows (a thread reading its own row touched 64 cache lines per instruction) -- and the 16 partial
+    // dot products are summed inside the row; lane d4 of row-group `part` keeps key part + 16 d4.
+    const int d4q = tid & 15, partq = tid >> 4, kidx = partq + 16 * d4q;
     float s = -INFINITY;
-    if (tid < nk) {
-        float a = 0.f;
-        if (Qp) {
-            // pre-split: the query row (one per workgroup, pre-scaled) from its planes, the keys from the fp32 K third that the qkv
-            // projection keeps for this kernel (a key row as three 128-B plane rows was twice as slow: 48 small loads per thread)
-            const __bf16* qp = Qp + ((size_t)bh * Npad + q) * HD;
-            const float4* kp = reinterpret_cast<const float4*>(base + (size_t)(k0 + tid) * row_stride + (size_t)H * HD);
+    {
+        float4 u;
+        if (Qp) u = planes4(Qp + ((size_t)bh * Npad + q) * HD + 4 * d4q, plane);        // pre-scaled query row from its planes
+        else {
+            u = reinterpret_cast<const float4*>(base + (size_t)q * row_stride)[d4q];
+            u.x *= scale_log2e; u.y *= scale_log2e; u.z *= scale_log2e; u.w *= scale_log2e;
+        }
+        // keys from the fp32 K third that the qkv projection keeps for this kernel
+        const float* kbase = base + (size_t)H * HD + 4 * d4q;
 #pragma unroll
-            for (int i = 0; i < HD / 4; i++) {
-                const float4 u = planes4(qp + 4 * i, plane), t = kp[i];
+        for (int jj = 0; jj < 16; jj++) {
+            const int j = partq + 16 * jj;
+            float a = 0.f;
+            if (j < nk) {
+                const float4 t = *reinterpret_cast<const float4*>(kbase + (size_t)(k0 + j) * row_stride);
                 a = fmaf(u.x, t.x, a); a = fmaf(u.y, t.y, a);
                 a = fmaf(u.z, t.z, a); a = fmaf(u.w, t.w, a);
             }
-        } else {
-            const float4* qp = reinterpret_cast<const float4*>(base + (size_t)q * row_stride);
-            const float4* kp = reinterpret_cast<const float4*>(base + (size_t)(k0 + tid) * row_stride + (size_t)H * HD);
-#pragma unroll
-            for (int i = 0; i < HD / 4; i++) {
-                const float4 u = qp[i], t = kp[i];
-                a = fmaf(u.x * scale_log2e, t.x, a); a = fmaf(u.y * scale_log2e, t.y, a);
-                a = fmaf(u.z * scale_log2e, t.z, a); a = fmaf(u.w * scale_log2e, t.w, a);
-            }
+            a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xF, 0xF, true));     // lane ^ 1
+            a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x4E, 0xF, 0xF, true));     // lane ^ 2
+            a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x141, 0xF, 0xF, true));    // row_half_mirror
+            a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x140, 0xF, 0xF, true));    // row_mirror
+            if (d4q == jj && j < nk) s = a;
         }
-        s = a;
     }
     float m = s;
 #pragma unroll
@@ -493,8 +497,8 @@ __global__ __launch_bounds__(256) void attention_tail_partial_kernel(const float
     if (lane == 0) red[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float e = tid < nk ? __builtin_amdgcn_exp2f(s - m) : 0.f;
-    p_lds[tid] = e;
+    const float e = kidx < nk ? __builtin_amdgcn_exp2f(s - m) : 0.f;
+    p_lds[kidx] = e;
     float l = e;
 #pragma unroll
     for (int k = 1; k < 64; k <<= 1) l += __shfl_xor(l, k);
