@@ -79,13 +79,27 @@ __global__ __launch_bounds__(256) void cols_partial_kernel(
     OnlineState st{-INFINITY, 0.f, 0.f, 0.f};
     const int r0 = chunk * COLS_ROWS_PER_BLOCK;
     const int r1 = min(r0 + COLS_ROWS_PER_BLOCK, P);
-    for (int r = r0 + wave; r < r1; r += 4) {
-        const bool rowok = rm == nullptr || rm[r] > 0.f;   // wavefront-uniform
-        if (qok) {
-            float v = S[base + (size_t)r * Q + q];
-            if (!(rowok && colok)) v = MASKED_SCORE;
-            if (S_out) S_out[base + (size_t)r * Q + q] = v;
-            online_push(st, tau * v, gx[r], gy[r]);
+    // eight rows per pass: their loads are issued together (the online update is a dependent chain with a branch -- issued row by
+    // row, every row paid the full memory latency), then pushed in row order
+    for (int rb = r0 + wave; rb < r1; rb += 32) {
+        float v[8], g0[8], g1[8];
+        bool ok[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int r = rb + 4 * u;
+            ok[u] = r < r1;
+            const int rc = ok[u] ? r : r0;
+            const bool rowok = rm == nullptr || rm[rc] > 0.f;   // wavefront-uniform
+            v[u] = qok ? S[base + (size_t)rc * Q + q] : 0.f;
+            if (!(rowok && colok)) v[u] = MASKED_SCORE;
+            g0[u] = gx[rc]; g1[u] = gy[rc];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (ok[u] && qok) {
+                if (S_out) S_out[base + (size_t)(rb + 4 * u) * Q + q] = v[u];
+                online_push(st, tau * v[u], g0[u], g1[u]);
+            }
         }
     }
     sh[wave][lane] = st;
@@ -262,6 +276,35 @@ __global__ __launch_bounds__(256) void dual_backward_kernel(const DualBwdArgs a)
     }
 }
 
+// ---- backward of the column soft-argmax alone (no row part, no direct gradient): thread = column, COLS_BWD_ROWS rows per workgroup.
+// The column's constants (max, 1 / sum, upstream gradient, its dot with the output) stay in registers over the rows -- in the
+// general kernel above every row's workgroup re-reads the six per-column arrays -- and each row is one coalesced read and one
+// coalesced write.  d S = tau P (g . grid_p - g . out_q), zero where masked.
+constexpr int COLS_BWD_ROWS = 32;
+__global__ __launch_bounds__(256) void cols_backward_kernel(const DualBwdArgs a) {
+    const int q = blockIdx.x * 256 + threadIdx.x, n = blockIdx.z;
+    const int p0 = blockIdx.y * COLS_BWD_ROWS, p1 = min(p0 + COLS_BWD_ROWS, a.P);
+    if (q >= a.Q) return;
+    const size_t c = (size_t)n * 2 * a.Q + q;
+    const bool colok = a.colmask == nullptr || a.colmask[(size_t)n * a.Q + q] > 0.f;
+    const float cmax = a.cstats[c], cinv = 1.f / a.cstats[c + a.Q];
+    const float gcx = a.g_cout[c], gcy = a.g_cout[c + a.Q];
+    const float cdot = gcx * a.cout[c] + gcy * a.cout[c + a.Q];
+    const float* g = a.grid + (a.grid_batched ? (size_t)n * 2 * a.P : 0);
+    const float* rm = a.rowmask ? a.rowmask + (size_t)n * a.P : nullptr;
+    const size_t base = (size_t)n * a.P * a.Q + q;
+#pragma unroll 8
+    for (int p = p0; p < p1; p++) {
+        const bool ok = colok && (rm == nullptr || rm[p] > 0.f);
+        float d = 0.f;
+        if (ok) {
+            const float pc = expf(a.tau_c * a.S[base + (size_t)p * a.Q] - cmax) * cinv;
+            d = a.tau_c * pc * (gcx * g[p] + gcy * g[a.P + p] - cdot);
+        }
+        a.g_out[base + (size_t)p * a.Q] = d;
+    }
+}
+
 }  // namespace
 
 extern "C" size_t scp_softargmax_cols_workspace(int N, int P, int Q) {
@@ -311,6 +354,10 @@ extern "C" int scp_dual_softmax_backward(const float* scores, const float* rowma
     DualBwdArgs a{scores, rowmask, colmask, g_scores_in, g_scores_out, colstats, col_out, g_col_out, grid,
                   grid_batched, tau_c, rowstats, row_out, g_row_out, weights, tau_r, P, Q};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (rowstats == nullptr && g_scores_in == nullptr && colstats != nullptr) {
+        hipLaunchKernelGGL(cols_backward_kernel, dim3((Q + 255) / 256, (P + COLS_BWD_ROWS - 1) / COLS_BWD_ROWS, N), dim3(256), 0, st, a);
+        return scp::check_launch("cols_backward");
+    }
     const dim3 grid_dim((unsigned)((long)N * P)), block(256);
     if (rowstats == nullptr || W == 3) hipLaunchKernelGGL(dual_backward_kernel<3>, grid_dim, block, 0, st, a);
     else if (W == 2) hipLaunchKernelGGL(dual_backward_kernel<2>, grid_dim, block, 0, st, a);
