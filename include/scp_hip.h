@@ -116,13 +116,17 @@ int scp_selftest_exact_division(unsigned long long n, unsigned seed, unsigned lo
  *   img_feat [B,64,hf*wf], mesh_feat [B,V,64], mask_down [B,hf*wf], verts [B,V,3], grid [2,hf*wf]
  *   forward ->  pooled [B,hf*wf/4,V] (2x2 mean of the masked scores), match [B,hf*wf,3], imatch [B,2,V],
  *               rowstat [B,hf*wf,2], colstat [B,V,2] (softmax max / sum, for the backward), workspace >= scp_fvm_workspace()
+ *               grid_half [2,hf*wf/4] (NULL = skip; then bridge_xy and bridge_colstat NULL too): the pixel grid at the pooled
+ *               resolution ->  bridge_xy [B,2,V] = grid_half @ softmax_{pooled pixels}(tau_mesh * pooled) and bridge_colstat [B,V,2]
+ *               (max, sum), i.e. the per-vertex column soft-argmax pretrained_corr.py:123-126 takes of the pooled scores (the
+ *               "mesh -> image" half of the vertex bridge), produced while the pooled values are still in registers
  *   backward -> g_img_feat [B,64,hf*wf], g_mesh_feat [B,V,64] from g_match / g_imatch / g_pooled (each may be NULL = zero);
  *               scores are recomputed on the matrix cores, nothing of size B*P*V is read or written. */
 size_t scp_fvm_workspace(int B, int hf, int V);
 int scp_fvm_forward(const float* img_feat, const float* mesh_feat, const float* mask_down, const float* verts,
                     const float* grid, float tau_img, float tau_mesh, int B, int C, int hf, int wf, int V, float* pooled,
-                    float* match, float* imatch, float* rowstat, float* colstat, void* workspace, size_t workspace_bytes,
-                    void* stream);
+                    float* match, float* imatch, float* rowstat, float* colstat, const float* grid_half, float* bridge_xy,
+                    float* bridge_colstat, void* workspace, size_t workspace_bytes, void* stream);
 int scp_fvm_backward(const float* img_feat, const float* mesh_feat, const float* mask_down, const float* verts,
                      const float* grid, float tau_img, float tau_mesh, int B, int C, int hf, int wf, int V,
                      const float* match, const float* imatch, const float* rowstat, const float* colstat,

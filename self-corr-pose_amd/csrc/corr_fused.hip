@@ -78,6 +78,8 @@ struct FvmArgs {
     float* match;          // [B, P, 3]
     float* rowstat;        // [B, P, 2]   (max of tau_img * s over vertices, sum of exp)
     float* colpart;        // [B, nblk, V, 4] (max, sum e, sum e gx, sum e gy) of tau_mesh * s over the strip's pixels
+    const float* grid_half;// [2, P/4] or null: pixel grid at the pooled resolution -> also the column statistics of the POOLED scores
+    float* colpart2;       // [B, nblk, V, 4] the same four numbers of tau_mesh * pooled over the strip's 32 pool cells (grid_half)
     // backward inputs
     const float* colstat;  // [B, V, 2]
     const float* imatch;   // [B, 2, V]
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(256) void fvm_forward_kernel(const FvmArgs a) {
     __shared__ __attribute__((aligned(16))) float colred[2][4][32][4];
     __shared__ __attribute__((aligned(8))) float pixgrid[4][32][2];          // per wavefront pixel: grid x, y
     __shared__ float ttile[4][32 * TROW];                                     // per wavefront: the score tile on its way to the other orientation
+    __shared__ __attribute__((aligned(16))) float colred2[2][4][32][4];       // column partials of the pooled scores (a9's bridge)
 
     const int blk = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -184,6 +187,19 @@ __global__ __launch_bounds__(256) void fvm_forward_kernel(const FvmArgs a) {
     float m_run = -INFINITY, l_run = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;     // row softmax over vertices (this half's share)
     // pooled cells of the lane = vertex orientation: registers 4j..4j+3 are the 2x2 cell 2j + half of the wavefront
     float* pooled_col = a.pooled + ((size_t)b * (a.P / 4) + blk * (WF / 2) + 8 * wave + half) * a.V + l31;
+    // pretrained_corr.py:123-126 takes a softmax over the POOLED pixels of every vertex' score map and its grid-weighted mean
+    // (the "mesh -> image" half of the vertex bridge): the pooled values are in this lane's registers anyway, so their column
+    // statistics are produced here as well (same partial / merge protocol as imatch) and the a9 pass over pooled[] disappears
+    const bool bridge = a.grid_half != nullptr;
+    float ghx[4] = {0.f, 0.f, 0.f, 0.f}, ghy[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bridge) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int p2 = blk * (WF / 2) + 8 * wave + 2 * j + half;
+            ghx[j] = a.grid_half[p2];
+            ghy[j] = a.grid_half[a.P / 4 + p2];
+        }
+    }
 
     stage_vertex_tile(a, b, 0, mt[0], vt[0]);
     __syncthreads();
@@ -235,12 +251,40 @@ __global__ __launch_bounds__(256) void fvm_forward_kernel(const FvmArgs a) {
         }
         se += other_half(se); sx += other_half(sx); sy += other_half(sy);
         if (half == 0) *reinterpret_cast<float4*>(&colred[buf][wave][l31][0]) = make_float4(cm, se, sx, sy);
+        float pq[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) pq[j] = 0.25f * ((accP[4 * j] + accP[4 * j + 1]) + (accP[4 * j + 2] + accP[4 * j + 3]));
         if (v0 + l31 < a.V) {
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                pooled_col[(size_t)(2 * j) * a.V + v0] = 0.25f * ((accP[4 * j] + accP[4 * j + 1]) + (accP[4 * j + 2] + accP[4 * j + 3]));
+            for (int j = 0; j < 4; j++) pooled_col[(size_t)(2 * j) * a.V + v0] = pq[j];
+        }
+        if (bridge) {        // workgroup-uniform
+            float cm2 = fmaxf(fmaxf(a.tau_mesh * pq[0], a.tau_mesh * pq[1]), fmaxf(a.tau_mesh * pq[2], a.tau_mesh * pq[3]));
+            cm2 = fmaxf(cm2, other_half(cm2));
+            float se2 = 0.f, sx2 = 0.f, sy2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float e = __expf(a.tau_mesh * pq[j] - cm2);
+                se2 += e; sx2 += e * ghx[j]; sy2 += e * ghy[j];
+            }
+            se2 += other_half(se2); sx2 += other_half(sx2); sy2 += other_half(sy2);
+            if (half == 0) *reinterpret_cast<float4*>(&colred2[buf][wave][l31][0]) = make_float4(cm2, se2, sx2, sy2);
         }
         __syncthreads();      // colred[buf] complete; next tile staged; everyone done reading mt[buf]
+        if (bridge && tid >= 32 && tid < 64 && v0 + tid - 32 < a.V) {     // lanes 32..63 of wavefront 0: the pooled scores' partials
+            const int vq = tid - 32;
+            float M = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < 4; w++) M = fmaxf(M, colred2[buf][w][vq][0]);
+            float se4 = 0.f, sx4 = 0.f, sy4 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const float4 c4 = *reinterpret_cast<const float4*>(&colred2[buf][w][vq][0]);
+                const float sc = __expf(c4.x - M);
+                se4 += c4.y * sc; sx4 += c4.z * sc; sy4 += c4.w * sc;
+            }
+            *reinterpret_cast<float4*>(a.colpart2 + (((size_t)b * a.nblk + blk) * a.V + v0 + vq) * 4) = make_float4(M, se4, sx4, sy4);
+        }
         if (tid < 32 && v0 + tid < a.V) {        // merge the four wavefronts' partials of vertex tid (fixed order)
             float M = -INFINITY;
 #pragma unroll
@@ -560,24 +604,32 @@ int check_shape(int B, int Cf, int hf, int wf, int V) {
 
 }  // namespace
 
-extern "C" size_t scp_fvm_workspace(int B, int hf, int V) { return (size_t)B * (hf / 2) * V * 4 * sizeof(float); }
+extern "C" size_t scp_fvm_workspace(int B, int hf, int V) { return 2 * (size_t)B * (hf / 2) * V * 4 * sizeof(float); }
 
 extern "C" int scp_fvm_forward(const float* img_feat, const float* mesh_feat, const float* mask_down, const float* verts,
                                const float* grid, float tau_img, float tau_mesh, int B, int Cf, int hf, int wf, int V,
-                               float* pooled, float* match, float* imatch, float* rowstat, float* colstat, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               float* pooled, float* match, float* imatch, float* rowstat, float* colstat, const float* grid_half,
+                               float* bridge_xy, float* bridge_colstat, void* workspace, size_t workspace_bytes, void* stream) {
     if (int e = check_shape(B, Cf, hf, wf, V)) return e;
     if (workspace_bytes < scp_fvm_workspace(B, hf, V)) return scp::fail(hipErrorInvalidValue, "feature_vertex_match: workspace too small");
     FvmArgs a{};
     a.img = img_feat; a.mesh = mesh_feat; a.mask = mask_down; a.verts = verts; a.grid = grid;
     a.tau_img = tau_img; a.tau_mesh = tau_mesh;
     a.B = B; a.P = hf * wf; a.V = V; a.hf = hf; a.ntile = (V + 31) / 32; a.nblk = hf / 2;
+    if ((grid_half != nullptr) != (bridge_xy != nullptr) || (grid_half != nullptr) != (bridge_colstat != nullptr))
+        return scp::fail(hipErrorInvalidValue, "feature_vertex_match: grid_half, bridge_xy and bridge_colstat come together");
     a.pooled = pooled; a.match = match; a.rowstat = rowstat; a.colpart = static_cast<float*>(workspace);
+    a.grid_half = grid_half; a.colpart2 = a.colpart + (size_t)B * a.nblk * V * 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(fvm_forward_kernel, dim3(a.nblk, B), dim3(256), 0, st, a);
     if (int e = scp::check_launch("fvm_forward")) return e;
     hipLaunchKernelGGL(fvm_col_merge_kernel, dim3((B * V + 255) / 256), dim3(256), 0, st, a.colpart, B, a.nblk, V, imatch, colstat);
-    return scp::check_launch("fvm_col_merge");
+    if (int e = scp::check_launch("fvm_col_merge")) return e;
+    if (grid_half) {
+        hipLaunchKernelGGL(fvm_col_merge_kernel, dim3((B * V + 255) / 256), dim3(256), 0, st, a.colpart2, B, a.nblk, V, bridge_xy, bridge_colstat);
+        return scp::check_launch("fvm_col_merge (pooled)");
+    }
+    return 0;
 }
 
 extern "C" int scp_fvm_backward(const float* img_feat, const float* mesh_feat, const float* mask_down, const float* verts,

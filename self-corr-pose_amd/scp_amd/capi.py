@@ -56,7 +56,7 @@ SYMBOLS = {
     "scp_split_bf16x3_tiled": (ctypes.c_int, [_P, _P, _I, _I, _P]),
     "scp_vit_linear_planes": (ctypes.c_int, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P]),
     "scp_fvm_workspace": (ctypes.c_size_t, [ctypes.c_int] * 3),
-    "scp_fvm_forward": (ctypes.c_int, [_P] * 5 + [ctypes.c_float] * 2 + [ctypes.c_int] * 5 + [_P] * 6 + [ctypes.c_size_t, _P]),
+    "scp_fvm_forward": (ctypes.c_int, [_P] * 5 + [ctypes.c_float] * 2 + [ctypes.c_int] * 5 + [_P] * 9 + [ctypes.c_size_t, _P]),
     "scp_fvm_backward": (ctypes.c_int, [_P] * 5 + [ctypes.c_float] * 2 + [ctypes.c_int] * 5 + [_P] * 10),
     "scp_pp_softargmax_forward": (ctypes.c_int, [_P] * 5 + [_I, _F] + [_I] * 4 + [_P] * 3),
     "scp_pp_softargmax_backward": (ctypes.c_int, [_P] * 5 + [_I, _F] + [_I] * 4 + [_P] * 6),

@@ -158,8 +158,11 @@ class PooledScores:
     pooled masked scores [B, hf*wf/4, V] (pretrained_corr.py:120-123 pools them first thing); the full [B, hf*wf, V] tensor is
     never formed"""
 
-    def __init__(self, pooled, hf, wf):
+    def __init__(self, pooled, hf, wf, bridge=None):
         self.pooled, self.hf, self.wf = pooled, hf, wf
+        # (grid_half [2,P/4], tau_mesh, xy [B,2,V], colstat [B,2,V]) when the fused forward also produced the column soft-argmax of
+        # the pooled scores that pretrained_corr.py:123-126 takes (ops.vertex_bridge_match then skips its pass over `pooled`)
+        self.bridge = bridge
         self.shape = (pooled.shape[0], hf * wf, pooled.shape[2])
         self.device, self.dtype = pooled.device, pooled.dtype
 
@@ -168,9 +171,9 @@ class FeatureVertexMatchFused(Function):
     """(pooled scores [B,P/4,V], match [B,P,3], imatch [B,2,V]) from unit features; scores live in registers only"""
 
     @staticmethod
-    def forward(ctx, img_feat, mesh_feat, mask_down, verts, grid, tau_img, tau_mesh, hf, wf):
+    def forward(ctx, img_feat, mesh_feat, mask_down, verts, grid, tau_img, tau_mesh, hf, wf, grid_half=None):
         img_feat, mesh_feat = img_feat.contiguous().float(), mesh_feat.contiguous().float()
-        mask_down, verts, grid = _c(mask_down), _c(verts), _c(grid)
+        mask_down, verts, grid, grid_half = _c(mask_down), _c(verts), _c(grid), _c(grid_half)
         b, c, p = img_feat.shape
         v = mesh_feat.shape[1]
         dev = img_feat.device
@@ -180,20 +183,33 @@ class FeatureVertexMatchFused(Function):
         imatch = torch.empty(b, 2, v, dtype=torch.float32, device=dev)
         rowstat = torch.empty(b, p, 2, dtype=torch.float32, device=dev)
         colstat = torch.empty(b, v, 2, dtype=torch.float32, device=dev)
+        bridge_xy = bridge_stat = None
+        if grid_half is not None:
+            if tuple(grid_half.shape) != (2, p // 4):
+                raise RuntimeError("feature_vertex_match: grid_half must be [2, %d]" % (p // 4))
+            bridge_xy = torch.empty(b, 2, v, dtype=torch.float32, device=dev)
+            bridge_stat = torch.empty(b, v, 2, dtype=torch.float32, device=dev)
         nbytes = L.scp_fvm_workspace(b, hf, v)
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
         capi.check(L.scp_fvm_forward(capi.dev_ptr(img_feat, "img_feat"), capi.dev_ptr(mesh_feat, "mesh_feat"),
                                      capi.dev_ptr(mask_down, "mask_down"), capi.dev_ptr(verts, "verts"), capi.dev_ptr(grid, "grid"),
                                      float(tau_img), float(tau_mesh), b, c, hf, wf, v, capi.dev_ptr(pooled, "pooled"),
                                      capi.dev_ptr(match, "match"), capi.dev_ptr(imatch, "imatch"), capi.dev_ptr(rowstat, "rowstat"),
-                                     capi.dev_ptr(colstat, "colstat"), capi.dev_ptr(ws, "workspace"), ctypes.c_size_t(nbytes),
+                                     capi.dev_ptr(colstat, "colstat"), capi.opt_ptr(grid_half, "grid_half"),
+                                     capi.opt_ptr(bridge_xy, "bridge_xy"), capi.opt_ptr(bridge_stat, "bridge_colstat"),
+                                     capi.dev_ptr(ws, "workspace"), ctypes.c_size_t(nbytes),
                                      capi.current_stream()), "scp_fvm_forward")
         ctx.save_for_backward(img_feat, mesh_feat, mask_down, verts, grid, match, imatch, rowstat, colstat)
         ctx.cfg = (float(tau_img), float(tau_mesh), hf, wf)
-        return pooled, match, imatch
+        if grid_half is None:
+            return pooled, match, imatch
+        # the bridge outputs are constants of this node: their gradient reaches `pooled` through ColsSoftArgmaxPrecomputed
+        bridge_stat = bridge_stat.transpose(1, 2).contiguous()          # [B,2,V], the layout scp_dual_softmax_backward reads
+        ctx.mark_non_differentiable(bridge_xy, bridge_stat)
+        return pooled, match, imatch, bridge_xy, bridge_stat
 
     @staticmethod
-    def backward(ctx, g_pooled, g_match, g_imatch):
+    def backward(ctx, g_pooled, g_match, g_imatch, *_unused):
         img_feat, mesh_feat, mask_down, verts, grid, match, imatch, rowstat, colstat = ctx.saved_tensors
         tau_img, tau_mesh, hf, wf = ctx.cfg
         b, c, p = img_feat.shape
@@ -207,7 +223,24 @@ class FeatureVertexMatchFused(Function):
             capi.dev_ptr(colstat, "colstat"), capi.opt_ptr(_c(g_match), "g_match"), capi.opt_ptr(_c(g_imatch), "g_imatch"),
             capi.opt_ptr(_c(g_pooled), "g_pooled"), capi.opt_ptr(g_img, "g_img"), capi.opt_ptr(g_mesh, "g_mesh"),
             capi.current_stream()), "scp_fvm_backward")
-        return g_img, g_mesh, None, None, None, None, None, None, None
+        return g_img, g_mesh, None, None, None, None, None, None, None, None
+
+
+class ColsSoftArgmaxPrecomputed(Function):
+    """ColsSoftArgmax (no masks) whose forward result already exists: out [N,2,Q] and stats [N,2,Q] were produced by the kernel that
+    produced `scores` (FeatureVertexMatchFused with grid_half); only the backward runs here."""
+
+    @staticmethod
+    def forward(ctx, scores, grid, tau, out, stats):
+        ctx.save_for_backward(scores, _c(grid), out, stats)
+        ctx.tau = float(tau)
+        return out.clone()
+
+    @staticmethod
+    def backward(ctx, g_out):
+        scores, grid, out, stats = ctx.saved_tensors
+        g = dual_backward(scores, None, None, None, (stats, out, _c(g_out), grid, ctx.tau), None)
+        return g, None, None, None, None
 
 
 def pp_fusable(src_feat, tgt_feat):

@@ -42,7 +42,8 @@ class Correspondence:
         if self.opts.train and img_feat.is_cuda and getattr(self, "fuse_scores", True):
             # training consumes the scores only 2x2-pooled (pretrained_corr.py:120-123): fused kernels, no [B,P,V] tensor
             fused = ops.feature_vertex_match_pooled(img_feat, mesh_feat, mask_down, pred_v.detach(), self.meshgrid,
-                                                    self.tau_img, self.tau_mesh, self.hf, self.wf)
+                                                    self.tau_img, self.tau_mesh, self.hf, self.wf,
+                                                    self.half_grid(1).reshape(2, -1) if getattr(self, "fuse_bridge", True) else None)
         if fused is not None:
             pointcorr, match, imatch = fused
         else:

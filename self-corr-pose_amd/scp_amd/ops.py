@@ -41,16 +41,22 @@ def feature_vertex_match(img_feat, mesh_feat, mask_down, verts, grid, tau_img, t
     return corr_ops.FeatureVertexMatch.apply(img_feat, mesh_feat, mask_down, verts, grid, tau_img, tau_mesh)
 
 
-def feature_vertex_match_pooled(img_feat, mesh_feat, mask_down, verts, grid, tau_img, tau_mesh, hf, wf):
+def feature_vertex_match_pooled(img_feat, mesh_feat, mask_down, verts, grid, tau_img, tau_mesh, hf, wf, grid_half=None):
     """training form of feature_vertex_match: the scores are consumed only 2x2-pooled (pretrained_corr.py:120-123), so they
     are produced that way and never stored at full resolution.  -> (PooledScores, match [B,P,3], imatch [B,2,V]);
-    None when the shape is outside what the fused kernels cover (caller falls back to feature_vertex_match)."""
+    None when the shape is outside what the fused kernels cover (caller falls back to feature_vertex_match).
+    grid_half [2,P/4] (the pixel grid at the pooled resolution): the same launch also leaves, in PooledScores.bridge, the column
+    soft-argmax of the pooled scores that the vertex bridge needs (pretrained_corr.py:123-126; vertex_bridge_match(precomputed=...))."""
     _require_gpu(img_feat, "feature_vertex_match_pooled")
     if not corr_ops.fvm_fusable(img_feat, mesh_feat, hf, wf):
         return None
-    pooled, match, imatch = corr_ops.FeatureVertexMatchFused.apply(img_feat, mesh_feat, mask_down, verts, grid, tau_img,
-                                                                   tau_mesh, hf, wf)
-    return corr_ops.PooledScores(pooled, hf, wf), match, imatch
+    if grid_half is None:
+        pooled, match, imatch = corr_ops.FeatureVertexMatchFused.apply(img_feat, mesh_feat, mask_down, verts, grid, tau_img,
+                                                                       tau_mesh, hf, wf)
+        return corr_ops.PooledScores(pooled, hf, wf), match, imatch
+    pooled, match, imatch, xy, stat = corr_ops.FeatureVertexMatchFused.apply(img_feat, mesh_feat, mask_down, verts, grid, tau_img,
+                                                                             tau_mesh, hf, wf, grid_half)
+    return corr_ops.PooledScores(pooled, hf, wf, (grid_half, float(tau_mesh), xy, stat)), match, imatch
 
 
 def nearest_vertex(points, verts):
@@ -106,7 +112,7 @@ def pool2x2_scores(pc, hf, wf):
     return (pc.reshape(b, hf // 2, 2, wf // 2, 2, v).sum((2, 4)) * 0.25).reshape(b, -1, v)
 
 
-def vertex_bridge_match(pooled, src_idx, tgt_idx, tgt_pixels, keep, grid_half, tau_img, tau_mesh):
+def vertex_bridge_match(pooled, src_idx, tgt_idx, tgt_pixels, keep, grid_half, tau_img, tau_mesh, precomputed=None):
     """Soft pixel->pixel map through the vertices, evaluated at the selected target pixels.
     pooled [B,P,V] per-image pooled scores; src_idx/tgt_idx [N] image pairs; tgt_pixels [N,K] selected
     target pixels; keep [B,V] bool (vertex visible); grid_half [2,P]  ->  [N,2,K].
@@ -119,7 +125,12 @@ def vertex_bridge_match(pooled, src_idx, tgt_idx, tgt_pixels, keep, grid_half, t
     so the [N,P,P] matrix and its 86-134 GFLOP GEMM are never formed; (grid @ P_mesh) is one column
     soft-argmax per unique image."""
     num_verts = pooled.shape[-1]
-    mxy = cols_softargmax(pooled, None, None, grid_half, tau_mesh)                       # [B,2,V]
+    if precomputed is not None and precomputed[1] == float(tau_mesh) and precomputed[0].shape == grid_half.shape:
+        # PooledScores.bridge: the kernel that produced `pooled` already took this soft-argmax (same grid values by construction:
+        # both sides interpolate make_meshgrid the same way); only its backward is a pass over pooled
+        mxy = corr_ops.ColsSoftArgmaxPrecomputed.apply(pooled, precomputed[0], tau_mesh, precomputed[2], precomputed[3])
+    else:
+        mxy = cols_softargmax(pooled, None, None, grid_half, tau_mesh)                   # [B,2,V]
     # the K selected rows of each pair's target image, taken straight from pooled[B,P/4,V] (one row gather forward, one row
     # scatter-add backward): no per-pair [N,P/4,V] copy of the pooled scores (168 MB at N = 64) and none of its gradient
     n_pool = pooled.shape[1]

@@ -179,6 +179,7 @@ class PretrainedCorrespondence(nn.Module):
         # bilinear half-resolution (= exact 2x2 mean) of the score maps, once per image
         pooled = ops.pool2x2_scores(pointcorr, self.hf, self.wf)                                    # b,p,v
         match = ops.vertex_bridge_match(pooled, src_idx, tgt_idx, indices_tgt, depth_weight >= 0.5,
-                                        self.half_grid(1).reshape(2, -1), self.tau_img, self.tau_mesh)
+                                        self.half_grid(1).reshape(2, -1), self.tau_img, self.tau_mesh,
+                                        precomputed=getattr(pointcorr, "bridge", None))
         cycle_loss = ((match - pts_src).norm(2, 1) * mask_k).mean()
         return cycle_loss, pts_src, pts_tgt, match, mask_k, img[src_idx], img[tgt_idx]

@@ -433,6 +433,46 @@ def test_fused_feature_vertex_match_vs_oracle(B, hf, V):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,hf,V", [(3, 64, 642), (2, 8, 37)])
+def test_fused_bridge_columns_equal_the_separate_pass(B, hf, V):
+    """feature_vertex_match_pooled(grid_half=...) also leaves the column soft-argmax of the POOLED scores (the mesh -> image half of
+    the vertex bridge, pretrained_corr.py:123-126): same values as the separate pass over pooled[], and vertex_bridge_match gives the
+    same output and the same feature gradients whether it uses them or recomputes them; one fully masked image"""
+    from scp_amd import ops
+    wf, C, K = 64, 64, 9
+    P = hf * wf
+    g = torch.Generator().manual_seed(B * 7 + V)
+    img = torch.nn.functional.normalize(torch.randn(B, C, P, generator=g), 2, 1).cuda()
+    mesh = torch.nn.functional.normalize(torch.randn(B, V, C, generator=g), 2, 2).cuda()
+    verts = torch.randn(B, V, 3, generator=g).cuda()
+    xs, ys = (torch.arange(float(wf)) + 0.5) / (wf / 2) - 1, (torch.arange(float(hf)) + 0.5) / (wf / 2) - 1
+    grid = torch.stack((xs.repeat(hf), ys.repeat_interleave(wf))).cuda()
+    gh = torch.nn.functional.interpolate(grid.reshape(2, hf, wf)[None], (hf // 2, wf // 2), mode="bilinear").reshape(2, -1)
+    mask = (torch.rand(B, P, generator=g) > 0.4).float().cuda()
+    mask[0] = 0.
+    src_idx, tgt_idx = torch.arange(B).cuda(), torch.arange(B).roll(1).cuda()
+    pix = torch.stack([torch.randperm(P // 4, generator=g)[:K] for _ in range(B)]).cuda()
+    keep = (torch.rand(B, V, generator=g) > 0.3).cuda()
+    w = torch.randn(B, 2, K, generator=g).cuda()
+
+    def run(with_bridge):
+        a, b = img.clone().requires_grad_(True), mesh.clone().requires_grad_(True)
+        pc, match, imatch = ops.feature_vertex_match_pooled(a, b, mask, verts, grid, 10., 10., hf, wf, gh if with_bridge else None)
+        assert (pc.bridge is not None) == with_bridge
+        out = ops.vertex_bridge_match(ops.pool2x2_scores(pc, hf, wf), src_idx, tgt_idx, pix, keep, gh, 10., 10., precomputed=pc.bridge)
+        ((out * w).sum() + match.square().sum() * 1e-3).backward()
+        return pc, out.detach(), a.grad, b.grad
+
+    pc, out1, ga1, gb1 = run(True)
+    ref = ops.cols_softargmax(pc.pooled.detach(), None, None, gh, 10.)
+    _close(pc.bridge[2], ref.cpu().numpy())
+    _, out0, ga0, gb0 = run(False)
+    _close(out1, out0.cpu().numpy())
+    _grad_close(ga1, ga0.cpu().numpy(), 2e-5)
+    _grad_close(gb1, gb0.cpu().numpy(), 2e-5)
+
+
+@pytest.mark.gpu
 def test_fused_match_in_training_step_equals_unfused():
     """Correspondence.match (train mode) through the fused kernels vs the round-1 path (rocBLAS scores + reductions): same
     match / imatch, same pooled scores, same feature gradients"""

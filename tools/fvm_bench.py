@@ -54,8 +54,18 @@ ptr = capi.dev_ptr
 
 def forward():
     capi.check(L.scp_fvm_forward(ptr(img, "i"), ptr(mesh, "m"), ptr(mask, "k"), ptr(verts, "v"), ptr(grid, "g"), 10., 10., B, C, hf, wf, V,
-                                 ptr(pooled, "p"), ptr(match, "m"), ptr(imatch, "i"), ptr(rowstat, "r"), ptr(colstat, "c"), ptr(ws, "w"),
+                                 ptr(pooled, "p"), ptr(match, "m"), ptr(imatch, "i"), ptr(rowstat, "r"), ptr(colstat, "c"), None, None, None, ptr(ws, "w"),
                                  ctypes.c_size_t(nbytes), capi.current_stream()), "fwd")
+
+
+gh = torch.nn.functional.interpolate(grid.reshape(2, hf, wf)[None], (hf // 2, wf // 2), mode="bilinear").reshape(2, -1).contiguous()
+bxy, bstat = torch.empty(B, 2, V, device="cuda"), torch.empty(B, V, 2, device="cuda")
+
+
+def forward_bridge():
+    capi.check(L.scp_fvm_forward(ptr(img, "i"), ptr(mesh, "m"), ptr(mask, "k"), ptr(verts, "v"), ptr(grid, "g"), 10., 10., B, C, hf, wf, V,
+                                 ptr(pooled, "p"), ptr(match, "m"), ptr(imatch, "i"), ptr(rowstat, "r"), ptr(colstat, "c"), ptr(gh, "gh"),
+                                 ptr(bxy, "x"), ptr(bstat, "s"), ptr(ws, "w"), ctypes.c_size_t(nbytes), capi.current_stream()), "fwd")
 
 
 def backward(gi, gm):
@@ -66,7 +76,9 @@ def backward(gi, gm):
 
 forward()
 t_f = timed(forward)
+t_fb = timed(forward_bridge)
 t_i = timed(lambda: backward(g_img, None))
 t_m = timed(lambda: backward(None, g_mesh))
-print("fvm V=%d lib=%s: forward (+ column merge) %.3f ms, backward_img %.3f ms, backward_mesh %.3f ms, sum %.3f ms"
-      % (V, os.path.basename(os.environ.get("SCP_HIP_LIB", "libscp_hip.so")), t_f, t_i, t_m, t_f + t_i + t_m))
+print("fvm V=%d lib=%s: forward (+ column merge) %.3f ms (%.3f ms with the pooled scores' column soft-argmax for a9), backward_img %.3f ms, "
+      "backward_mesh %.3f ms, sum %.3f ms" % (V, os.path.basename(os.environ.get("SCP_HIP_LIB", "libscp_hip.so")), t_f, t_fb, t_i, t_m,
+                                              t_f + t_i + t_m))
