@@ -660,6 +660,9 @@ def main():
     # before this step's backward.  Per-step work is unchanged -- every step of the timed region enqueues exactly one ViT pass
     # (for the batch after it) besides its own forward / backward / optimizer -- but the pass no longer heads the critical path
     # of the step that consumes it.  The synthetic "next batch" is the same resident batch.  --no-lookahead: the unpipelined step.
+    from scp_amd import streams as stream_policy
+    if not stream_policy.overlap():
+        args.no_lookahead = True             # SCP_STREAMS=serial (the default): one stream, no look-ahead (scp_amd/streams.py)
     nxt = None if args.no_lookahead else data
     for _ in range(INIT_STEPS):
         tr.step(data)
@@ -833,6 +836,11 @@ def main():
                        "images_per_sec": world * args.steps * B / elapsed, "parallelism": "dp%d" % world,
                        "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else 0,
                        "gradient_buckets": len(tr.grads.buckets), "buckets_launched_inside_backward": tr.grads.launched_in_backward,
+                       "streams": {"mode": stream_policy.MODE,
+                                   "what": "serial = one HIP stream, kernels of the step never run side by side (the default); overlap = "
+                                           "frozen ViT / rotation-cycle encoder pass / texture pass on side streams + ViT look-ahead: "
+                                           "faster (profiles/r04_bench_n1_overlap.json) but wavefronts sharing a SIMD with the bf16-MFMA "
+                                           "kernels were observed to compute wrong values on this part (DESIGN 5.2, tools/race_repro.py)"},
                        "vit_lookahead": {"enabled": not args.no_lookahead,
                                          "what": "step(data, next_data): the frozen-DINO ViT pass of the NEXT batch runs on the side stream "
                                                  "during this step's backward, as in Trainer.train(); one ViT pass per timed step either way",

@@ -171,6 +171,7 @@ using SplitOf = scp::SplitCfg<CFG::WM, CFG::WN, CFG::NWM, CFG::NWN, CFG::MINBLK,
 template <class FCFG, int TAPS, int EPI, bool STATS, bool SPLIT>
 __global__ __launch_bounds__(FCFG::THREADS, 2) void conv_igemm_kernel(const ConvArgs g) {
     using CFG = std::conditional_t<SPLIT, SplitOf<FCFG>, FCFG>;
+    if constexpr (SPLIT) scp::claim_vgprs_for_tile<FCFG::WM, FCFG::WN>();       // bf16 MFMAs: the wavefronts tile the SIMD's register file (scp_common.h)
     __shared__ __attribute__((aligned(16))) float lds[CFG::LDS_BYTES / 4];
     using Core = std::conditional_t<SPLIT, scp::SplitGemmCore<SplitOf<FCFG>, ConvASource<SplitOf<FCFG>, TAPS>>,
                                     scp::GemmCore<FCFG, ConvSource<FCFG, TAPS>>>;
@@ -343,6 +344,8 @@ struct Dgrad2ASource {
 template <class FCFG>
 __global__ __launch_bounds__(FCFG::THREADS, 2) void conv_dgrad_s2_kernel(const ConvArgs g) {
     using CFG = SplitOf<FCFG>;
+    if constexpr (FCFG::WM * FCFG::WN >= 4) scp::claim_vgprs<256>();            // 180 - 196 registers: the 2 x 256 class (scp_common.h)
+    else scp::claim_vgprs_for_tile<FCFG::WM, FCFG::WN>();
     __shared__ __attribute__((aligned(16))) float lds[CFG::LDS_BYTES / 4];
     using Core = scp::SplitGemmCore<CFG, Dgrad2ASource<CFG>>;
     // two kinds of workgroups per tile of the dy grid: one takes the 4-tap class, the other the 2 + 2 + 1-tap classes one after the

@@ -323,6 +323,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_wgrad_kernel(const WgradArgs 
     static_assert(SPLIT || (STR == 1 && KS == 3), "the fp32 core's compile-time read offsets are the stride-1 3x3 halo's");
     using Core = std::conditional_t<SPLIT, WgradSplitCore<CW, STR, KS>, WgradCore<CW, STR, KS>>;
     constexpr int NT = KS * KS;
+    if constexpr (SPLIT) scp::claim_vgprs<256>();                               // bf16 MFMAs: two wavefronts fill a SIMD's register file (scp_common.h)
     __shared__ __attribute__((aligned(16))) float lds[NSTAGE * Core::STAGE_BYTES / 4];
     // workgroup b runs on XCD b % 8 and takes a contiguous share of the (split, co block, ci block) list, split slowest: the
     // workgroups that read the same pixels sit on one XCD's L2

@@ -144,6 +144,7 @@ __device__ __forceinline__ unsigned long long pack_key(float v, int idx) {
 template <class CFG, class Core>
 __global__ __launch_bounds__(CFG::THREADS, 2) void mutual_nn_fused_kernel(const FusedArgs g) {
     static_assert(CFG::WM == 2 && CFG::WN == 2, "the epilogue's lane <-> row / column slots assume 64 x 64 per wavefront");
+    if constexpr (!std::is_same_v<Core, scp::GemmCore<CFG>>) scp::claim_vgprs<168>();      // split core = bf16 MFMAs (scp_common.h)
     __shared__ __attribute__((aligned(16))) float lds[CFG::LDS_BYTES / 4];
     // all tiles of a pair on one XCD (workgroup b runs on XCD b % 8): its 8 + 8 operand panels (3.9 MB) stay in that XCD's L2
     const int tiles_1d = (g.P + CFG::BM - 1) / CFG::BM, tiles = tiles_1d * tiles_1d;

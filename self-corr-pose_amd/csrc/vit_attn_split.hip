@@ -148,6 +148,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attention_split_kernel(cons
                                                                          int Npad, int H, const int* __restrict__ q_rows,
                                                                          const int* __restrict__ q_count, int n_main,
                                                                          __bf16* __restrict__ out3) {
+    scp::claim_vgprs<256>();                                    // bf16 MFMAs: two wavefronts fill a SIMD's register file (scp_common.h)
     // per buffer: K planes 3 x [32 keys][64 d] bf16 (128 B rows), V^T planes 3 x [64 d][32 keys] bf16 (64 B rows)
     __shared__ __attribute__((aligned(16))) char k_lds[2][3 * 4096];
     __shared__ __attribute__((aligned(16))) char v_lds[2][3 * 4096];

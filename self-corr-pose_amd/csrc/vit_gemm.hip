@@ -299,6 +299,7 @@ __global__ __launch_bounds__(THREADS, 2) void vit_gemm_kernel(const GemmArgs g) 
     __shared__ __attribute__((aligned(16))) float lds[Big::LDS_BYTES / 4];
     static_assert(4 * 32 * 36 * 4 <= Big::LDS_BYTES, "the plane epilogue's four staging blocks (run_tile) fit the big tile's ring");
     // row count: host value, or read from the device (rows selected by an earlier kernel, no host round trip)
+    if constexpr (CORE != 0) scp::claim_vgprs<256>();          // bf16 MFMAs: two wavefronts fill a SIMD's register file (scp_common.h)
     int M = g.M;
     if (g.m_dev) M = min(max(__builtin_amdgcn_readfirstlane(*g.m_dev), 0), g.M);
     if (M <= 0) return;

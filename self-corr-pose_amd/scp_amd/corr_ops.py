@@ -203,7 +203,7 @@ class FeatureVertexMatchFused(Function):
         ctx.cfg = (float(tau_img), float(tau_mesh), hf, wf)
         if grid_half is None:
             return pooled, match, imatch
-        # the bridge outputs are constants of this node: their gradient reaches `pooled` through ColsSoftArgmaxPrecomputed
+        # the bridge outputs are constants of this node: their gradient reaches `pooled` through BridgeInputs
         bridge_stat = bridge_stat.transpose(1, 2).contiguous()          # [B,2,V], the layout scp_dual_softmax_backward reads
         ctx.mark_non_differentiable(bridge_xy, bridge_stat)
         return pooled, match, imatch, bridge_xy, bridge_stat
@@ -224,23 +224,6 @@ class FeatureVertexMatchFused(Function):
             capi.opt_ptr(_c(g_pooled), "g_pooled"), capi.opt_ptr(g_img, "g_img"), capi.opt_ptr(g_mesh, "g_mesh"),
             capi.current_stream()), "scp_fvm_backward")
         return g_img, g_mesh, None, None, None, None, None, None, None, None
-
-
-class ColsSoftArgmaxPrecomputed(Function):
-    """ColsSoftArgmax (no masks) whose forward result already exists: out [N,2,Q] and stats [N,2,Q] were produced by the kernel that
-    produced `scores` (FeatureVertexMatchFused with grid_half); only the backward runs here."""
-
-    @staticmethod
-    def forward(ctx, scores, grid, tau, out, stats):
-        ctx.save_for_backward(scores, _c(grid), out, stats)
-        ctx.tau = float(tau)
-        return out.clone()
-
-    @staticmethod
-    def backward(ctx, g_out):
-        scores, grid, out, stats = ctx.saved_tensors
-        g = dual_backward(scores, None, None, None, (stats, out, _c(g_out), grid, ctx.tau), None)
-        return g, None, None, None, None
 
 
 def pp_fusable(src_feat, tgt_feat):
@@ -285,6 +268,31 @@ class PixelPixelSoftArgmax(Function):
             capi.dev_ptr(stats, "stats"), capi.dev_ptr(_c(g_out), "g_out"), capi.opt_ptr(g_src, "g_src"), capi.opt_ptr(g_tgt, "g_tgt"),
             capi.current_stream()), "scp_pp_softargmax_backward")
         return g_src, g_tgt, None, None, None, None
+
+
+class BridgeInputs(Function):
+    """The two things ops.vertex_bridge_match reads from the pooled scores [B,P4,V], as ONE autograd node: the K selected rows of every
+    pair (`rows` [N*K] indices into the [B*P4] rows) and the per-vertex column soft-argmax (already computed: out / stats [B,2,V] from
+    FeatureVertexMatchFused).  Backward: the column part writes the whole gradient tensor once (scp_dual_softmax_backward), the
+    gathered rows' gradients are added into it in place -- separately these were a zero-fill + scatter, a full write and autograd's
+    sum of the two (5 passes over 84 MB instead of 2)."""
+
+    @staticmethod
+    def forward(ctx, scores, rows, grid, tau, out, stats):
+        ctx.save_for_backward(scores, rows, _c(grid), out, stats)
+        ctx.tau = float(tau)
+        return scores.reshape(-1, scores.shape[-1]).index_select(0, rows), out.clone()
+
+    @staticmethod
+    def backward(ctx, g_sel, g_out):
+        scores, rows, grid, out, stats = ctx.saved_tensors
+        if g_out is not None:
+            g = dual_backward(scores, None, None, None, (stats, out, _c(g_out), grid, ctx.tau), None)
+        else:
+            g = torch.zeros_like(scores)
+        if g_sel is not None:
+            g.view(-1, g.shape[-1]).index_add_(0, rows, g_sel)
+        return g, None, None, None, None, None
 
 
 class ColsSoftArgmax(Function):

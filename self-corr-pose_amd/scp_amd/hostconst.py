@@ -3,7 +3,8 @@
 `torch.tensor(list, device="cuda")` stages through pageable memory, which blocks the host until the
 stream has drained up to the copy -- one such call in the middle of the step serialises the host with the
 device (measured: 5 ms per call inside the rotation-cycle branch).  These helpers stage through pinned
-memory with an asynchronous copy, and memoise true constants per device."""
+memory with an asynchronous copy (per-call values, consumed on the stream that made them), and memoise true constants per device
+(uploaded synchronously: every stream may read them)."""
 import functools
 
 import torch
@@ -20,7 +21,15 @@ def small_tensor(values, dtype, device):
 
 @functools.lru_cache(maxsize=512)
 def _memo(values, dtype, device_str):
-    return small_tensor(values, dtype, device_str)
+    # A memoised constant is shared by every stream of the step (the render passes run on the main and on the soft-texture side
+    # stream), but an asynchronous upload is ordered only on the stream that happened to ask first: the other stream could read the
+    # buffer before the copy landed -- seen as a first-step-only deviation of the mask / match loss terms (bench loss_delta, round 4).
+    # Constants are therefore uploaded with a blocking copy and the creating stream is drained: once per constant and process.
+    device = torch.device(device_str)
+    t = torch.tensor(values, dtype=dtype).to(device)
+    if device.type == "cuda":
+        torch.cuda.current_stream(device).synchronize()
+    return t
 
 
 def _freeze(v):

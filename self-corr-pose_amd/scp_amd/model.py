@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import dino, fused_losses, losses
+from . import dino, fused_losses, losses, streams
 from .correspondence import Correspondence
 from .encoder import Encoder
 from .mesh import CanonicalMesh
@@ -50,7 +50,7 @@ class MeshNet(nn.Module):
         mean_v = self.mesh.mean_v[None].expand(bsz, -1, -1)
         faces = self.mesh.faces[None].expand(bsz, -1, -1)
 
-        if opts.train and getattr(self, "overlap_dino", True):
+        if opts.train and getattr(self, "overlap_dino", streams.overlap()):
             self.pretrain_corr_net.prefetch_features(img, mask)
         img_feat, mesh_feat, pred_v, rotation, translation, scale = self.encoder(img, mean_v, pp_crop, foc_crop)
         # The rotation-cycle branch (a second, independent encoder pass over the rotated images) only
@@ -58,7 +58,7 @@ class MeshNet(nn.Module):
         # loss work of the main stream (many small, latency-bound kernels); autograd replays each
         # backward node on its forward stream, so the two backward halves overlap as well.
         cycle_side = None
-        if opts.train and img.is_cuda and getattr(self, "overlap_rotation_cycle", True):
+        if opts.train and img.is_cuda and getattr(self, "overlap_rotation_cycle", streams.overlap()):
             if getattr(self, "_cycle_stream", None) is None:
                 self._cycle_stream = torch.cuda.Stream(device=img.device)
             main = torch.cuda.current_stream(img.device)
@@ -80,7 +80,7 @@ class MeshNet(nn.Module):
         # GPU they run on a second side stream.  Both chains are rasteriser launches (VALU-bound, far from filling the device)
         # strung together by small latency-bound kernels, forward and -- autograd replays nodes on their forward stream --
         # backward; side by side they shorten the step's serial middle part.
-        tex_side = opts.train and img.is_cuda and tex is not None and getattr(self, "overlap_texture_pass", True)
+        tex_side = opts.train and img.is_cuda and tex is not None and getattr(self, "overlap_texture_pass", streams.overlap())
         if tex_side:
             if getattr(self, "_tex_stream", None) is None:
                 self._tex_stream = torch.cuda.Stream(device=img.device)

@@ -125,17 +125,18 @@ def vertex_bridge_match(pooled, src_idx, tgt_idx, tgt_pixels, keep, grid_half, t
     so the [N,P,P] matrix and its 86-134 GFLOP GEMM are never formed; (grid @ P_mesh) is one column
     soft-argmax per unique image."""
     num_verts = pooled.shape[-1]
-    if precomputed is not None and precomputed[1] == float(tau_mesh) and precomputed[0].shape == grid_half.shape:
-        # PooledScores.bridge: the kernel that produced `pooled` already took this soft-argmax (same grid values by construction:
-        # both sides interpolate make_meshgrid the same way); only its backward is a pass over pooled
-        mxy = corr_ops.ColsSoftArgmaxPrecomputed.apply(pooled, precomputed[0], tau_mesh, precomputed[2], precomputed[3])
-    else:
-        mxy = cols_softargmax(pooled, None, None, grid_half, tau_mesh)                   # [B,2,V]
     # the K selected rows of each pair's target image, taken straight from pooled[B,P/4,V] (one row gather forward, one row
     # scatter-add backward): no per-pair [N,P/4,V] copy of the pooled scores (168 MB at N = 64) and none of its gradient
     n_pool = pooled.shape[1]
     rows = (tgt_idx[:, None] * n_pool + tgt_pixels).reshape(-1)
-    pc_tgt_sel = pooled.reshape(-1, num_verts).index_select(0, rows).reshape(tgt_pixels.shape[0], tgt_pixels.shape[1], num_verts)
+    if precomputed is not None and precomputed[1] == float(tau_mesh) and precomputed[0].shape == grid_half.shape:
+        # PooledScores.bridge: the kernel that produced `pooled` already took the column soft-argmax (same grid values by
+        # construction: both sides interpolate make_meshgrid the same way); one autograd node for both reads of `pooled`
+        sel, mxy = corr_ops.BridgeInputs.apply(pooled, rows, precomputed[0], tau_mesh, precomputed[2], precomputed[3])
+    else:
+        mxy = cols_softargmax(pooled, None, None, grid_half, tau_mesh)                   # [B,2,V]
+        sel = pooled.reshape(-1, num_verts).index_select(0, rows)
+    pc_tgt_sel = sel.reshape(tgt_pixels.shape[0], tgt_pixels.shape[1], num_verts)
     p_img = torch.softmax(tau_img * pc_tgt_sel, dim=2)                                   # [N,K,V]
     both = (keep[src_idx] & keep[tgt_idx]).to(pooled.dtype)                              # [N,V]
     p_img = p_img * both[:, None, :]

@@ -23,6 +23,8 @@ FlatGradients (used by the Trainer at every world size):
 import torch
 import torch.distributed as dist
 
+from . import streams
+
 
 class FlatGradients:
     def __init__(self, params, process_group=None, bucket_bytes=25 << 20, distributed=None, force_collectives=False):
@@ -64,7 +66,10 @@ class FlatGradients:
         self._global_used_dev = None
         self._used_mismatch = None             # device flag: some rank's used set differed from the established one
         self.launched_in_backward = 0          # buckets whose collective was enqueued from a hook (test / log)
-        self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" and self.active else None
+        # SCP_STREAMS=serial (scp_amd/streams.py): no communication stream and no launches from the gradient hooks -- the buckets go
+        # out from finish(), after backward, so that the reduction kernels never share a compute unit with the backward's bf16-MFMA kernels
+        self.overlap = dev.type != "cuda" or streams.overlap()
+        self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" and self.active and self.overlap else None
         # hooks at every world size: with one rank they only record which parameters received a gradient (finish() needs that
         # to leave the unused ones at grad = None)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
@@ -124,7 +129,7 @@ class FlatGradients:
         self._fired = set()
         self._poisoned = set()
         self.launched_in_backward = 0
-        self._armed = True
+        self._armed = self.overlap
         self._prepared = True
 
     def _launch(self, i):
@@ -142,12 +147,12 @@ class FlatGradients:
         if self._prepared and p.grad is not None and p.grad.data_ptr() != v.data_ptr():     # autograd replaced the view (first-touch steal)
             v.copy_(p.grad)
             p.grad = v
-        if not self._armed:
+        if not self._prepared:
             return
         i = self.bucket_of[id(p)]
         first = id(p) not in self._fired
-        self._fired.add(id(p))
-        if not first or not self.active:
+        self._fired.add(id(p))                            # (also without overlap: finish() tells used from unused parameters by it)
+        if not self._armed or not first or not self.active:
             return
         if id(p) in self._silent:
             # a parameter that had no gradient in the previous step produces one now (an iteration- or flag-dependent

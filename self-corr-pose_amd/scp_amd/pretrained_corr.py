@@ -167,7 +167,7 @@ class PretrainedCorrespondence(nn.Module):
         keys = self.net.key_tokens(img, None if mask is None else self._keep_tokens(mask))
         return keys, self._match_pairs(keys, mask)
 
-    def compute_cycle_loss(self, img, mask, depth_weight, pointcorr):
+    def compute_cycle_loss(self, img, mask, depth_weight, pointcorr, with_images=False):
         num_verts = pointcorr.shape[-1]
         src_idx, tgt_idx = pair_indices(self.divide_kind, self.opts.batch_size, self.opts.repeat, img.device)
         n = src_idx.shape[0]
@@ -182,4 +182,8 @@ class PretrainedCorrespondence(nn.Module):
                                         self.half_grid(1).reshape(2, -1), self.tau_img, self.tau_mesh,
                                         precomputed=getattr(pointcorr, "bridge", None))
         cycle_loss = ((match - pts_src).norm(2, 1) * mask_k).mean()
-        return cycle_loss, pts_src, pts_tgt, match, mask_k, img[src_idx], img[tgt_idx]
+        # the reference also returns the paired images (pretrained_corr.py:139; only its visualisation reads them): two 50 MB
+        # gathers per step at B = 32 that the training step never looks at -- on request only
+        if with_images:
+            return cycle_loss, pts_src, pts_tgt, match, mask_k, img[src_idx], img[tgt_idx]
+        return cycle_loss, pts_src, pts_tgt, match, mask_k, None, None

@@ -13,6 +13,7 @@ import tempfile
 
 import torch
 
+from . import streams
 from .model import MeshNet
 from .optimizers import Optimizers
 from .parallel import FlatGradients
@@ -185,10 +186,9 @@ class Trainer:
         # convolution shape, forward and backward.  It runs without the side streams, so that the search measures
         # undisturbed kernels instead of kernels sharing the device with the ViT / the second encoder pass (the winners
         # are cached per process; a perturbed search can settle on slower solvers for the whole run).
-        serial = self._steps_done == 0 and self.device.type == "cuda"
+        serial = (self._steps_done == 0 or not streams.overlap()) and self.device.type == "cuda"
         if serial:
-            saved = (getattr(self.model, "overlap_dino", True), getattr(self.model, "overlap_rotation_cycle", True),
-                     getattr(self.model, "overlap_texture_pass", True))
+            saved = tuple(getattr(self.model, k, streams.overlap()) for k in ("overlap_dino", "overlap_rotation_cycle", "overlap_texture_pass"))
             self.model.overlap_dino = self.model.overlap_rotation_cycle = self.model.overlap_texture_pass = False
             next_data = None
         try:

@@ -202,8 +202,10 @@ def test_every_wild6d_category_preset_steps(category):
     assert not torch.equal(before, tr.model.mesh.mean_v)
 
 
-def test_lookahead_of_the_frozen_vit_changes_nothing_but_the_schedule():
-    """Trainer.step(data, next_data): the DINO pass of the following batch is enqueued on the side stream before this step's
+def test_lookahead_of_the_frozen_vit_changes_nothing_but_the_schedule(monkeypatch):
+    """SCP_STREAMS=overlap (scp_amd/streams.py; not the default since round 4 -- the mechanism is tested here, with bands that absorb what
+    kernels of different streams do to each other on this part).
+    Trainer.step(data, next_data): the DINO pass of the following batch is enqueued on the side stream before this step's
     backward (Trainer.train() and bench.py do that).  (1) What the look-ahead leaves for the next step -- features and pair
     matching of the NEXT batch, a different tensor than the current one -- is bit-identical to computing them when the step starts;
     (2) four steps on four different batches with and without it end in the same losses and parameters, up to the run-to-run
@@ -214,6 +216,8 @@ def test_lookahead_of_the_frozen_vit_changes_nothing_but_the_schedule():
     from scp_amd.trainer import Trainer
     import scenes
     import synth
+    from scp_amd import streams
+    monkeypatch.setattr(streams, "MODE", "overlap")
     dino.ALLOW_RANDOM_INIT = True
     batches = [synth.make_batch(2, 2, 256, seed=10 + i, device="cuda") for i in range(4)]
     runs, state = {}, None
