@@ -327,7 +327,9 @@ def _rccl_two_rank_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", rank=rank, world_size=world)
+    from scp_amd import streams
     from scp_amd.parallel import FlatGradients
+    streams.MODE = "overlap"                 # this test is about the buckets that go out from inside backward (scp_amd/streams.py)
     torch.manual_seed(0)
     net = torch.nn.Sequential(*[torch.nn.Linear(256, 256) for _ in range(6)]).cuda()
     red = FlatGradients(net.parameters(), bucket_bytes=2 * (256 * 256 + 256) * 4)
@@ -356,10 +358,14 @@ def test_two_rank_rccl_gradient_equals_joint_batch():
 
 
 @pytest.mark.gpu
-def test_flat_gradients_over_rccl_single_rank():
-    """the CUDA side of the overlapped all-reduce (communication stream, events, async RCCL work objects, views with
-    channels_last strides) on ONE GPU: a 1-rank nccl group with force_collectives -- the sum over one rank must equal plain
-    autograd, buckets must go out from the hooks, and a second step must reuse the same buffers"""
+@pytest.mark.parametrize("mode", ["overlap", "serial"])
+def test_flat_gradients_over_rccl_single_rank(mode, monkeypatch):
+    """the CUDA side of the all-reduce (views with channels_last strides, async RCCL work objects; SCP_STREAMS=overlap: communication
+    stream, events, buckets launched from the gradient hooks; serial, the default: no communication stream, every bucket goes out from
+    finish()) on ONE GPU: a 1-rank nccl group with force_collectives -- the sum over one rank must equal plain autograd and a second
+    step must reuse the same buffers"""
+    from scp_amd import streams
+    monkeypatch.setattr(streams, "MODE", mode)
     for p in (ROOT, os.path.join(ROOT, "self-corr-pose_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -373,13 +379,16 @@ def test_flat_gradients_over_rccl_single_rank():
         x = torch.randn(4, 3, 16, 16, device="cuda").contiguous(memory_format=torch.channels_last)
         ref = torch.autograd.grad(net(x).square().sum(), list(net.parameters()))
         red = FlatGradients(net.parameters(), bucket_bytes=4096, distributed=True, force_collectives=True)
-        assert red.active and red.comm_stream is not None and len(red.buckets) > 1
+        assert red.active and (red.comm_stream is not None) == (mode == "overlap") and len(red.buckets) > 1
         for step in range(2):
             red.prepare()
             net(x).square().sum().backward()
             flat = red.finish()
             torch.cuda.synchronize()
-            assert red.launched_in_backward >= len(red.buckets) - 1, (red.launched_in_backward, len(red.buckets))
+            if mode == "overlap":
+                assert red.launched_in_backward >= len(red.buckets) - 1, (red.launched_in_backward, len(red.buckets))
+            else:
+                assert red.launched_in_backward == 0
             for p, g in zip(net.parameters(), ref):
                 assert p.grad.data_ptr() == red.views[id(p)].data_ptr() and p.grad.stride() == p.stride()
                 torch.testing.assert_close(p.grad, g, rtol=1e-5, atol=1e-6)
