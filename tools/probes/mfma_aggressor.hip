@@ -1,0 +1,66 @@
+// tools/probes/mfma_aggressor.hip -- which matrix instruction disturbs its SIMD neighbours?  (tools/race_repro.py)
+// Register-only kernels: every wavefront issues `iters` MFMAs of ONE kind on constant operands (no LDS, no memory traffic but one
+// store at the end), ~40 vector registers, so that foreign wavefronts fit beside them on every SIMD.
+//   hipcc -O3 --offload-arch=gfx950 -shared -fPIC tools/probes/mfma_aggressor.hip -o tools/probes/libmfma_aggr.so
+#include <hip/hip_runtime.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int KIND>
+__global__ __launch_bounds__(256) void aggressor(float* out, int iters, float seed) {
+    const int lane = threadIdx.x & 63;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 a8, b8;
+    f16x8 ha, hb;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        a8[i] = (__bf16)(seed * (float)(lane + i) * 1e-3f);
+        b8[i] = (__bf16)(seed * (float)(lane - i) * 1e-3f);
+        ha[i] = (_Float16)(seed * (float)(lane + i) * 1e-3f);
+        hb[i] = (_Float16)(seed * (float)(lane - i) * 1e-3f);
+    }
+    const float fa = seed * lane * 1e-3f, fb = seed * (63 - lane) * 1e-3f;
+    for (int k = 0; k < iters; k++) {
+        if (KIND == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc, 0, 0, 0);
+        if (KIND == 1) acc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc4, 0, 0, 0);
+        if (KIND == 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, acc, 0, 0, 0);
+        if (KIND == 3) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+        if (KIND == 5) {          // the bf16 instruction at a fraction of its rate: one MFMA (32 cycles of the pipe), then ~64 * 7 idle cycles
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc, 0, 0, 0);
+            __builtin_amdgcn_s_sleep(7);
+        }
+        if (KIND == 6) {          // ... at about half rate
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc, 0, 0, 0);
+            asm volatile("s_nop 15");
+            asm volatile("s_nop 15");
+        }
+        if (KIND == 4) {          // no matrix instruction: the same loop on the vector ALU
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = __builtin_fmaf(acc[r], 0.999f, fa);
+        }
+    }
+    float s = acc4[0] + acc4[1] + acc4[2] + acc4[3];
+#pragma unroll
+    for (int r = 0; r < 16; r++) s += acc[r];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+extern "C" int mfma_aggressor(int kind, float* out, int blocks, int iters, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (kind) {
+        case 0: hipLaunchKernelGGL(aggressor<0>, dim3(blocks), dim3(256), 0, st, out, iters, 1.f); break;
+        case 1: hipLaunchKernelGGL(aggressor<1>, dim3(blocks), dim3(256), 0, st, out, iters, 1.f); break;
+        case 2: hipLaunchKernelGGL(aggressor<2>, dim3(blocks), dim3(256), 0, st, out, iters, 1.f); break;
+        case 3: hipLaunchKernelGGL(aggressor<3>, dim3(blocks), dim3(256), 0, st, out, iters, 1.f); break;
+        case 5: hipLaunchKernelGGL(aggressor<5>, dim3(blocks), dim3(256), 0, st, out, iters, 1.f); break;
+        case 6: hipLaunchKernelGGL(aggressor<6>, dim3(blocks), dim3(256), 0, st, out, iters, 1.f); break;
+        default: hipLaunchKernelGGL(aggressor<4>, dim3(blocks), dim3(256), 0, st, out, iters, 1.f); break;
+    }
+    return (int)hipGetLastError();
+}

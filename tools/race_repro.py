@@ -42,6 +42,12 @@ f_verts = torch.randn(32, 642, 3, generator=_g).to(dev)
 f_mask = (torch.rand(32, 4096, generator=_g) > 0.4).float().to(dev)
 f_grid = (torch.rand(2, 4096, generator=_g) * 2 - 1).to(dev)
 VICTIM = os.environ.get("VICTIM", "raster")
+import ctypes  # noqa: E402
+MFMA_KINDS = {"mfma_bf16_32": 0, "mfma_bf16_16": 1, "mfma_f16_32": 2, "mfma_f32": 3, "valu": 4, "mfma_bf16_slow": 5, "mfma_bf16_half": 6}
+MFMA_ITERS = {"mfma_bf16_32": 4000, "mfma_bf16_16": 8000, "mfma_f16_32": 4000, "mfma_f32": 2000, "valu": 2000, "mfma_bf16_slow": 500, "mfma_bf16_half": 2000}      # ~0.1-0.3 ms per launch
+_aggr_path = os.path.join(ROOT, "tools", "probes", "libmfma_aggr.so")
+AGGR = ctypes.CDLL(_aggr_path) if os.path.exists(_aggr_path) else None
+aggr_out = torch.empty(2048 * 256, device=dev)
 P = dict(fv=fv_t.reshape(B, -1, 9).contiguous(), tex=tex.reshape(B, -1, 3, 3).contiguous(), fi=torch.zeros(B, fv_t.shape[1], 27, device=dev),
          ai=torch.zeros(B, 2, S, S, device=dev), sc=torch.ones(B, 4, S, S, device=dev))
 
@@ -138,6 +144,11 @@ def work(kind, reps):
                 cv, xin = CONVS[kind]
                 for _k in range(4):
                     fused_conv.conv_bias_leaky(xin, cv)
+            elif kind in MFMA_KINDS:               # register-only loops of ONE matrix instruction (tools/probes/mfma_aggressor.hip)
+                for _k in range(4):
+                    code = AGGR.mfma_aggressor(MFMA_KINDS[kind], ctypes.c_void_p(aggr_out.data_ptr()), 2048, MFMA_ITERS[kind],
+                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                    assert code == 0, code
             elif kind == "split":                  # fp32 -> three bf16 planes (v_cvt_pk_bf16_f32), no matrix instruction
                 for _k in range(4):
                     dino.split_tiled(x0)
