@@ -64,3 +64,32 @@ extern "C" int mfma_aggressor(int kind, float* out, int blocks, int iters, void*
     }
     return (int)hipGetLastError();
 }
+
+// ---- victims: deterministic register-only loops, one ingredient each; out[i] depends on i only --------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void victim(float* out, int iters) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float x = 1.0f + (float)(i & 1023) * 1e-3f, y = 0.5f + (float)(i >> 10) * 1e-4f;
+    for (int k = 0; k < iters; k++) {
+        if (KIND == 0) x = x / (y + 1.0f) + 1.25f;                                   // IEEE fp32 division (v_div_scale / v_div_fmas / v_div_fixup)
+        if (KIND == 1) x = (float)(1.0 / (1.0 + (double)x * 0.5)) + y;               // conversions + double division
+        if (KIND == 2) { if (((i + k) & 3) == 0) x = x * 0.99f + y; else if (x > 1.5f) x = x * 0.5f + 0.75f; else x = x * 1.01f + 0.01f; }   // divergence
+        if (KIND == 3) x = __expf(-x * 0.1f) + sqrtf(x + y) * 0.5f + __frcp_rn(x + 2.0f);   // transcendental unit
+        if (KIND == 4) x = __builtin_fmaf(x, 0.999f, y * 0.001f);                     // plain fma chain
+        if (KIND == 5) { const float m = fmaxf(x, y), n = fminf(x, y); x = (m > 1.2f ? m * 0.9f : m + 0.1f) + (n < 0.6f ? 0.05f : -0.01f); }   // compares / selects
+    }
+    out[i] = x;
+}
+
+extern "C" int probe_victim(int kind, float* out, int blocks, int iters, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (kind) {
+        case 0: hipLaunchKernelGGL(victim<0>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+        case 1: hipLaunchKernelGGL(victim<1>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+        case 2: hipLaunchKernelGGL(victim<2>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+        case 3: hipLaunchKernelGGL(victim<3>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+        case 4: hipLaunchKernelGGL(victim<4>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+        default: hipLaunchKernelGGL(victim<5>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    }
+    return (int)hipGetLastError();
+}

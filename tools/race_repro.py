@@ -93,6 +93,12 @@ def victim():
         if os.environ.get("SETUP_PART") == "sc":
             return sc
         return torch.cat((fi.reshape(-1), sc.reshape(-1)))
+    if VICTIM.startswith("probe:"):        # one-ingredient victims of tools/probes/mfma_aggressor.hip: div, f64, branch, trans, fma, select
+        kind = {"div": 0, "f64": 1, "branch": 2, "trans": 3, "fma": 4, "select": 5}[VICTIM[6:]]
+        o = torch.empty(4096 * 256, device=dev)
+        code = AGGR.probe_victim(kind, ctypes.c_void_p(o.data_ptr()), 4096, 600, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert code == 0, code
+        return o
     raise ValueError(VICTIM)
 
 
