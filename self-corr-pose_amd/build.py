@@ -19,7 +19,11 @@ ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-munsafe-fp-atomics",
           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function"]
 # per-file extra flags
-EXTRA = {"softras.hip": ["-ffp-contract=off"] + (["-DSCP_FAST_GRAD_DIV"] if os.environ.get("SCP_FAST_GRAD_DIV") == "1" else []), "imgops.hip": ["-ffp-contract=off"], "softras_f64.hip": ["-ffp-contract=off"]}
+# -fno-slp-vectorize (rasteriser files): no packed-fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 ...).  Round 4, DESIGN 5.2: with them the
+# rasteriser kernels computed wrong values whenever another kernel on the device issued the K-doubled 16-bit MFMAs of gfx950
+# (tools/race_repro.py: 60 of 60 passes next to a register-only bf16-MFMA loop; 0 of 60 built this way; not slower).
+EXTRA = {"softras.hip": ["-ffp-contract=off", "-fno-slp-vectorize"] + (["-DSCP_FAST_GRAD_DIV"] if os.environ.get("SCP_FAST_GRAD_DIV") == "1" else []),
+         "imgops.hip": ["-ffp-contract=off"], "softras_f64.hip": ["-ffp-contract=off", "-fno-slp-vectorize"]}
 
 
 def sources():

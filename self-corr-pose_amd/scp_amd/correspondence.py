@@ -72,6 +72,11 @@ class Correspondence:
             self._half_grid = F.interpolate(self.meshgrid.reshape(2, self.hf, self.wf)[None], (self.hf // 2, self.wf // 2),
                                             mode="bilinear")
             self._half_grid_key = key
+            if self._half_grid.is_cuda:
+                # cached and read by every stream of the step, but enqueued on whichever stream asked first (SCP_STREAMS=overlap: a side
+                # stream): drained once, so that no other stream can read it before it exists (seen as a first-step deviation of the
+                # bridge's column soft-argmax, tools/first_step_flake.py)
+                torch.cuda.current_stream(self._half_grid.device).synchronize()
         return self._half_grid.expand(bsz, -1, -1, -1)
 
     def compute_rotation_cycle_loss(self, src_img, src_mask, src_img_feat, encoder, angle=None):

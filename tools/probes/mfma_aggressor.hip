@@ -76,6 +76,14 @@ __global__ __launch_bounds__(256) void victim(float* out, int iters) {
         if (KIND == 2) { if (((i + k) & 3) == 0) x = x * 0.99f + y; else if (x > 1.5f) x = x * 0.5f + 0.75f; else x = x * 1.01f + 0.01f; }   // divergence
         if (KIND == 3) x = __expf(-x * 0.1f) + sqrtf(x + y) * 0.5f + __frcp_rn(x + 2.0f);   // transcendental unit
         if (KIND == 4) x = __builtin_fmaf(x, 0.999f, y * 0.001f);                     // plain fma chain
+        if (KIND == 6) {          // packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: VOP3P, the encoding family of the MFMAs)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 v = {x, y};
+            const f32x2 c = {0.999f, 1.001f}, d = {0.001f, -0.0005f};
+            v = v * c + d;
+            v = v * v.yx * (f32x2){0.5f, 0.5f} + (f32x2){0.25f, 0.25f};
+            x = v.x; y = v.y;
+        }
         if (KIND == 5) { const float m = fmaxf(x, y), n = fminf(x, y); x = (m > 1.2f ? m * 0.9f : m + 0.1f) + (n < 0.6f ? 0.05f : -0.01f); }   // compares / selects
     }
     out[i] = x;
@@ -89,6 +97,7 @@ extern "C" int probe_victim(int kind, float* out, int blocks, int iters, void* s
         case 2: hipLaunchKernelGGL(victim<2>, dim3(blocks), dim3(256), 0, st, out, iters); break;
         case 3: hipLaunchKernelGGL(victim<3>, dim3(blocks), dim3(256), 0, st, out, iters); break;
         case 4: hipLaunchKernelGGL(victim<4>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+        case 6: hipLaunchKernelGGL(victim<6>, dim3(blocks), dim3(256), 0, st, out, iters); break;
         default: hipLaunchKernelGGL(victim<5>, dim3(blocks), dim3(256), 0, st, out, iters); break;
     }
     return (int)hipGetLastError();

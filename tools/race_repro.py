@@ -51,6 +51,13 @@ aggr_out = torch.empty(2048 * 256, device=dev)
 P = dict(fv=fv_t.reshape(B, -1, 9).contiguous(), tex=tex.reshape(B, -1, 3, 3).contiguous(), fi=torch.zeros(B, fv_t.shape[1], 27, device=dev),
          ai=torch.zeros(B, 2, S, S, device=dev), sc=torch.ones(B, 4, S, S, device=dev))
 
+_gl = torch.Generator().manual_seed(11)
+LIBV = dict(cv=torch.nn.Conv2d(128, 128, 3, padding=1).to(dev),
+            xin=torch.randn(32, 128, 32, 32, generator=_gl).to(dev).contiguous(memory_format=torch.channels_last),
+            src=F.normalize(torch.randn(32, 64, 1024, generator=_gl), 2, 1).to(dev), tgt=F.normalize(torch.randn(32, 64, 1024, generator=_gl), 2, 1).to(dev),
+            m=(torch.rand(32, 1024, generator=_gl) > 0.4).float().to(dev), g=(torch.rand(32, 2, 1024, generator=_gl) * 2 - 1).to(dev),
+            sc=torch.randn(32, 1024, 642, generator=_gl).to(dev), g2=(torch.rand(2, 1024, generator=_gl) * 2 - 1).to(dev))
+
 
 def victim():
     if VICTIM == "raster":
@@ -93,8 +100,23 @@ def victim():
         if os.environ.get("SETUP_PART") == "sc":
             return sc
         return torch.cat((fi.reshape(-1), sc.reshape(-1)))
-    if VICTIM.startswith("probe:"):        # one-ingredient victims of tools/probes/mfma_aggressor.hip: div, f64, branch, trans, fma, select
-        kind = {"div": 0, "f64": 1, "branch": 2, "trans": 3, "fma": 4, "select": 5}[VICTIM[6:]]
+    if VICTIM.startswith("lib:"):          # other kernels of this library as victims (deterministic forward passes)
+        k = VICTIM[4:]
+        if k == "conv":                    # encoder 3x3 convolution (split main loop unless SCP_CONV_GEMM=fp32), 128 ch 32 x 32
+            return fused_conv.conv_bias_leaky(LIBV["xin"], LIBV["cv"])
+        if k == "pp":                      # pixel <-> pixel soft-argmax forward (fp32 MFMA; csrc/corr_pp.hip)
+            return corr_ops.PixelPixelSoftArgmax.apply(LIBV["src"], LIBV["tgt"], LIBV["m"], LIBV["m"], LIBV["g"], 10.)
+        if k == "cols":                    # column soft-argmax over [32,1024,642] (csrc/corr.hip)
+            return corr_ops.cols_forward(LIBV["sc"], None, None, LIBV["g2"], 10.)[0]
+        if k == "gemm32":                  # ViT linear on the fp32 matrix cores
+            return dino.vit_linear(x0, blk.mlp.fc1.weight, blk.mlp.fc1.bias, epilogue=dino.GEMM_BIAS, mode="fp32")
+        if k == "gemm":                    # ViT linear on the split (bf16) main loop
+            return dino.vit_linear(x0, blk.mlp.fc1.weight, blk.mlp.fc1.bias, epilogue=dino.GEMM_BIAS, mode="split")
+        if k == "stats":
+            return dino.row_mean_rstd(x0, 1e-6)
+        raise ValueError(k)
+    if VICTIM.startswith("probe:"):        # one-ingredient victims of tools/probes/mfma_aggressor.hip: div, f64, branch, trans, fma, select, pk
+        kind = {"div": 0, "f64": 1, "branch": 2, "trans": 3, "fma": 4, "select": 5, "pk": 6}[VICTIM[6:]]
         o = torch.empty(4096 * 256, device=dev)
         code = AGGR.probe_victim(kind, ctypes.c_void_p(o.data_ptr()), 4096, 600, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert code == 0, code
