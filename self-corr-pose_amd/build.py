@@ -18,12 +18,36 @@ ARCH = "gfx950"
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-munsafe-fp-atomics",
           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function"]
-# per-file extra flags
-# -fno-slp-vectorize (rasteriser files): no packed-fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 ...).  Round 4, DESIGN 5.2: with them the
-# rasteriser kernels computed wrong values whenever another kernel on the device issued the K-doubled 16-bit MFMAs of gfx950
-# (tools/race_repro.py: 60 of 60 passes next to a register-only bf16-MFMA loop; 0 of 60 built this way; not slower).
-EXTRA = {"softras.hip": ["-ffp-contract=off", "-fno-slp-vectorize"] + (["-DSCP_FAST_GRAD_DIV"] if os.environ.get("SCP_FAST_GRAD_DIV") == "1" else []),
-         "imgops.hip": ["-ffp-contract=off"], "softras_f64.hip": ["-ffp-contract=off", "-fno-slp-vectorize"]}
+# Packed-fp32 policy.  On gfx950 a wavefront that shares a SIMD with a wavefront issuing the K-doubled 16-bit MFMAs
+# (v_mfma_f32_32x32x16_bf16 & co: every split GEMM / convolution / attention kernel of this build) can get WRONG RESULTS from
+# packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32): round 4 found the rasteriser returning different images for
+# bit-identical inputs (tools/race_repro.py: 60 of 60 passes; 0 of 60 without packed instructions, same speed).  So every file that is
+# not itself a bf16-MFMA GEMM is compiled with the packed-fp32 feature switched off in the back end -- the compiler cannot emit them,
+# neither through the SLP vectoriser nor from explicit vector types -- and tests/test_capi_symbols.py disassembles the objects to
+# assert it.  The GEMM files keep them (they ARE the bf16 kernels; tests/test_coresidency_gpu.py screens them as victims too).
+NO_PACKED = ["-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+GEMM_FILES = ("selftest.hip", "conv_igemm.hip", "conv_wgrad.hip", "vit_gemm.hip", "vit_attn_split.hip", "vit_attn_bf16.hip", "mutual_nn.hip")
+# (selftest.hip is listed with them: it holds the erratum form on purpose, as inline assembly.)
+# -ffp-contract=off: parity -- the reference semantics pinned by the oracle are un-contracted
+_EXTRA = {"softras.hip": ["-ffp-contract=off"] + (["-DSCP_FAST_GRAD_DIV"] if os.environ.get("SCP_FAST_GRAD_DIV") == "1" else []),
+          "imgops.hip": ["-ffp-contract=off"], "softras_f64.hip": ["-ffp-contract=off"]}
+
+
+class _Extra(dict):
+    def get(self, name, default=None):
+        return _EXTRA.get(name, []) + ([] if name in GEMM_FILES else NO_PACKED)
+
+    __getitem__ = get
+
+
+EXTRA = _Extra()
+
+
+def _echo(err):
+    """hipcc's stderr minus the HOST pass' remark about the device-only target feature of NO_PACKED"""
+    for line in (err or "").splitlines():
+        if "'-packed-fp32-ops' is not a recognized feature" not in line:
+            print(line, file=sys.stderr)
 
 
 def sources():
@@ -59,9 +83,11 @@ def build(force=False, verbose=True):
         cmd = [hipcc] + COMMON + EXTRA.get(s, []) + ["-c", src, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((s, subprocess.Popen(cmd)))
+        procs.append((s, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
     for s, p in procs:
-        if p.wait() != 0:
+        _, err = p.communicate()
+        _echo(err)
+        if p.returncode != 0:
             raise RuntimeError("hipcc failed on " + s)
     cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH] + objs + ["-o", OUT]
     if verbose:
@@ -70,5 +96,32 @@ def build(force=False, verbose=True):
     return OUT
 
 
+CONTROL = os.path.join(HERE, "lib", "libscp_hip_slpctl.so")
+
+
+def build_slp_control(verbose=False):
+    """The POSITIVE CONTROL of tests/test_coresidency_gpu.py: the same library with csrc/softras.hip compiled the way it was until round 4
+    (SLP vectoriser on => packed-fp32 instructions with op_sel).  Next to bf16-MFMA wavefronts THAT rasteriser returns wrong images
+    (DESIGN 5.2); a co-residency screen that cannot see it fail proves nothing.  Never loaded by the product (capi.LIB_PATH is the
+    shipped library; only the test's subprocess sets SCP_HIP_LIB to this file)."""
+    build(verbose=verbose)
+    objdir = os.path.join(HERE, "build")
+    src = os.path.join(CSRC, "softras.hip")
+    ctl = os.path.join(objdir, "softras_slpctl.o")
+    deps = [src, __file__] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(ctl) or os.path.getmtime(ctl) < max(os.path.getmtime(d) for d in deps):
+        flags = [f for f in COMMON + EXTRA["softras.hip"] if f not in NO_PACKED]
+        r = subprocess.run([hipcc] + flags + ["-c", src, "-o", ctl], stderr=subprocess.PIPE, text=True)
+        _echo(r.stderr)
+        r.check_returncode()
+    objs = [os.path.join(objdir, s[:-4] + ".o") for s in sources() if s != "softras.hip"] + [ctl]
+    if not os.path.exists(CONTROL) or os.path.getmtime(CONTROL) < max(os.path.getmtime(o) for o in objs):
+        subprocess.check_call([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH] + objs + ["-o", CONTROL])
+    return CONTROL
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    if "--control" in sys.argv:
+        print(build_slp_control())

@@ -12,7 +12,7 @@ import torch
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # SCP_HIP_LIB: an alternative build of the same library (A/B of kernel variants from tools/); the default is the in-tree build
 LIB_PATH = os.environ.get("SCP_HIP_LIB") or os.path.join(_PKG, "lib", "libscp_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class RasterParams(ctypes.Structure):
@@ -50,6 +50,8 @@ SYMBOLS = {
     "scp_soft_rasterize_forward_f64": (ctypes.c_int, [_P] * 5 + [_RP, _P]),
     "scp_soft_rasterize_backward_f64": (ctypes.c_int, [_P] * 8 + [_RP, _P]),
     "scp_selftest_exact_division": (ctypes.c_int, [ctypes.c_ulonglong, ctypes.c_uint, _P, _P]),
+    "scp_selftest_mfma_load": (ctypes.c_int, [_I, _P, _I, _I, _P, _P]),
+    "scp_selftest_packed_fp32": (ctypes.c_int, [_I, _P, _I, _I, _P]),
     "scp_vit_linear": (ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 4 + [_P]),
     "scp_vit_linear_rows": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "scp_split_bf16x3_tiled_elements": (ctypes.c_size_t, [_I, _I]),
