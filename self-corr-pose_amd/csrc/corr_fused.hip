@@ -253,7 +253,10 @@ __global__ __launch_bounds__(256) void fvm_forward_kernel(const FvmArgs a) {
         if (half == 0) *reinterpret_cast<float4*>(&colred[buf][wave][l31][0]) = make_float4(cm, se, sx, sy);
         float pq[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) pq[j] = 0.25f * ((accP[4 * j] + accP[4 * j + 1]) + (accP[4 * j + 2] + accP[4 * j + 3]));
+        // registers 4j .. 4j+3 = (row 0, x), (row 1, x), (row 0, x+1), (row 1, x+1) of the cell (strip_pixel); summed in the association of
+        // ATen's bilinear kernel, horizontal neighbours first -- 0.25 * ((a + b) + (c + d)) -- because at the mask border a cell mixes
+        // -1e5 with real scores and the order of the additions decides the rounding (pretrained_corr.py:120-123; G4 fixture)
+        for (int j = 0; j < 4; j++) pq[j] = 0.25f * ((accP[4 * j] + accP[4 * j + 2]) + (accP[4 * j + 1] + accP[4 * j + 3]));
         if (v0 + l31 < a.V) {
 #pragma unroll
             for (int j = 0; j < 4; j++) pooled_col[(size_t)(2 * j) * a.V + v0] = pq[j];

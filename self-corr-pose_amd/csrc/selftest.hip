@@ -38,6 +38,10 @@ __global__ __launch_bounds__(256) void mfma_load_kernel(float* out, int iters, c
     for (int k = 0; k < iters; k++) {
         if (KIND == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc, 0, 0, 0);
         if (KIND == 1) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+        if (KIND == 2) {          // the bf16 instruction in bursts: one MFMA, then the matrix pipe idles for ~450 cycles
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc, 0, 0, 0);
+            __builtin_amdgcn_s_sleep(7);
+        }
         // a persistent load: leave as soon as the host-side screen raises *stop (polled every 256 instructions; `iters` bounds the
         // launch whatever happens to the flag, so a failed test cannot leave the device spinning)
         if (stop != nullptr && (k & 255) == 255 && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
@@ -87,6 +91,7 @@ extern "C" int scp_selftest_mfma_load(int kind, float* out, int blocks, int iter
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (kind == 0) hipLaunchKernelGGL(mfma_load_kernel<0>, dim3(blocks), dim3(256), 0, st, out, iters, stop);
     else if (kind == 1) hipLaunchKernelGGL(mfma_load_kernel<1>, dim3(blocks), dim3(256), 0, st, out, iters, stop);
+    else if (kind == 2) hipLaunchKernelGGL(mfma_load_kernel<2>, dim3(blocks), dim3(256), 0, st, out, iters, stop);
     else return scp::fail(hipErrorInvalidValue, "scp_selftest_mfma_load: kind");
     return scp::check_launch("selftest_mfma_load");
 }

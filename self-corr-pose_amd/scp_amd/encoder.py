@@ -44,11 +44,15 @@ class Encoder(nn.Module):
                 and not bool(getattr(self.opts, "mixed_bf16", False)))
 
     def _normalized(self, img):
-        x = imgops.jitter_normalize(img, self.random_jitter, self.resnet_transform)
-        if x.is_cuda:
-            # NHWC end to end: MIOpen's fp32 implicit-GEMM kernels and PyTorch's NHWC bilinear
-            # upsampling are ~2x faster on gfx950 than the NCHW paths for these shapes (measured,
-            # tools/conv_diag.py); values are layout independent
+        # The trunk runs NHWC end to end, but its first layer -- the own 7x7 stem kernel (csrc/conv_stem.hip) -- reads the 3-channel image as
+        # NCHW rows and writes NHWC: when it will run, the normalised image is produced NCHW and never converted (it used to be written
+        # NHWC and copied back, 2 x 25 MB per pass at B = 32); otherwise (stock stem: bf16 autocast, eval-mode BatchNorm, ...) NHWC.
+        from .fused_conv import stem_takes_own_kernels
+        r = self.backbone.resnet
+        nchw = img.is_cuda and stem_takes_own_kernels(img.detach().float() if img.dtype != torch.float32 else img.detach(), r.conv1, r.bn1,
+                                                      autocast=bool(getattr(self.opts, "mixed_bf16", False)))
+        x = imgops.jitter_normalize(img, self.random_jitter, self.resnet_transform, channels_last=not nchw)
+        if x.is_cuda and not nchw:
             x = x.contiguous(memory_format=torch.channels_last)
         return x
 

@@ -114,7 +114,10 @@ def weight_planes(conv, with_dgrad):
     key = (w.data_ptr(), w._version, str(w.device), WEIGHT_EPOCH[0])
     cache = conv.__dict__.get("_scp_planes")
     if cache is None:
-        cache = conv.__dict__["_scp_planes"] = {"key": None}
+        cache = conv.__dict__["_scp_planes"] = {"key": None, "readers": {}}
+        # whoever loads a state dict into the module writes the weight without touching the key above
+        conv.register_load_state_dict_post_hook(lambda module, incompatible: invalidate())
+    cur = torch.cuda.current_stream(w.device)
     stale = cache["key"] != key
     if stale or (with_dgrad and "dgrad" not in cache):
         if capi.CAPTURING:
@@ -125,13 +128,43 @@ def weight_planes(conv, with_dgrad):
         build_dgrad = with_dgrad or "dgrad" in cache
         if build_dgrad and "dgrad" not in cache:
             cache["dgrad"] = torch.empty(tiled_planes_numel(cin, k * k * cout), dtype=torch.bfloat16, device=w.device)
+        # the buffers are rewritten in place: streams that read the previous contents (side-stream encoder pass, look-ahead) finish first
+        for other in cache["readers"].values():
+            cur.wait_stream(other)
+        cache["readers"] = {}
         wd = w.detach()
         # one launch fills both plane sets (a "fwd" set that is current is rewritten with the values it already holds)
         capi.check(capi.lib().scp_conv_weight_planes(ctypes.c_void_p(wd.data_ptr()), wd.stride(0), wd.stride(1), wd.stride(2), wd.stride(3),
                                                      cout, cin, k, _ptr(cache["fwd"]), _ptr(cache["dgrad"] if build_dgrad else None),
                                                      capi.current_stream()), "conv_weight_planes")
         cache["key"] = key
+        cache["built_on"] = cur
+        cache["built"] = torch.cuda.Event()
+        cache["built"].record(cur)
+        if CHECK_PLANES:
+            cache["checksum"] = wd.double().sum()
+    elif cache.get("built_on") is not None and cur != cache["built_on"] and not capi.CAPTURING:
+        # a consumer on another stream than the one that built them: ordered behind the build, remembered for the next rebuild
+        if cur.cuda_stream not in cache["readers"]:
+            cur.wait_event(cache["built"])
+            cache["readers"][cur.cuda_stream] = cur
+    if CHECK_PLANES and not capi.CAPTURING and "checksum" in cache and not torch.equal(cache["checksum"], w.detach().double().sum()):
+        raise RuntimeError("scp_amd.fused_conv: the weight of %r changed without its split planes being rebuilt (a write through .data? "
+                           "call fused_conv.invalidate() after such writes)" % (conv,))
     return cache
+
+
+# SCP_CHECK_PLANES=1: every use of cached planes compares a checksum of the weight with the one taken when they were built (one host
+# sync per convolution call: a debugging aid for code that updates weights behind autograd's back)
+CHECK_PLANES = os.environ.get("SCP_CHECK_PLANES", "0") == "1"
+
+
+def invalidate():
+    """Every cached plane set is rebuilt at its next use.  Call after writing convolution weights in a way that neither bumps the
+    tensor's version counter nor goes through load_state_dict (both are noticed automatically): `.data` writes -- EMA updates,
+    vector_to_parameters, hand-written broadcasts, optimizers that step through `.data` (scp_amd.optimizers registers this as a
+    post-step hook for exactly that case)."""
+    WEIGHT_EPOCH[0] += 1
 
 
 # bumped by whoever changes weights without going through an optimizer step on the tensor itself (load_state_dict / broadcast via .data)
@@ -354,17 +387,24 @@ class _StemConvBNAct(Function):
         return None, dw, dgamma, dbeta, None, None
 
 
+def stem_takes_own_kernels(x, conv, bn, autocast=None):
+    """whether stem_conv_bn_act(x, conv, bn) will run csrc/conv_stem.hip -- which reads the image as NCHW rows; the encoder asks before
+    choosing the layout of the normalised image (scp_amd/encoder.py), so that no layout copy is made only to be undone"""
+    w = conv.weight
+    autocast = torch.is_autocast_enabled() if autocast is None else autocast
+    return (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 4 and tuple(w.shape) == (64, 3, 7, 7)
+            and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+            and x.shape[1] == 3 and x.shape[2] % 2 == 0 and x.shape[3] % 4 == 0 and x.shape[2] >= 8 and x.shape[3] >= 8
+            and not x.requires_grad and type(bn) is nn.BatchNorm2d and (bn.training or bn.running_mean is None)
+            and not autocast and os.environ.get("SCP_STEM", "own") == "own")
+
+
 def stem_conv_bn_act(x, conv, bn, relu=True):
     """relu(bn(conv(x))) for the 7x7 / stride-2 / pad-3 stem of the ResNet trunk; anything else (CPU, eval-mode BatchNorm, autocast,
     an image that needs a gradient, odd sizes) takes the stock composition"""
     from .fused_bn import bn_act
-    w = conv.weight
-    if (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 4 and tuple(w.shape) == (64, 3, 7, 7)
-            and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
-            and x.shape[1] == 3 and x.shape[2] % 2 == 0 and x.shape[3] % 4 == 0 and x.shape[2] >= 8 and x.shape[3] >= 8
-            and not x.requires_grad and type(bn) is nn.BatchNorm2d and (bn.training or bn.running_mean is None)
-            and not torch.is_autocast_enabled() and os.environ.get("SCP_STEM", "own") == "own"):
-        return _StemConvBNAct.apply(x, w, bn.weight, bn.bias, bn, relu)
+    if stem_takes_own_kernels(x, conv, bn):
+        return _StemConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, bn, relu)
     return bn_act(conv(x), bn, relu=relu)
 
 

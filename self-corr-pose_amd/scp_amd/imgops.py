@@ -106,10 +106,10 @@ class ColorJitter(nn.Module):
         return img
 
 
-def jitter_normalize(img, jitter, normalize):
-    """`normalize(jitter(img))` for the encoder.  CUDA: ONE fused HIP pass that also lands the result in
-    channels_last storage (csrc/imgops.hip; no fallback -- capi raises without the library).  CPU (golden
-    runs, CPU baseline): the torch composition above."""
+def jitter_normalize(img, jitter, normalize, channels_last=True):
+    """`normalize(jitter(img))` for the encoder.  CUDA: ONE fused HIP pass that lands the result in the layout its consumer reads
+    (channels_last for the NHWC convolutions, NCHW for the own 7x7 stem kernel; csrc/imgops.hip; no fallback -- capi raises without
+    the library).  CPU (golden runs, CPU baseline): the torch composition above."""
     if not img.is_cuda or not isinstance(jitter, ColorJitter):
         return normalize(jitter(img))
     from . import capi
@@ -118,7 +118,8 @@ def jitter_normalize(img, jitter, normalize):
     if c != 3:
         raise ValueError("jitter_normalize expects RGB images [N,3,H,W]")
     img = img.contiguous().float()
-    out = torch.empty((n, 3, h, w), dtype=torch.float32, device=img.device, memory_format=torch.channels_last)
+    out = torch.empty((n, 3, h, w), dtype=torch.float32, device=img.device,
+                      memory_format=torch.channels_last if channels_last else torch.contiguous_format)
     L = capi.lib()
     ws = torch.empty(max(1, L.scp_color_jitter_workspace(n) // 4), dtype=torch.float32, device=img.device)
     i4, f3 = ctypes.c_int * 4, ctypes.c_float * 3
@@ -126,7 +127,7 @@ def jitter_normalize(img, jitter, normalize):
     capi.check(L.scp_color_jitter_normalize(
         capi.dev_ptr(img, "img"), n, h, w, i4(*slots), f3(*ratio), f3(*[1.0 - r for r in ratio]),
         float(hue_shift), f3(*normalize.host_mean),
-        f3(*normalize.host_std), 1, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+        f3(*normalize.host_std), int(bool(channels_last)), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
         ws.numel() * 4, capi.current_stream()), "color_jitter_normalize")
     return out
 

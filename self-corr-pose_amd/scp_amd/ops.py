@@ -107,9 +107,11 @@ def pool2x2_scores(pc, hf, wf):
         assert (pc.hf, pc.wf) == (hf, wf)
         return pc.pooled
     b, _, v = pc.shape
-    # one reduction forward, one broadcast backward; equals the bilinear form up to the order of the four
-    # additions (last ulp)
-    return (pc.reshape(b, hf // 2, 2, wf // 2, 2, v).sum((2, 4)) * 0.25).reshape(b, -1, v)
+    # the association of ATen's bilinear kernel for an exact factor 2 -- 0.5 * (0.5 a + 0.5 b) + 0.5 * (0.5 c + 0.5 d) with (a, b) the
+    # horizontal neighbours: scalings by powers of two are exact, so this is 0.25 * ((a + b) + (c + d)) bit for bit.  The order matters
+    # at the mask border, where a cell mixes -1e5 with real scores and the sum is rounded at 2^-7 (the G4 fixture sees it per entry).
+    x = pc.reshape(b, hf // 2, 2, wf // 2, 2, v)
+    return (0.25 * ((x[:, :, 0, :, 0] + x[:, :, 0, :, 1]) + (x[:, :, 1, :, 0] + x[:, :, 1, :, 1]))).reshape(b, -1, v)
 
 
 def vertex_bridge_match(pooled, src_idx, tgt_idx, tgt_pixels, keep, grid_half, tau_img, tau_mesh, precomputed=None):

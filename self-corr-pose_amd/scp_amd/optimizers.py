@@ -36,6 +36,11 @@ class Optimizers:
         on_gpu = any(p.is_cuda for g in groups for p in g)
         self.optimizer = torch.optim.AdamW([{"params": g} for g in groups], lr=lr, betas=(0.9, 0.999),
                                            weight_decay=1e-4, **({"fused": True} if on_gpu else {}))
+        if on_gpu:
+            # an optimizer may step through .data (no version bump on the parameter): the convolutions' cached split planes are keyed
+            # by tensor version AND this epoch (scp_amd/fused_conv.py), so the step itself invalidates them whatever its implementation
+            from . import fused_conv
+            self.optimizer.register_step_post_hook(lambda *a, **k: fused_conv.invalidate())
         max_lrs = [opts.vert_lr_ratio * lr, opts.cam_lr_ratio * lr, lr, lr, lr]
         self.scheduler = torch.optim.lr_scheduler.OneCycleLR(
             self.optimizer, max_lrs, total_steps=self.total_steps, pct_start=0.05, cycle_momentum=False,

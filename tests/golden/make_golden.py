@@ -739,10 +739,88 @@ def gen_data():
     print("  items:", len(ds), " img", tuple(e["img"].shape), e["img"].dtype, " depth", e["depth"].dtype)
 
 
+def gen_pretrained():
+    """G4: the reference's PretrainedCorrespondence -- `match` (pretrained_corr.py:48-104) and `compute_cycle_loss`
+    (:107-140) -- with INJECTED feature maps in place of the DINO ViT (self.net is replaced by a table look-up: image i is the
+    constant image of value i), so that a8 / a9 are pinned stand-alone: mutual-nearest-neighbour indices with their float64 top-2
+    gaps (F16), the top-k selection, the bridged soft match, the loss and its gradient w.r.t. `pointcorr`.
+    4 images = batch 2 x repeat 2 (divide_by_frame), 128 x 128 images => 16 x 16 DINO tokens, corr map 32 x 32, 42 vertices, k = 40."""
+    flags = ref_harness.install()
+    import config  # noqa: F401
+    import model.module.pretrained_corr as pcm
+
+    class _NoDino(torch.nn.Module):             # DINO() loads a checkpoint from disk; the features are injected below
+        def forward(self, x):
+            raise RuntimeError("replaced")
+    pcm.DINO = _NoDino
+    for k, v in dict(img_size=128, corr_h=32, corr_w=32, tau_img=10., tau_mesh=10., pretrain_k=40, divide_fn="frame",
+                     batch_size=2, repeat=2).items():
+        setattr(flags, k, v)
+    net = pcm.PretrainedCorrespondence(flags, mesh=None)
+    g = torch.Generator().manual_seed(23)
+    n_img, C, fs, V, P = 4, 384, 16, 42, 32 * 32
+    feats = F_normalize(torch.randn(n_img, C, fs, fs, generator=g), 1)
+    # the two frames of an instance look alike (as two views of one object do): mutual neighbours exist, gaps are not degenerate
+    feats[1] = F_normalize(feats[0] + 0.35 * torch.randn(C, fs, fs, generator=g), 0)
+    feats[3] = F_normalize(feats[2] + 0.35 * torch.randn(C, fs, fs, generator=g), 0)
+    del net._modules["net"]
+    net.__dict__["net"] = lambda imgs: feats[imgs[:, 0, 0, 0].round().long()]
+    img = torch.arange(n_img, dtype=torch.float32)[:, None, None, None].expand(-1, 3, 128, 128).contiguous()
+    yy, xx = torch.meshgrid(torch.arange(128.), torch.arange(128.), indexing="ij")
+    mask = torch.stack([(((xx - 64 - 6 * i) / 44.) ** 2 + ((yy - 60 + 4 * i) / 50.) ** 2 < 1).float() for i in range(n_img)])
+    depth_weight = (torch.rand(n_img, V, generator=g) > 0.3).float()
+    # masked scores as Correspondence.match leaves them: cosine scores, -1e5 outside the object mask at the corr resolution
+    mask_corr = torch.nn.functional.interpolate(mask[:, None], (32, 32), mode="nearest").reshape(n_img, -1)
+    pc = (torch.rand(n_img, P, V, generator=g) * 2 - 1) * 0.9
+    pointcorr = (pc * (mask_corr[:, :, None] > 0) - 1e5 * (mask_corr[:, :, None] == 0)).requires_grad_(True)
+
+    spy = {}
+    orig_match = net.match
+
+    def match_spy(*a, **k):
+        out = orig_match(*a, **k)
+        spy["match"] = [t.detach().clone() for t in out]
+        return out
+    net.match = match_spy
+    loss, pts_src, pts_tgt, match, mk, _, _ = net.compute_cycle_loss(img, mask, depth_weight, pointcorr)
+    loss.backward(retain_graph=True)
+    grad_full = pointcorr.grad.clone()
+    # the same loss over the selected target pixels whose 2x2 pooling cell does not straddle the mask (a straddling cell averages the
+    # -1e5 sentinel with real scores: its bits depend on the association of ATen's kernel, tests/test_pretrained_golden.py)
+    cells = mask_corr.reshape(n_img, 16, 2, 16, 2)
+    homog = (cells.amax((2, 4)) == cells.amin((2, 4))).reshape(n_img, -1)
+    wc = torch.gather(homog[torch.tensor([1, 0, 3, 2])], 1, spy["match"][3]).float()
+    pointcorr.grad = None
+    loss_wc = ((match - pts_src).norm(2, 1) * mk * wc).mean()
+    loss_wc.backward()
+    grad_wc = pointcorr.grad.clone()
+    pointcorr.grad = grad_full
+    # the discrete selections and how decided they are (float64 scores of the same features)
+    src_idx, tgt_idx = torch.tensor([0, 1, 2, 3]), torch.tensor([1, 0, 3, 2])
+    fd = feats.double().reshape(n_img, C, -1)
+    md = torch.nn.functional.interpolate(mask[:, None], (fs, fs), mode="nearest").reshape(n_img, -1).double()
+    sc = fd[src_idx].permute(0, 2, 1).bmm(fd[tgt_idx])
+    keep = md[src_idx][:, :, None] * md[tgt_idx][:, None, :]
+    sc = sc * (keep > 0) - 1e5 * (keep == 0)
+    top_bw, top_fw = sc.topk(2, dim=1).values, sc.topk(2, dim=2).values
+    save("pretrained_corr_b2x2", feats=feats.numpy(), mask=mask.numpy(), depth_weight=depth_weight.numpy(),
+         pointcorr=pointcorr.detach().numpy(), src_idx=src_idx.numpy(), tgt_idx=tgt_idx.numpy(),
+         nn_bw=sc.max(1).indices.numpy(), nn_fw=sc.max(2).indices.numpy(),
+         gap_bw=(top_bw[:, 0] - top_bw[:, 1]).numpy(), gap_fw=(top_fw[:, :, 0] - top_fw[:, :, 1]).numpy(),
+         match_pts_src=spy["match"][0].numpy(), match_pts_tgt=spy["match"][1].numpy(), indices_match=spy["match"][2].numpy(),
+         topk_indices=spy["match"][3].numpy(), match_mask=spy["match"][4].numpy(),
+         bridge_match=match.detach().numpy(), cycle_loss=np.float64(loss.item()), grad_pointcorr=pointcorr.grad.numpy(),
+         well_conditioned=wc.numpy(), cycle_loss_wc=np.float64(loss_wc.item()), grad_pointcorr_wc=grad_wc.numpy(),
+         meshgrid=net.meshgrid.numpy(), cfg=np.array([128, 32, 32, 40, 2, 2], dtype=np.int64), tau=np.array([10., 10.]))
+    print("  cycle_loss %.6f  |grad| %.3e  min gap bw %.2e fw %.2e (foreground rows)" % (
+        loss.item(), pointcorr.grad.abs().max().item(), float((top_bw[:, 0] - top_bw[:, 1])[md[tgt_idx] > 0].min()),
+        float((top_fw[:, :, 0] - top_fw[:, :, 1])[md[src_idx] > 0].min())))
+
+
 GENERATORS = {"softras": gen_softras, "render": gen_render, "step": gen_step, "corr": gen_corr, "losses": gen_losses,
               "step_laptop": gen_step_laptop, "step_single": gen_step_single, "step_conditioning": gen_step_conditioning,
               "step_conditioning_laptop_b8": gen_step_conditioning_laptop_b8, "step_conditioning_bottle_b32": gen_step_conditioning_bottle_b32,
-              "flatten": gen_flatten, "posefit": gen_posefit, "data": gen_data}
+              "flatten": gen_flatten, "posefit": gen_posefit, "data": gen_data, "pretrained": gen_pretrained}
 
 
 if __name__ == "__main__":
