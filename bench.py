@@ -49,6 +49,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s HBM3E
 FP32_VALU_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 vector peak
 BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix-core peak
 FLOP_PER_PAIR_BWD = 220.0   # ~220 flop per active pair in the backward
+FLOP_PER_PAIR_FWD = 130.0   # ... ~130 in the forward (distance, sigmoid, barycentric clip, softmax update)
 
 
 class KernelTimer:
@@ -688,19 +689,29 @@ def main():
     # ---- the roofline legs: the same K steps again with the hot kernels timed live (HIP events on the stream each one is launched
     # on; in-kernel duration clock for the GEMM family).  strides 5 and 3 are coprime to the 33 / 8 selected launches per step: over
     # the steps every layer shape is sampled evenly.  This loop's own wall time is reported as `instrumented_ms_per_step`.
+    # the other hand-written hot kernels (VERDICT r4 missing #6): the sigma = 1e-3 forward rasteriser, the fused feature<->vertex
+    # matching (forward; backward = its two kernels in one C-ABI call) and the fused mutual-NN -- timed at the C-ABI entry points
+    from scp_amd import capi as capi_mod
+    clib = capi_mod.lib()
+    fwd_softtex = lambda *a: abs(a[9] - 1e-3) < 1e-9        # sigma_val of forward_soft_rasterize(faces, textures, faces_info, aggrs, colours, size, near, far, sigma, ...)
+    anycall = lambda *a, **k: True
     with KernelTimer(native, "backward_soft_rasterize", is_softtex) as kt, \
+            KernelTimer(native, "forward_soft_rasterize", fwd_softtex) as ft, \
+            KernelTimer(clib, "scp_fvm_forward", anycall) as fvf, KernelTimer(clib, "scp_fvm_backward", anycall) as fvb, \
+            KernelTimer(clib, "scp_mutual_nn_fused", anycall) as mnt, \
             KernelTimer(dino_mod, "fused_attention", lambda *a, **k: len(a) <= 6 and k.get("q_rows") is None, stride=3) as at, \
             KernelTimer(dino_mod, "vit_linear", full_gemm, stride=5, on_timed=count_gemm) as gt, \
             KernelClock(dino_mod, "vit_linear", 64 * args.steps + 64, device) as kc:
-        kt.enabled = at.enabled = gt.enabled = True
+        kt.enabled = at.enabled = gt.enabled = ft.enabled = fvf.enabled = fvb.enabled = mnt.enabled = True
         kc.start()
         t1 = time.perf_counter()
         for _ in range(args.steps):
             tr.step(data, next_data=nxt)
         sync()
         instrumented = time.perf_counter() - t1
-        kt.enabled = at.enabled = gt.enabled = False
+        kt.enabled = at.enabled = gt.enabled = ft.enabled = fvf.enabled = fvb.enabled = mnt.enabled = False
         kc.stop()
+        fwd_raster_ms, fvm_fwd_ms, fvm_bwd_ms, mnn_ms = ft.mean_ms(), fvf.mean_ms(), fvb.mean_ms(), mnt.mean_ms()
         gemm_clock = kc.result()
         kernel_ms = kt.mean_ms()
         attn_ms = at.mean_ms()
@@ -752,6 +763,44 @@ def main():
                 raster["valu"] = {"pairs_active": pairs, "flop_per_pair": FLOP_PER_PAIR_BWD, "achieved_TFLOPs": tf,
                                   "peak_TFLOPs": FP32_VALU_PEAK_TF, "frac": tf / FP32_VALU_PEAK_TF}
             others["raster_backward"] = raster
+            if fwd_raster_ms:
+                # forward of the same pass: faces + textures in, faces_info + aggrs_info + soft_colors out
+                fb = 4.0 * B * (n_faces * (9 + 9 + 27) + S * S * (4 + 2))
+                fr = {"kernel": "raster_forward_kernel<softmax,vertex> (sigma=1e-3 texture pass; + the per-face kernel of the same call)",
+                      "bound": "hbm", "achieved": fb / (fwd_raster_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": fb / (fwd_raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic("raster_forward", size_tag),
+                      "avg_launch_ms": fwd_raster_ms, "algorithmic_bytes_per_launch": fb,
+                      "note": "not HBM-bound in any honest accounting: the VALU figure on active pairs is the one that grades it"}
+                if pairs:
+                    tf = pairs * FLOP_PER_PAIR_FWD / (fwd_raster_ms * 1e-3) / 1e12
+                    fr["valu"] = {"pairs_active": pairs, "flop_per_pair": FLOP_PER_PAIR_FWD, "achieved_TFLOPs": tf,
+                                  "peak_TFLOPs": FP32_VALU_PEAK_TF, "frac": tf / FP32_VALU_PEAK_TF}
+                others["raster_forward"] = fr
+        if fvm_fwd_ms and fvm_bwd_ms:
+            P, C = opts.corr_h * opts.corr_w, opts.n_corr_feat
+            prod = 2.0 * B * P * n_verts * C                      # one K = 64 score / gradient product over the [P, V] tile grid
+            io_f = 4.0 * B * (C * P + n_verts * C + P + n_verts * 3 + (P // 4) * n_verts + P * 3 + 2 * n_verts + 2 * P + 2 * n_verts)
+            io_b = 4.0 * B * (2 * C * P + 2 * n_verts * C + (P // 4) * n_verts + P * 3 + 2 * n_verts + 2 * P + 2 * n_verts)
+            for tag, ms, nprod, io, what in (("fvm_forward", fvm_fwd_ms, 1, io_f, "fvm_forward_kernel + column merge (a7 forward: scores, both softmaxes, soft-argmaxes, 2x2 pooling)"),
+                                             ("fvm_backward", fvm_bwd_ms, 3, io_b, "fvm_backward_img_kernel + fvm_backward_mesh_kernel (one C-ABI call; algorithmic = score tile once + "
+                                                                                  "two gradient products, executed = the tile twice)")):
+                tf = nprod * prod / (ms * 1e-3) / 1e12
+                others[tag] = {"kernel": what, "bound": "mfma", "achieved": tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": tf / FP32_VALU_PEAK_TF, "traffic": measured_traffic(tag, size_tag), "avg_launch_ms": ms,
+                               "algorithmic_flops_per_launch": nprod * prod, "algorithmic_bytes_per_launch": io,
+                               "hbm_frac_of_algorithmic_bytes": io / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32) tiles that never leave registers; VALU-bound by the two softmaxes "
+                                       "(~30 VALU instructions per score), DESIGN 4.3"}
+        if mnn_ms:
+            n_pairs, ptok, kdim = B, (S // 8) ** 2, 384           # divide_by_frame: one pair per image
+            fl = 2.0 * n_pairs * ptok * ptok * kdim
+            split = dino_mod.GEMM_MODE == "split"
+            pk = BF16_MFMA_PEAK_TF / 6.0 if split else FP32_VALU_PEAK_TF
+            tf = fl / (mnn_ms * 1e-3) / 1e12
+            others["mutual_nn_fused"] = {"kernel": "mutual_nn_fused_kernel (a8: DINO-key score GEMM + both argmax reductions, no score tensor)",
+                                         "bound": "mfma", "achieved": tf, "peak": pk, "unit": "TFLOP/s", "frac": tf / pk,
+                                         "vs_fp32_mfma_peak": tf / FP32_VALU_PEAK_TF, "traffic": measured_traffic("mutual_nn_fused", size_tag),
+                                         "avg_launch_ms": mnn_ms, "algorithmic_flops_per_launch": fl, "pairs": n_pairs}
         if attn_ms:
             n_tok, heads, hd = (S // 8) ** 2 + 1, 6, 64
             flops = 4.0 * B * heads * n_tok * n_tok * hd

@@ -30,7 +30,7 @@ GEMM_FILES = ("selftest.hip", "conv_igemm.hip", "conv_wgrad.hip", "vit_gemm.hip"
 # (selftest.hip is listed with them: it holds the erratum form on purpose, as inline assembly.)
 # -ffp-contract=off: parity -- the reference semantics pinned by the oracle are un-contracted
 _EXTRA = {"softras.hip": ["-ffp-contract=off"] + (["-DSCP_FAST_GRAD_DIV"] if os.environ.get("SCP_FAST_GRAD_DIV") == "1" else []),
-          "imgops.hip": ["-ffp-contract=off"], "softras_f64.hip": ["-ffp-contract=off"]}
+          "imgops.hip": ["-ffp-contract=off"], "softras_f64.hip": ["-ffp-contract=off"], "project.hip": ["-ffp-contract=off"]}
 
 
 class _Extra(dict):

@@ -50,6 +50,10 @@ SYMBOLS = {
     "scp_soft_rasterize_forward_f64": (ctypes.c_int, [_P] * 5 + [_RP, _P]),
     "scp_soft_rasterize_backward_f64": (ctypes.c_int, [_P] * 8 + [_RP, _P]),
     "scp_selftest_exact_division": (ctypes.c_int, [ctypes.c_ulonglong, ctypes.c_uint, _P, _P]),
+    "scp_project_vertices_forward": (ctypes.c_int, [_P] * 5 + [_I] * 4 + [_P] * 3),
+    "scp_project_vertices_backward": (ctypes.c_int, [_P] * 5 + [_I] * 4 + [_P] * 4),
+    "scp_gradclip_workspace": (ctypes.c_size_t, []),
+    "scp_gradclip": (ctypes.c_int, [_P, ctypes.c_longlong, _F, _P, _P, _P, _I, _F, _F, _F, _P, ctypes.c_size_t, _P, _P]),
     "scp_selftest_mfma_load": (ctypes.c_int, [_I, _P, _I, _I, _P, _P]),
     "scp_selftest_packed_fp32": (ctypes.c_int, [_I, _P, _I, _I, _P]),
     "scp_vit_linear": (ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 4 + [_P]),

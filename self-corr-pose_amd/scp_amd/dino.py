@@ -546,7 +546,34 @@ class _PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(3, embed_dim, kernel_size=patch_size, stride=patch_size)
 
     def forward(self, x):
+        if self._own_gemm_ok(x):
+            return self._forward_gemm(x)
         return self.proj(x).flatten(2).transpose(1, 2)
+
+    def _own_gemm_ok(self, x):
+        """the frozen ViT on the GPU: the patch embedding is one [B * patches, 3 p^2] x [3 p^2, embed] product on the build's own GEMM
+        (vision_transformer_flexible.py:134-149 is a p x p / stride-p convolution = exactly that), no library kernel"""
+        w = self.proj.weight
+        k = w.shape[1] * w.shape[2] * w.shape[3]
+        return (x.is_cuda and x.dim() == 4 and not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad))
+                and w.dtype == torch.float32 and k % 16 == 0 and x.shape[2] % self.patch_size == 0 and x.shape[3] % self.patch_size == 0
+                and (MIXED_OWN_KERNELS or not MIXED_BF16) and os.environ.get("SCP_PATCH_EMBED", "own") == "own")
+
+    def _forward_gemm(self, x):
+        b, c, h, w = x.shape
+        p, n = self.patch_size, self.proj.weight.shape[0]
+        # im2col of non-overlapping patches is a pure permutation: rows = (image, patch row, patch column), K = (channel, ky, kx), the
+        # order of proj.weight.reshape(embed, -1); the result IS the token-major [B, patches, embed] the blocks consume
+        a = x.float().reshape(b, c, h // p, p, w // p, p).permute(0, 2, 4, 1, 3, 5).reshape(b * (h // p) * (w // p), c * p * p)
+        wt = self.proj.weight
+        mode = "fp32" if GEMM_MODE == "fp32" else "split"       # fp32-accurate in every precision mode (3 % of the ViT's flops)
+        key = (wt.data_ptr(), wt._version, mode)
+        cache = self.__dict__.get("_w2d")
+        if cache is None or cache[0] != key:
+            w2d = wt.detach().reshape(n, c * p * p).contiguous()
+            cache = self.__dict__["_w2d"] = (key, w2d, split_weight(w2d) if mode == "split" else None)
+        out = vit_linear(a, cache[1], self.proj.bias.detach(), epilogue=GEMM_BIAS, w_split=cache[2], mode=mode)
+        return out.view(b, -1, n)
 
 
 class VisionTransformer(nn.Module):

@@ -21,8 +21,10 @@ DEFAULTS = dict(
     resnet18_path="pretrain/resnet18-f37072fd.pth",
     # model/tester.py:35-37 (the CUB evaluation and the visualisation flags are not provided)
     eval=False, eval_nocs=False,
-    # config.py
-    train=False, test=False, seed=0, ngpu=1, local_rank=0, num_workers=8, checkpoint_dir="log",
+    # config.py  (num_workers: the reference's default is 8 -- for a step of ~1 s; at 30+ it/s a rank consumes ~1 000 frames/s and a
+    # decode worker delivers ~208, and eight ranks share one host: 12 workers per rank delivered 5.8 k img/s in aggregate, 24 gave
+    # 23 k (profiles/r04_data_bench8.json), the 8 x 33 it/s node needs 8.5 k => 16 per rank by default)
+    train=False, test=False, seed=0, ngpu=1, local_rank=0, num_workers=16, checkpoint_dir="log",
     name="exp", train_list="", test_list="", model_path="", vis_path="", total_iters=10000,
     batch_log_interval=10, save_freq=1, vis_freq=1, batch_size=4, dframe_eval=1, logger="tensorboard",
     # data/dataloader.py

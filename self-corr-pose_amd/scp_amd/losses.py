@@ -33,11 +33,72 @@ def pinhole_cam(verts, pp, foc):
     raise ValueError("vertices shape must be (bsz, N, 3) or (N, 3).")
 
 
+class _ProjectVertices(torch.autograd.Function):
+    """(verts @ rot + trans) -> pinhole_cam -> optional y flip as one HIP launch forward and one backward (csrc/project.hip):
+    the torch composition is ~15 launches forward and ~35 backward (every `verts[:, :, k]` select has a zero-fill + copy backward),
+    three times per step on the serial chain.  Fixed summation order for the K = 3 product (a library GEMM's depends on the solution
+    the process happens to have tuned); float64 evaluation of the projection when the intrinsics are float64, like pinhole_cam."""
+
+    @staticmethod
+    def forward(ctx, verts, rot, trans, foc, pp, flip_y):
+        import ctypes
+        from . import capi
+        b, v = verts.shape[:2]
+        verts, rot = verts.contiguous(), rot.contiguous()
+        trans = trans.reshape(b, 3).contiguous()
+        f64 = foc.dtype == torch.float64
+        foc, pp = foc.to(torch.float64 if f64 else torch.float32).contiguous(), pp.to(torch.float64 if f64 else torch.float32).contiguous()
+        out, cam = torch.empty_like(verts), torch.empty_like(verts)
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())
+        capi.check(capi.lib().scp_project_vertices_forward(capi.dev_ptr(verts, "verts"), capi.dev_ptr(rot, "rot"), capi.dev_ptr(trans, "trans"),
+                                                           vp(foc), vp(pp), int(f64), int(flip_y), b, v, capi.dev_ptr(out, "out"),
+                                                           capi.dev_ptr(cam, "cam"), capi.current_stream()), "project_vertices_forward")
+        ctx.save_for_backward(verts, rot, cam, foc)
+        ctx.cfg = (int(f64), int(flip_y), b, v)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        from . import capi
+        verts, rot, cam, foc = ctx.saved_tensors
+        f64, flip_y, b, v = ctx.cfg
+        g = g.contiguous()
+        gv = torch.empty_like(verts) if ctx.needs_input_grad[0] else None
+        gr = torch.empty_like(rot) if ctx.needs_input_grad[1] else None
+        gt = torch.empty(b, 1, 3, dtype=verts.dtype, device=verts.device) if ctx.needs_input_grad[2] else None
+        capi.check(capi.lib().scp_project_vertices_backward(capi.dev_ptr(g, "g_out"), capi.dev_ptr(verts, "verts"), capi.dev_ptr(rot, "rot"),
+                                                            capi.dev_ptr(cam, "cam"), ctypes.c_void_p(foc.data_ptr()), f64, flip_y, b, v,
+                                                            capi.opt_ptr(gv, "g_verts"), capi.opt_ptr(gr, "g_rot"), capi.opt_ptr(gt, "g_trans"),
+                                                            capi.current_stream()), "project_vertices_backward")
+        return gv, gr, gt, None, None, None
+
+
+def _fused_projection_ok(verts, rot, trans, foc, pp):
+    return (verts.is_cuda and verts.dim() == 3 and verts.dtype == torch.float32 and rot.dtype == torch.float32 and trans.dtype == torch.float32
+            and tuple(rot.shape) == (verts.shape[0], 3, 3) and trans.numel() == verts.shape[0] * 3
+            and foc.dtype == pp.dtype and foc.dtype in (torch.float32, torch.float64) and tuple(foc.shape) == (verts.shape[0], 2)
+            and tuple(pp.shape) == (verts.shape[0], 2) and not (foc.requires_grad or pp.requires_grad) and FUSE_PROJECTION)
+
+
+FUSE_PROJECTION = True      # tests switch it off to compare with the torch composition
+
+
+def project_vertices(verts, foc, pp, rotation, translation, flip_y):
+    """pinhole_cam(verts @ rotation + translation) with the y axis optionally flipped: the fused HIP op on the GPU, the torch
+    composition elsewhere (CPU runs, exotic dtypes)"""
+    if _fused_projection_ok(verts, rotation, translation, foc, pp):
+        return _ProjectVertices.apply(verts, rotation, translation, foc, pp, bool(flip_y))
+    cam = pinhole_cam(verts.bmm(rotation) + translation, pp, foc)
+    if flip_y:
+        return torch.stack((cam[:, :, 0], -cam[:, :, 1], cam[:, :, 2]), 2)  # image y is flipped
+    return cam
+
+
 def project_for_render(verts, foc, pp, rotation, translation, rotation_detach=False, translation_detach=False):
     rot = rotation.detach() if rotation_detach else rotation
     trans = translation.detach() if translation_detach else translation
-    cam = pinhole_cam(verts.bmm(rot) + trans, pp, foc)
-    return torch.stack((cam[:, :, 0], -cam[:, :, 1], cam[:, :, 2]), 2)  # image y is flipped
+    return project_vertices(verts, foc, pp, rot, trans, flip_y=True)
 
 
 def render(renderer, verts, faces, tex, foc, pp, rotation, translation, rotation_detach=False,

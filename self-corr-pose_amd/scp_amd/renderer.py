@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from . import soft_renderer as sr
-from .losses import pinhole_cam, project_for_render, render
+from .losses import pinhole_cam, project_for_render, project_vertices, render
 
 
 class Renderer:
@@ -90,11 +90,11 @@ class Renderer:
         match_mask, match_gt = match_out[:, -1], match_out[:, :3]
 
         # projected vertex positions: differentiable w.r.t. rotation / translation (renderer.py:63-67)
-        cam_v = canon.bmm(rotation) + translation
-        imatch_gt = pinhole_cam(cam_v, pp_crop, foc_crop)[:, :, :2].permute(0, 2, 1)   # b,2,n
+        proj = project_vertices(canon, foc_crop, pp_crop, rotation, translation, flip_y=False)          # b,n,3 = (x, y, camera z)
+        imatch_gt = proj[:, :, :2].permute(0, 2, 1)   # b,2,n
         with torch.no_grad():  # visibility weight, detached in the reference (:69-71)
-            seen = F.grid_sample(depth_render[:, None], imatch_gt.permute(0, 2, 1)[:, None], align_corners=False)[:, 0, 0]
-            depth_weight = (-5 * F.relu(cam_v[:, :, 2] - seen)).exp()
+            seen = F.grid_sample(depth_render[:, None], proj[:, None, :, :2], align_corners=False)[:, 0, 0]
+            depth_weight = (-5 * F.relu(proj[:, :, 2] - seen)).exp()
         if raw:
             return depth_out, match_out, imatch_gt, depth_weight
         return mask_render, depth_render, match_gt, imatch_gt, depth_mask, match_mask, depth_weight

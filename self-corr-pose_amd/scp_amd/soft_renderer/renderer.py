@@ -38,7 +38,18 @@ class Lighting(nn.Module):
                                              self.color_directionals, self.directions)
         return light
 
+    def _is_identity(self):
+        """ambient 1.0 x white and no directional light (every renderer of model/module/renderer.py:13-26): the light is exactly 1.0
+        per channel and textures * 1.0 are the textures -- nothing to launch"""
+        try:
+            return (float(self.intensity_directionals) == 0.0 and float(self.intensity_ambient) == 1.0
+                    and all(float(c) == 1.0 for c in self.color_ambient))
+        except (TypeError, ValueError):
+            return False
+
     def forward(self, mesh):
+        if self._is_identity() and mesh.textures is not None and mesh.textures.dtype == torch.float32:
+            return mesh
         if self.light_mode == "surface":
             light = self._light(mesh.faces, lambda: mesh.surface_normals)
             mesh.textures = mesh.textures * light[:, :, None, :]
@@ -54,7 +65,26 @@ class LookAt(nn.Module):
         self.perspective, self.viewing_angle, self.viewing_scale = perspective, viewing_angle, viewing_scale
         self._eye = eye if eye is not None else [0, 0, -(1. / math.tan(math.radians(viewing_angle)) + 1)]
 
+    def _pure_translation(self):
+        """The trainer's camera (renderer.py:13-26: look_at, orthographic, default eye on the -z axis looking at the origin with +y up)
+        is a pure translation: the look-at rotation is the identity EXACTLY (normalize((0, 0, e)) = (0, 0, 1) in IEEE arithmetic:
+        sqrt(RN(e^2)) = |e| whether the square is kept in fp32 or fp64) and the orthographic scale is 1, so
+        orthogonal(look_at(v)) = v - eye bit for bit (x * 1 + y * 0 + z * 0 adds exact zeros).  One launch instead of ~14
+        (normalize x3, cross x2, stack, matmul, three selects, two multiplies, stack) and one backward node instead of ~10."""
+        eye = self._eye
+        if self.perspective or self.viewing_scale != 1.0 or not isinstance(eye, (list, tuple)) or len(eye) != 3:
+            return False
+        try:
+            ex, ey, ez = (float(t) for t in eye)
+        except (TypeError, ValueError):
+            return False
+        import numpy as np
+        e32 = np.float32(ez)
+        return ex == 0.0 and ey == 0.0 and ez < 0.0 and np.float32(-e32) / np.sqrt(e32 * e32, dtype=np.float32) == np.float32(1.0)
+
     def forward(self, vertices):
+        if self._pure_translation():
+            return vertices - srf.const_tensor(self._eye, torch.float32, vertices.device).reshape(1, 1, 3)
         vertices = srf.look_at(vertices, self._eye)
         if self.perspective:
             return srf.perspective(vertices, angle=self.viewing_angle)

@@ -256,3 +256,47 @@ def test_weight_planes_kernel_equals_the_torch_composition():
         from scp_amd.dino import TiledPlanes
         planes = TiledPlanes(96, 9 * 64, "cuda", blob=cache["fwd"]).untile()
         assert torch.equal(planes.double().sum(0).reshape(96, 3, 3, 64), w.permute(0, 2, 3, 1).double())
+
+
+def test_weight_planes_follow_every_way_a_weight_can_change(conv_mode, monkeypatch):
+    """the cached split planes of a convolution (fused_conv.weight_planes) must never serve a stale weight: in-place autograd-visible
+    writes (version counter), load_state_dict (module hook), optimizer steps (Optimizers' post-step hook -> invalidate()) and raw
+    `.data` writes followed by fused_conv.invalidate(); a raw `.data` write WITHOUT it is what SCP_CHECK_PLANES=1 exists to catch"""
+    from scp_amd import fused_conv
+    if conv_mode != "split":
+        pytest.skip("planes exist in split mode only")
+    torch.manual_seed(3)
+    conv = nn.Conv2d(64, 64, 3, padding=1).cuda()
+    x = torch.randn(2, 64, 16, 16, device="cuda").contiguous(memory_format=torch.channels_last)
+
+    def check(what):
+        with torch.no_grad():
+            got = fused_conv.conv_bias_leaky(x, conv, slope=1.0)
+            ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+        _close(got, ref, 2e-5, what)
+
+    check("fresh")
+    with torch.no_grad():
+        conv.weight.mul_(1.5)                                     # in-place, bumps the version counter
+    check("in-place write")
+    conv.load_state_dict({k: v * 0.5 for k, v in conv.state_dict().items()})
+    check("load_state_dict")
+    conv.weight.data.add_(0.25)                                   # behind autograd's back
+    fused_conv.invalidate()
+    check(".data write + invalidate()")
+    other = torch.cuda.Stream()
+    other.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(other):                                # a consumer on another stream, then a rebuild on the main stream
+        check("other stream")
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+    check("rebuild after a foreign reader")
+    torch.cuda.synchronize()
+    # the debugging aid: a silent .data write is detected instead of served stale
+    monkeypatch.setattr(fused_conv, "CHECK_PLANES", True)
+    with torch.no_grad():
+        conv.weight.mul_(1.0)                                     # rebuild once with the checksum recorded
+    check("checksum armed")
+    conv.weight.data.mul_(3.0)
+    with pytest.raises(RuntimeError, match="without its split planes"):
+        check("stale")

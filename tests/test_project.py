@@ -1,0 +1,148 @@
+"""The step's camera glue: loss_utils.py:38-61 (render(): bmm + translation, pinhole_cam, y flip) as the fused HIP projection
+(csrc/project.hip, scp_amd.losses.project_vertices) and the two exact shortcuts of the SoftRenderer stages the trainer's cameras make
+trivial (identity look-at rotation, unit lighting).  CPU: the shortcuts are bit-identical to the long way round.  GPU: the fused op vs the
+torch composition in float64 -- forward to the rounding of the final cast (2 ulp), gradients 1e-6 relative; float64 and float32
+intrinsics, both y conventions, detached operands, and a whole render pass with and without the fused glue."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+
+def _camera(b, v, seed, f64):
+    g = torch.Generator().manual_seed(seed)
+    verts = torch.randn(b, v, 3, generator=g) * 0.4
+    q = torch.randn(b, 3, 3, generator=g)
+    rot = torch.linalg.qr(q).Q.contiguous()
+    trans = torch.cat((torch.randn(b, 1, 2, generator=g) * 0.1, 4.5 + torch.rand(b, 1, 1, generator=g)), 2)
+    dt = torch.float64 if f64 else torch.float32
+    foc = (5.5 + torch.rand(b, 2, generator=g)).to(dt)
+    pp = (torch.rand(b, 2, generator=g) * 0.3 - 0.15).to(dt)
+    return verts, rot, trans, foc, pp
+
+
+def test_look_at_and_lighting_shortcuts_are_bit_identical_cpu():
+    from scp_amd.soft_renderer import functional as srf
+    from scp_amd.soft_renderer.renderer import Lighting, LookAt
+    from scp_amd.soft_renderer.mesh import Mesh
+    la = LookAt(perspective=False)
+    assert la._pure_translation()
+    v = torch.randn(3, 50, 3) * 2
+    long_way = srf.orthogonal(srf.look_at(v, la._eye), 1.0)
+    assert torch.equal(la(v), long_way)
+    assert not LookAt(perspective=True)._pure_translation()
+    assert not LookAt(perspective=False, viewing_scale=2.0)._pure_translation()
+    assert not LookAt(perspective=False, eye=[0.1, 0, -2.7])._pure_translation()
+    other = LookAt(perspective=False, eye=[0.3, -0.2, -2.0])
+    assert torch.allclose(other(v), srf.orthogonal(srf.look_at(v, other._eye), 1.0))
+    faces = torch.randint(0, 50, (3, 20, 3))
+    tex = torch.rand(3, 50, 3)
+    lit = Lighting("vertex", 1., (1, 1, 1), 0.)
+    assert lit._is_identity()
+    m = lit(Mesh(v, faces, tex, texture_type="vertex"))
+    assert torch.equal(m.textures, tex)
+    dim = Lighting("vertex", 0.5, (1, 1, 1), 0.)
+    assert not dim._is_identity() and torch.equal(dim(Mesh(v, faces, tex, texture_type="vertex")).textures, tex * 0.5)
+
+
+def _reference(verts, rot, trans, foc, pp, flip_y):
+    cam = verts.double().bmm(rot.double()) + trans.double()
+    x = pp.double()[:, 0][:, None] + cam[:, :, 0] * foc.double()[:, 0][:, None] / cam[:, :, 2]
+    y = pp.double()[:, 1][:, None] + cam[:, :, 1] * foc.double()[:, 1][:, None] / cam[:, :, 2]
+    return torch.stack((x, -y if flip_y else y, cam[:, :, 2]), 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,v", [(32, 642), (3, 7), (2, 2562), (1, 257)])
+@pytest.mark.parametrize("f64", [True, False])
+@pytest.mark.parametrize("flip_y", [True, False])
+def test_fused_projection_vs_float64_composition(b, v, f64, flip_y):
+    from scp_amd import losses
+    verts, rot, trans, foc, pp = (t.cuda() for t in _camera(b, v, b + v, f64))
+    w = torch.randn(b, v, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    a = [t.clone().requires_grad_(True) for t in (verts, rot, trans)]
+    out = losses.project_vertices(a[0], foc, pp, a[1], a[2], flip_y)
+    assert out.grad_fn is not None and "ProjectVertices" in type(out.grad_fn).__name__
+    (out * w).sum().backward()
+    r = [t.double().clone().requires_grad_(True) for t in (verts, rot, trans)]
+    ref = _reference(r[0], r[1], r[2], foc, pp, flip_y)
+    (ref * w.double()).sum().backward()
+    # forward: fp32 K = 3 product (a few ulp of the camera-space point) + the final rounding
+    err = (out.double() - ref).abs()
+    assert (err <= 2e-6 * (1 + ref.abs())).all(), err.max().item()
+    for got, want, name in zip(a, r, ("verts", "rot", "trans")):
+        scale = float(want.grad.abs().max())
+        assert float((got.grad.double() - want.grad.reshape(got.grad.shape)).abs().max()) <= 2e-6 * scale, name
+    # detached operands: only the requested gradients are produced
+    a2 = verts.clone().requires_grad_(True)
+    losses.project_vertices(a2, foc, pp, rot, trans, flip_y).sum().backward()
+    assert a2.grad is not None
+
+
+@pytest.mark.gpu
+def test_fused_projection_equals_the_torch_composition_in_a_render_pass(monkeypatch):
+    """one depth-group render with the fused glue and with FUSE_PROJECTION off: the projected vertices agree to the K = 3 summation
+    order (1 ulp), the rendered images to the F12 band, image sums to 1e-4"""
+    import scp_amd.dino as dino
+    from scp_amd import losses, synthetic
+    from scp_amd.flags import Options
+    from scp_amd.model import MeshNet
+    dino.ALLOW_RANDOM_INIT = True
+    opts = Options("laptop_wild6d", batch_size=1, repeat=2, train=True)
+    torch.manual_seed(0)
+    model = MeshNet(opts, prior=synthetic.bottle_like(3)).cuda()
+    data = synthetic.make_batch(1, 2, 256, seed=4, device="cuda")
+    verts = model.mesh.mean_v.detach()[None].expand(2, -1, -1).contiguous() * 0.9
+    _, rot, trans, _, _ = (t.cuda() for t in _camera(2, 4, 9, False))
+    trans = torch.tensor([[[0.02, -0.03, 5.0]], [[-0.04, 0.01, 5.4]]], device="cuda")
+    faces = model.mesh.faces[None].expand(2, -1, -1)
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(losses, "FUSE_PROJECTION", fused)
+        with torch.no_grad():
+            proj = losses.project_for_render(verts, data[7], data[9], rot, trans)
+            depth_out, match_out, imatch_gt, dw = model.renderer.render_depth_group(verts, faces, data[7], data[9], rot, trans, raw=True)
+        outs[fused] = (proj, depth_out, imatch_gt, dw)
+    a, b = outs[True], outs[False]
+    assert float((a[0] - b[0]).abs().max()) <= 1e-6
+    assert float((a[2] - b[2]).abs().max()) <= 1e-6
+    assert abs(float(a[1][:, 3].sum()) - float(b[1][:, 3].sum())) <= 1e-4 * float(b[1][:, 3].sum())      # F12: image sums 2e-6 .. 2.4e-5
+    assert float(((a[1] - b[1]).abs() <= 1e-4).float().mean()) >= 0.97
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("poison", [None, "nan", "inf"])
+def test_fused_gradient_clip_equals_the_torch_composition(poison):
+    """trainer.py:132-150 on the flat buffer: csrc/gradclip.hip (two launches) vs the torch composition it replaces -- group norms,
+    clipped values, untouched groups, the NaN guard; through Trainer.collect_grad on identical gradients"""
+    import scp_amd.dino as dino
+    from scp_amd import synthetic
+    from scp_amd.flags import Options
+    from scp_amd.trainer import Trainer
+    dino.ALLOW_RANDOM_INIT = True
+    opts = Options("laptop_wild6d", batch_size=1, repeat=2, train=True, total_iters=10)
+    torch.manual_seed(0)
+    tr = Trainer(opts, prior=synthetic.bottle_like(2), device="cuda")
+    gen = torch.Generator().manual_seed(4)
+    grads = [torch.randn(p.shape, generator=gen).cuda() * (3.0 if "pose" in n else 0.05)
+             for n, p in tr.model.named_parameters() if p.requires_grad]
+    res = {}
+    for fused in (True, False):
+        tr.fuse_clip = fused
+        tr.grads.prepare()
+        for p, g in zip(tr._trainable, grads):
+            p.grad.copy_(g)
+        if poison is not None:
+            tr._trainable[3].grad.view(-1)[5] = float(poison)
+        norms = tr.collect_grad()
+        res[fused] = (torch.stack([n.reshape(()) for n in norms]).cpu(), tr.grads.flat.detach().clone().cpu())
+    assert hasattr(tr, "last_clip"), "the fused path must have run"
+    np.testing.assert_allclose(res[True][0].numpy(), res[False][0].numpy(), rtol=2e-6, atol=0)
+    a, b = res[True][1], res[False][1]
+    assert torch.isfinite(a).all()
+    if poison is not None:
+        assert float(a.abs().max()) == 0.0 and float(b.abs().max()) == 0.0 and float(res[True][0].abs().max()) == 0.0
+    else:
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+        assert float(res[True][0][2]) > 0.1 and float(tr.last_clip[5]) < 1.0        # the pose group really was clipped

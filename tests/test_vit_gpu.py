@@ -435,3 +435,29 @@ def test_configs4_bf16_modes_of_the_own_kernels():
     rel = (out - ref).norm() / ref.norm()
     assert rel <= 1e-2, rel                        # bf16 operands: ~3 significant digits
     assert rel >= 1e-4, "bf16 mode must actually round its operands"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,S,P,E", [(3, 256, 8, 384), (2, 64, 8, 384), (1, 48, 16, 192), (2, 512, 8, 384)])
+def test_patch_embedding_on_the_own_gemm_vs_float64_convolution(B, S, P, E, gemm_mode, monkeypatch):
+    """vision_transformer_flexible.py:134-149 (Conv2d(3, embed, p, stride p) -> flatten -> transpose) as ONE product on the build's GEMM
+    (dino._PatchEmbed._forward_gemm): against the float64 convolution, 2e-5 of scale, both matrix-core modes; the stock composition
+    (nn.Conv2d -> library) is what SCP_PATCH_EMBED=stock still runs and must agree as well"""
+    from scp_amd import dino
+    torch.manual_seed(B + S)
+    pe = dino._PatchEmbed(P, E).cuda()
+    x = torch.randn(B, 3, S, S, device="cuda")
+    with torch.no_grad():
+        assert pe._own_gemm_ok(x)
+        got = pe(x)
+        ref = torch.nn.functional.conv2d(x.double(), pe.proj.weight.double(), pe.proj.bias.double(), stride=P).flatten(2).transpose(1, 2)
+        monkeypatch.setenv("SCP_PATCH_EMBED", "stock")
+        assert not pe._own_gemm_ok(x)
+        stock = pe(x)
+    assert got.shape == ref.shape == (B, (S // P) ** 2, E) and got.is_contiguous()
+    scale = float(ref.abs().max())
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * scale
+    assert float((stock.double() - ref).abs().max()) <= 2e-5 * scale
+    # a training-mode caller (gradient wanted) keeps the autograd-capable stock path
+    monkeypatch.delenv("SCP_PATCH_EMBED")
+    assert not pe._own_gemm_ok(x.clone().requires_grad_(True))

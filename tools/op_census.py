@@ -103,3 +103,21 @@ print("%-26s %8d %9.2f | %8d %9.2f" % ("TOTAL", *tot))
 print("\ntop small ops")
 for (stage, name, shp), (n, ms) in sorted(small_ops.items(), key=lambda kv: -kv[1][1])[:70]:
     print("%7.3f ms x%-3d %-22s %-32s %s" % (ms, n, stage, name[:32], shp))
+
+# ---- framework (aten::) launches by call site: what the ~500 small launches of a step are ------------------------------------------------
+aten = collections.defaultdict(lambda: [0, 0.0])
+for (stage, name, shp), (n, ms) in small_ops.items():
+    if name.startswith("aten::") or name.startswith("hipMemcpy") or name.startswith("Memcpy") or name.startswith("Memset"):
+        aten[(stage, name)][0] += n
+        aten[(stage, name)][1] += ms
+tot_n, tot_ms = sum(v[0] for v in aten.values()), sum(v[1] for v in aten.values())
+print("\naten:: launches of the step: %d, %.2f ms of device time; by (stage, op), sorted by launches" % (tot_n, tot_ms))
+for (stage, name), (n, ms) in sorted(aten.items(), key=lambda kv: -kv[1][0])[:90]:
+    print("x%-4d %7.3f ms  %-22s %s" % (n, ms, stage, name))
+by_stage = collections.defaultdict(lambda: [0, 0.0])
+for (stage, name), (n, ms) in aten.items():
+    by_stage[stage][0] += n
+    by_stage[stage][1] += ms
+print("\naten:: launches by stage")
+for stage, (n, ms) in sorted(by_stage.items(), key=lambda kv: -kv[1][0]):
+    print("x%-4d %7.3f ms  %s" % (n, ms, stage))
