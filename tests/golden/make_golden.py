@@ -361,6 +361,7 @@ def gen_render():
     # conditioning of the per-pixel planes (the companion of SURVEY F12's "alpha max-abs" band): the reference's OWN render re-run with
     # its geometry inputs perturbed at the level of their last bits -- what any backend's rounding of the projection does to them
     cond = {k: [0.0, 0.0, 0.0] for k in ("mask_render", "tex_mask", "depth_mask", "match_mask")}
+    cond_stats = {k: np.zeros(2) for k in names}       # largest relative move of (|sum|, sum of squares) of every output
     gp = torch.Generator().manual_seed(5)
     with torch.no_grad():
         for si, sigma in enumerate((1e-7, 3e-7, 1e-6)):
@@ -370,10 +371,14 @@ def gen_render():
                 tr_ = translation.detach() + sigma * torch.randn(translation.shape, generator=gp)
                 o2 = model.renderer.render_all(pv, faces, tex.detach(), foc_crop, pp_crop, ro, tr_, None)
                 for k, a, b in zip(names, outs, o2):
+                    sa, sb = _stats(a)[1:], _stats(b)[1:]
+                    cond_stats[k] = np.maximum(cond_stats[k], np.abs(sb - sa) / np.maximum(np.abs(sa), 1e-30))
                     if k in cond:
                         cond[k][si] = max(cond[k][si], float((a.detach() - b).abs().max()))
     print("  alpha max-abs change under input perturbations of sigma 1e-7 / 3e-7 / 1e-6:", {k: ["%.3e" % x for x in v] for k, v in cond.items()})
-    save("render_all_bottle_b2", cond_sigmas=np.array([1e-7, 3e-7, 1e-6]), **{"cond_maxabs_" + k: np.array(v) for k, v in cond.items()}, pred_v=pred_v.detach().numpy(), rotation=rotation.detach().numpy(), translation=translation.detach().numpy(),
+    print("  relative move of (|sum|, sum of squares):", {k: ["%.2e" % x for x in v] for k, v in cond_stats.items()})
+    save("render_all_bottle_b2", cond_sigmas=np.array([1e-7, 3e-7, 1e-6]), **{"cond_maxabs_" + k: np.array(v) for k, v in cond.items()},
+         **{"cond_stats_" + k: v for k, v in cond_stats.items()}, pred_v=pred_v.detach().numpy(), rotation=rotation.detach().numpy(), translation=translation.detach().numpy(),
          tex=tex.detach().numpy(), foc_crop=foc_crop.numpy(), pp_crop=pp_crop.numpy(), faces=model.mesh.faces.numpy().astype(np.int64),
          **{"out_" + k: sub(o) for k, o in zip(names, outs)}, **{"stats_" + k: _stats(o) for k, o in zip(names, outs)},
          weights_seed=np.int64(77),   # the functional's weights: torch.Generator().manual_seed(77); rand(tex) first, then randn per output in order

@@ -42,7 +42,10 @@ def _check(d, outs, grads):
         got = o.detach().double().cpu()
         ref_stats = d["stats_" + k]
         mine = np.array([got.sum().item(), got.abs().sum().item(), (got * got).sum().item()])
-        np.testing.assert_allclose(mine[1:], ref_stats[1:], rtol=1e-4, err_msg=k)          # |sum|, sum of squares: loss-like
+        # |sum|, sum of squares (loss-like): 1e-4, or what the REFERENCE's own render moves them by when its inputs are perturbed at
+        # 1e-7 .. 1e-6 (cond_stats_*: a handful of pixels flipping across the hard footprint cut move the depth planes' sums by ~1e-4)
+        tol = np.maximum(1e-4, 1.5 * d["cond_stats_" + k])
+        assert (np.abs(mine[1:] - ref_stats[1:]) <= tol * np.abs(ref_stats[1:])).all(), (k, mine[1:], ref_stats[1:], tol)
         sub = got.numpy()[..., ::2, ::2] if got.dim() >= 3 and got.shape[-1] == 256 else got.numpy()
         ref = d["out_" + k]
         diff = np.abs(sub - ref)
