@@ -149,7 +149,7 @@ class KernelClock:
 
 
 INIT_STEPS = 3
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")   # written by tools/traffic_report.py from rocprofv3 PMC passes
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")   # written by tools/traffic_report.py from rocprofv3 PMC passes
 
 
 def measured_traffic(key, size_tag):
@@ -768,7 +768,7 @@ def main():
                 fb = 4.0 * B * (n_faces * (9 + 9 + 27) + S * S * (4 + 2))
                 fr = {"kernel": "raster_forward_kernel<softmax,vertex> (sigma=1e-3 texture pass; + the per-face kernel of the same call)",
                       "bound": "hbm", "achieved": fb / (fwd_raster_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": fb / (fwd_raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic("raster_forward", size_tag),
+                      "frac": fb / (fwd_raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic("raster_forward_softtex", size_tag),
                       "avg_launch_ms": fwd_raster_ms, "algorithmic_bytes_per_launch": fb,
                       "note": "not HBM-bound in any honest accounting: the VALU figure on active pairs is the one that grades it"}
                 if pairs:
@@ -847,7 +847,7 @@ def main():
                         "arithmetic": ("fp32-accurate: operands represented exactly, dropped partial products < 2^-24 |a b|; error "
                                        "vs float64 not above the fp32 matrix cores' (tests/test_vit_gpu.py); SCP_VIT_GEMM=fp32 "
                                        "selects the fp32 cores" if split else "v_mfma_f32_32x32x2_f32"),
-                        "traffic": measured_traffic("vit_gemm", size_tag), "traffic_source": "profiles/r04_traffic.json (per step)",
+                        "traffic": measured_traffic("vit_gemm", size_tag), "traffic_source": "profiles/r05_traffic.json (per step)",
                         "clock": "in-kernel s_memrealtime stamps: first workgroup start to last workgroup end of every full launch "
                                  "of the timed region (= rocprofv3 kernel-trace duration; profiles/r04_kernel_stats_timed_window.csv)",
                         "avg_launch_ms": cms / cn, "algorithmic_flops_per_launch": cfl / cn,

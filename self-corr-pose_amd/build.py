@@ -121,7 +121,32 @@ def build_slp_control(verbose=False):
     return CONTROL
 
 
+def build_variant(name, per_file_flags):
+    """A/B builds (tools/): lib/libscp_hip_<name>.so = the shipped objects with the listed files recompiled with extra flags, e.g.
+    build_variant("conv2", {"conv_igemm.hip": ["-DSCP_CONV_STAGES=2"]}); selected at run time with SCP_HIP_LIB=<path>"""
+    build(verbose=False)
+    objdir = os.path.join(HERE, "build")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for s in sources():
+        o = os.path.join(objdir, s[:-4] + ".o")
+        if s in per_file_flags:
+            o = os.path.join(objdir, "%s_%s.o" % (s[:-4], name))
+            r = subprocess.run([hipcc] + COMMON + EXTRA.get(s, []) + list(per_file_flags[s]) + ["-c", os.path.join(CSRC, s), "-o", o],
+                               stderr=subprocess.PIPE, text=True)
+            _echo(r.stderr)
+            r.check_returncode()
+        objs.append(o)
+    out = os.path.join(HERE, "lib", "libscp_hip_%s.so" % name)
+    subprocess.check_call([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH] + objs + ["-o", out])
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    for arg in sys.argv[1:]:
+        if arg.startswith("--variant="):          # --variant=conv2:conv_igemm.hip:-DSCP_CONV_STAGES=2
+            vname, vfile, vflag = arg[len("--variant="):].split(":", 2)
+            print(build_variant(vname, {vfile: vflag.split()}))
     if "--control" in sys.argv:
         print(build_slp_control())

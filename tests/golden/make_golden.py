@@ -360,7 +360,7 @@ def gen_render():
     sub = lambda t: t.detach().numpy()[..., ::2, ::2] if t.dim() >= 3 and t.shape[-1] == 256 else t.detach().numpy()
     # conditioning of the per-pixel planes (the companion of SURVEY F12's "alpha max-abs" band): the reference's OWN render re-run with
     # its geometry inputs perturbed at the level of their last bits -- what any backend's rounding of the projection does to them
-    cond = {k: [0.0, 0.0, 0.0] for k in ("mask_render", "tex_mask", "depth_mask", "match_mask")}
+    cond = {k: [0.0, 0.0, 0.0] for k in ("mask_render", "tex_mask", "depth_mask", "match_mask", "imatch_gt", "depth_weight")}
     cond_stats = {k: np.zeros(2) for k in names}       # largest relative move of (|sum|, sum of squares) of every output
     gp = torch.Generator().manual_seed(5)
     with torch.no_grad():
