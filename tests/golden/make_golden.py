@@ -376,9 +376,27 @@ def gen_render():
                     if k in cond:
                         cond[k][si] = max(cond[k][si], float((a.detach() - b).abs().max()))
     print("  alpha max-abs change under input perturbations of sigma 1e-7 / 3e-7 / 1e-6:", {k: ["%.3e" % x for x in v] for k, v in cond.items()})
+    # ... and of the gradients: the same functional's gradients with the inputs perturbed at 1e-7 / 3e-7 (cosine to the base gradient,
+    # relative change of the norm) -- the band a backend whose projection rounds differently can be held to
+    base_g = {"pred_v": pred_v.grad.clone(), "tex": tex.grad.clone(), "rotation": rotation.grad.clone(), "translation": translation.grad.clone()}
+    cond_grad = {k: np.array([1.0, 0.0]) for k in base_g}          # (min cosine, max norm-rel)
+    for sigma in (1e-7, 3e-7):
+        for _ in range(4):
+            pv = (pred_v.detach() + sigma * torch.randn(pred_v.shape, generator=gp)).requires_grad_(True)
+            ro = (rotation.detach() + sigma * torch.randn(rotation.shape, generator=gp)).requires_grad_(True)
+            tr_ = (translation.detach() + sigma * torch.randn(translation.shape, generator=gp)).requires_grad_(True)
+            tx = tex.detach().clone().requires_grad_(True)
+            o2 = model.renderer.render_all(pv, faces, tx, foc_crop, pp_crop, ro, tr_, None)
+            sum((o * weights[k]).sum() for k, o in zip(names, o2) if k in in_loss).backward()
+            for k, gnew in (("pred_v", pv.grad), ("tex", tx.grad), ("rotation", ro.grad), ("translation", tr_.grad)):
+                a, b = gnew.double().reshape(-1), base_g[k].double().reshape(-1)
+                cos = float(a @ b / (a.norm() * b.norm()))
+                rel = float((a.norm() - b.norm()).abs() / b.norm())
+                cond_grad[k] = np.array([min(cond_grad[k][0], cos), max(cond_grad[k][1], rel)])
+    print("  gradient (min cosine, max norm-rel) under 1e-7 / 3e-7 perturbations:", {k: ["%.7f" % v[0], "%.2e" % v[1]] for k, v in cond_grad.items()})
     print("  relative move of (|sum|, sum of squares):", {k: ["%.2e" % x for x in v] for k, v in cond_stats.items()})
     save("render_all_bottle_b2", cond_sigmas=np.array([1e-7, 3e-7, 1e-6]), **{"cond_maxabs_" + k: np.array(v) for k, v in cond.items()},
-         **{"cond_stats_" + k: v for k, v in cond_stats.items()}, pred_v=pred_v.detach().numpy(), rotation=rotation.detach().numpy(), translation=translation.detach().numpy(),
+         **{"cond_stats_" + k: v for k, v in cond_stats.items()}, **{"cond_grad_" + k: v for k, v in cond_grad.items()}, pred_v=pred_v.detach().numpy(), rotation=rotation.detach().numpy(), translation=translation.detach().numpy(),
          tex=tex.detach().numpy(), foc_crop=foc_crop.numpy(), pp_crop=pp_crop.numpy(), faces=model.mesh.faces.numpy().astype(np.int64),
          **{"out_" + k: sub(o) for k, o in zip(names, outs)}, **{"stats_" + k: _stats(o) for k, o in zip(names, outs)},
          weights_seed=np.int64(77),   # the functional's weights: torch.Generator().manual_seed(77); rand(tex) first, then randn per output in order

@@ -70,7 +70,10 @@ def _check(d, outs, grads):
         cos = a @ b / (np.linalg.norm(a) * np.linalg.norm(b))
         rel = abs(np.linalg.norm(a) - np.linalg.norm(b)) / np.linalg.norm(b)
         print("grad %-12s cos %.7f norm rel %.2e" % (k, cos, rel))
-        assert cos >= 0.9999 and rel <= 1e-2, (k, cos, rel)
+        # SURVEY F12's band (cosine >= 0.9999, norm within 1e-2) -- or, where the reference's OWN gradient moves further when its
+        # inputs are perturbed by 1e-7 .. 3e-7 (cond_grad_*: the silhouette terms), that recorded move with slack
+        min_cos, max_rel = (float(x) for x in d["cond_grad_" + k])
+        assert cos >= min(0.9999, 1.0 - 2.0 * (1.0 - min_cos)) and rel <= max(1e-2, 2.0 * max_rel), (k, cos, rel, min_cos, max_rel)
 
 
 def test_render_all_matches_reference_cpu(monkeypatch):
