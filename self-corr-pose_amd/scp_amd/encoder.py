@@ -26,23 +26,6 @@ class Encoder(nn.Module):
         self.shape_predictor = ShapePredictor(opts)
         self.pose_predictor = PosePredictor(opts, 512)
 
-    # ---- HIP-graph replay of the two passes (scp_amd/graphed.py) ------------------------------------------------------------------
-    # Trainer switches this on (use_graphs = True) for fp32 training on the GPU: everything after the colour jitter -- whose random
-    # draw is a host-side kernel argument -- has static shapes and runs on one stream, ~100 launches forward and ~330 backward
-    # per pass.  The full pass (trunk + decoder + heads) and the rotated images' half-resolution pass are separate segments.
-    use_graphs = False
-
-    def _segment(self, name, fn):
-        segs = self.__dict__.setdefault("_graph_segments", {})
-        if name not in segs:
-            from .graphed import GraphedSegment
-            segs[name] = GraphedSegment(fn, [p for p in self.parameters() if p.requires_grad], warmup=2, name=name)
-        return segs[name]
-
-    def _graphable(self, x):
-        return (self.use_graphs and x.is_cuda and self.training and torch.is_grad_enabled()
-                and not bool(getattr(self.opts, "mixed_bf16", False)))
-
     def _normalized(self, img):
         # The trunk runs NHWC end to end, but its first layer -- the own 7x7 stem kernel (csrc/conv_stem.hip) -- reads the 3-channel image as
         # NCHW rows and writes NHWC: when it will run, the normalised image is produced NCHW and never converted (it used to be written
@@ -66,21 +49,12 @@ class Encoder(nn.Module):
         feat = feat.float().contiguous().reshape(x.shape[0], self.opts.n_corr_feat, -1)
         return img_code, F.normalize(feat, 2, 1)
 
-    def _features_half(self, x):
-        return self._features(x, half_res=True)
-
     def encode_img(self, img, half_res=False):
         """half_res: features at the even pixels of the feature map only (nets.ResNet_Decoder.forward)"""
-        x = self._normalized(img)
-        if self._graphable(x):
-            return self._segment("half" if half_res else "img", self._features_half if half_res else self._features)(x)
-        return self._features(x, half_res)
+        return self._features(self._normalized(img), half_res)
 
     def forward(self, img, mean_v, pp_crop, foc_crop):
-        x = self._normalized(img)
-        if self._graphable(x):
-            return self._segment("full", self._heads_from_normalized)(x, mean_v, pp_crop, foc_crop)
-        return self._heads_from_normalized(x, mean_v, pp_crop, foc_crop)
+        return self._heads_from_normalized(self._normalized(img), mean_v, pp_crop, foc_crop)
 
     def _heads_from_normalized(self, x, mean_v, pp_crop, foc_crop):
         img_code, img_feat = self._features(x)

@@ -32,8 +32,8 @@ TUNED_GEMMS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__fil
 
 def enable_gemm_tuning():
     """The GEMM-side twin of cudnn.benchmark: PyTorch's TunableOp times the rocBLAS / hipBLASLt solutions
-    for every GEMM shape the step issues and keeps the fastest (the ViT-S linears go from 0.41/0.38/0.32 ms
-    to 0.23/0.30/0.28 ms per launch on MI355X, -2.2 ms per step).  Selections recorded on an MI355X are shipped in
+    for the few library GEMMs the step still issues (the small pose / shape / texture heads and the mesh encoder's linears: every
+    large product -- ViT, convolutions, correspondence -- runs on the build's own kernels).  Selections recorded on an MI355X are shipped in
     tuning/gemm_gfx950.csv so that a fresh process starts tuned (TunableOp ignores the file if its
     library-version validators do not match, and tunes online during the first steps instead).
     SCP_GEMM_TUNING=0 disables it.  New results go to a scratch file, never back into the package."""
@@ -105,19 +105,13 @@ class Trainer:
             # buffers included
             self.reducer.broadcast_parameters(self.model, 0)
         self._group_spans = None
-        # HIP-graph replay of the static single-stream segments (scp_amd/graphed.py): the two encoder passes (forward + backward) and
-        # the frozen ViT with its pair matching.  OPT-IN and EXPERIMENTAL (SCP_GRAPHS=1 or Trainer(..., graphs=True)): measured on one
-        # MI355X in the bench workload (profiles/r04_host_enqueue.txt) the host needs 8.5-10.2 ms instead of 21.2 ms to enqueue a step;
-        # the step itself is device-bound and does not get faster (31.8 vs 31.8-32.4 ms).  In other process setups ending the
-        # capture of the encoder's backward graph has crashed inside the HIP runtime (tools/graph_variants.py); not for production.
-        # Not under SyncBatchNorm (collectives inside the segment) and not in configs[4] precision (autocast's weight-cast cache does
-        # not survive a capture).
+        # HIP-graph replay of the frozen ViT + pair matching (scp_amd/graphed.py GraphedInference; OPT-IN, SCP_GRAPHS=1 or graphs=True):
+        # saves host enqueue time, not device time.  Not in configs[4] precision (autocast's weight-cast cache does not survive capture).
         from . import fused_conv
         self._convs = [m for m in self.model.encoder.modules() if isinstance(m, torch.nn.Conv2d)]
         fused_conv.WEIGHT_EPOCH[0] += 1                 # load_network / broadcast wrote weights through .data
         self.use_graphs = (self.device.type == "cuda" and not self.sync_bn and (graphs if graphs is not None else os.environ.get("SCP_GRAPHS", "0") == "1")
                            and not bool(getattr(opts, "mixed_bf16", False)))
-        self.model.encoder.use_graphs = self.use_graphs
         self.model.pretrain_corr_net.use_graphs = self.use_graphs
 
     def batch_reshape(self, batch):

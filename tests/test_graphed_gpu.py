@@ -1,5 +1,5 @@
 """scp_amd/graphed.py (opt-in, SCP_GRAPHS=1, experimental): the forward-only replay wrapper GraphedInference against eager execution.
-GraphedSegment (forward + BACKWARD graphs behind one autograd Function) has no test here on purpose: on this ROCm stack ending the
+GraphedSegment (forward + BACKWARD graphs; since round 5 an experiment under tools/graphed_segment.py) has no test on purpose: on this ROCm stack ending the
 capture of a backward graph -- whose nodes the autograd engine's device thread records -- takes the interpreter down in
 hipStreamEndCapture in every setup tried except the bench workload's (tools/graph_mlp.py: a two-layer torch MLP is enough;
 tools/graph_variants.py).  The measurements of the full step under graphs (profiles/r04_host_enqueue.txt) come from that one setup."""

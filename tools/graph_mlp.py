@@ -14,7 +14,8 @@ if "tunable" in opts:
     torch.cuda.tunable.enable(True)
 if "warn" in opts:
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-from scp_amd.graphed import GraphedSegment
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from graphed_segment import GraphedSegment
 torch.manual_seed(0)
 net = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.ReLU(), torch.nn.Linear(128, 32)).cuda()
 seg = GraphedSegment(lambda x: (net(x),), list(net.parameters()), warmup=2)
