@@ -727,6 +727,32 @@ def main():
         sync()
         unpipelined = time.perf_counter() - t1
 
+    # the GEMM family once more with the device to itself (one HIP stream for K steps): in the overlapped schedule a launch shares
+    # the CUs with the encoder's and the rasteriser's kernels, so its in-schedule duration (the contract's `roofline.achieved`) says how
+    # the SCHEDULE treats the kernel; this leg says what the kernel does with the whole device, on the same kernel-duration clock
+    exclusive = None
+    if stream_policy.overlap() and world == 1 and gemm_clock:
+        stream_policy.MODE = "serial"
+        try:
+            tr.step(data)
+            sync()
+            with KernelClock(dino_mod, "vit_linear", 64 * args.steps + 64, device) as kc2:
+                kc2.start()
+                for _ in range(args.steps):
+                    tr.step(data)
+                sync()
+                kc2.stop()
+                exclusive = kc2.result()
+                exclusive_by_shape = getattr(kc2, "by_shape", None)
+        finally:
+            stream_policy.MODE = "overlap"
+
+    # a step whose gradients contain a NaN is "trained" with all-zero gradients (the reference's guard, trainer.py:140-150): the
+    # timing would not notice.  The last timed step's guard flag and clip norms go into the line.
+    last_clip = getattr(tr, "last_clip", None)
+    grads_ok = None if last_clip is None else {"all_finite": bool(float(last_clip[6]) == 1.0),
+                                                "group_norms_mean_v_shapenerf_pose": [float(x) for x in last_clip[:3]]}
+
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -874,6 +900,11 @@ def main():
                         "algorithmic_bytes_per_step": 4.0 * (B * ((S // 8) ** 2 + 1) * (9 * 6912 + 768) + 9 * 4608 * 384 + 384 * 384),
                         # the live figure is taken while the encoder / render streams share the device; the four layer
                         # shapes alone on an idle device, for reference (not the roofline claim):
+                        "exclusive_device": None if not exclusive else {
+                            "what": "the same launches of the same training step on ONE stream (SCP_STREAMS=serial for these K steps): "
+                                    "nothing shares the CUs with a GEMM launch; kernel-duration clock",
+                            "achieved": exclusive[0] / (exclusive[1] * 1e-3) / 1e12, "frac": exclusive[0] / (exclusive[1] * 1e-3) / 1e12 / peak,
+                            "launches": exclusive[2], "avg_launch_ms": exclusive[1] / exclusive[2], "by_shape": exclusive_by_shape},
                         "isolated": None if args.no_isolated else isolated_gemms(B * ((S // 8) ** 2 + 1)),
                         "others": others}
         elif others:
@@ -884,7 +915,7 @@ def main():
             "value": world * args.steps / elapsed, "unit": "iters/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
             "instrumented_ms_per_step": 1000.0 * instrumented / args.steps,
-            "scaling": "weak", "vs_baseline": None,
+            "scaling": "weak", "vs_baseline": None, "gradients": grads_ok,
             "dtype": "bf16 convolutions + ViT linears, f32 elsewhere (configs[4] precision; not the headline)" if args.mixed_bf16 else "f32",
             "data": "synthetic",
             "config": {"workload": ("configs[4] geometry: B=%d (batch_size %d x repeat 4) 512x512 per GPU, 2562v/5120f mesh, laptop_wild6d flags, "

@@ -165,12 +165,8 @@ __device__ __forceinline__ void finalize_statistics(const ConvArgs& g, float* ld
 // the split twin of a tile shape: same wavefront grid and MFMA tiles per wavefront
 // (round 4: its W planes are TILED -- csrc/gemm_core_split.h -- every LDS-DMA piece of the weight one contiguous KiB instead of
 // 32 rows x 32 B = 32 cache lines: the weight pieces were 3/4 of the main loop's address traffic)
-// SCP_CONV_STAGES (build-time A/B switch): depth of the operand ring of the split convolution kernels
-#ifndef SCP_CONV_STAGES
-#define SCP_CONV_STAGES 3
-#endif
 template <class CFG>
-using SplitOf = scp::SplitCfg<CFG::WM, CFG::WN, CFG::NWM, CFG::NWN, CFG::MINBLK, 3, (CFG::WM * CFG::WN <= 4), false, true, SCP_CONV_STAGES>;
+using SplitOf = scp::SplitCfg<CFG::WM, CFG::WN, CFG::NWM, CFG::NWN, CFG::MINBLK, 3, (CFG::WM * CFG::WN <= 4), false, true>;
 
 template <class FCFG, int TAPS, int EPI, bool STATS, bool SPLIT>
 __global__ __launch_bounds__(FCFG::THREADS, 2) void conv_igemm_kernel(const ConvArgs g) {

@@ -51,13 +51,12 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 // of the MFMAs: -10 %; removing the DMA: -30 %); tiled, it touches 8.
 // WTILED: the W planes are tiled (always with APLANES; a kernel that splits its fp32 A in registers may still take a tiled W).
 template <int WM_, int WN_, int NWM_, int NWN_, int MINBLK_, int NPLANES_ = 3, bool ZSTART_ = (WM_ * WN_ <= 4), bool APLANES_ = false,
-          bool WTILED_ = APLANES_, int NSTAGE_ = 2>
+          bool WTILED_ = APLANES_>
 struct SplitCfg {
     static constexpr int NPLANES = NPLANES_;
     static constexpr bool ZSTART = ZSTART_, APLANES = APLANES_, TILED = WTILED_;
     static_assert(!APLANES_ || WTILED_, "pre-split A comes with tiled W planes");
-    static_assert(NSTAGE_ == 2 || NSTAGE_ == 3, "ring of two or three stages");
-    static constexpr int WM = WM_, WN = WN_, NWM = NWM_, NWN = NWN_, NSTAGE = NSTAGE_, MINBLK = MINBLK_;
+    static constexpr int WM = WM_, WN = WN_, NWM = NWM_, NWN = NWN_, NSTAGE = 2, MINBLK = MINBLK_;
     static constexpr int BM = 32 * WM * NWM, BN = 32 * WN * NWN, BK = 16;
     static constexpr int NW = NWM * NWN, THREADS = 64 * NW;
     static constexpr int A_GROUPS = BM / 32;
@@ -389,43 +388,24 @@ struct SplitGemmCore {
         }
     }
 
-    // acc = sum over nk chunks of 16 k.  Two-stage ring: nk even and >= 2.  Three-stage ring (round 5; the convolutions): any
-    // nk >= 1 -- the DMA of chunk kc + 2 is issued at the top of chunk kc, so a chunk's operands have TWO chunks of matrix work to
-    // arrive in instead of one (a chunk of the split loop is 0.4-0.8 us of MFMAs, a global -> LDS round trip about as long).
-    // On return all LDS accesses and DMAs of this wavefront have completed.
+    // acc = sum over nk chunks of 16 k (nk even and >= 2).  On return all LDS accesses and DMAs of this wavefront have completed.
+    // (Round 5 tried a THREE-stage ring for the convolutions -- the DMA of chunk kc + 2 issued at the top of chunk kc: neutral in
+    // isolation, -0.1 .. -0.2 ms inside the step, i.e. within noise, at 60 instead of 40 KiB of LDS; not kept.
+    // profiles/r05_conv_ring_depth.txt.  Whoever retries it: wavefronts issue UNEQUAL numbers of DMA instructions per chunk when
+    // the piece counts do not divide by the wavefront count, so the partial s_waitcnt has to be per wavefront.)
     __device__ __forceinline__ void run(Acc& acc, int nk) {
 #pragma unroll
         for (int t = 0; t < CFG::NT; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc.t[t][r] = 0.f;
-        if constexpr (CFG::NSTAGE == 2) {
-            issue(0, 0);
-            for (int kc = 0; kc < nk; kc += 2) {
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                issue(kc + 1, 1);
-                compute<0>(acc);
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                if (kc + 2 < nk) issue(kc + 2, 0);
-                compute<1>(acc);
-            }
-        } else {
-            // every wavefront issues the same number of DMA instructions per chunk only when the piece counts divide evenly; a
-            // wavefront that is a piece short simply waits for "at most PER outstanding", which its shorter queue satisfies earlier
-            constexpr int PER = CFG::A_PER + CFG::W_PER;
-            issue(0, 0);
-            if (nk > 1) issue(1, 1);
-            int kc = 0;
-            auto top = [&](int next_stage) {
-                // chunk kc has landed (chunk kc + 1 may still be in flight); everyone is done reading the stage chunk kc + 2 goes to
-                if (kc + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PER) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                if (kc + 2 < nk) issue(kc + 2, next_stage);
-            };
-            while (true) {
-                top(2); compute<0>(acc); if (++kc == nk) break;
-                top(0); compute<1>(acc); if (++kc == nk) break;
-                top(1); compute<2>(acc); if (++kc == nk) break;
-            }
+        issue(0, 0);
+        for (int kc = 0; kc < nk; kc += 2) {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            issue(kc + 1, 1);
+            compute<0>(acc);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kc + 2 < nk) issue(kc + 2, 0);
+            compute<1>(acc);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }

@@ -27,6 +27,13 @@ class RasterParams(ctypes.Structure):
     ]
 
 
+class AdamWTensor(ctypes.Structure):
+    """struct scp_adamw_tensor"""
+    _fields_ = [("param", ctypes.c_ulonglong), ("flat_offset", ctypes.c_longlong), ("numel", ctypes.c_longlong),
+                ("lr", ctypes.c_float), ("weight_decay", ctypes.c_float), ("step_size", ctypes.c_float),
+                ("inv_bias_correction2_sqrt", ctypes.c_float), ("active", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
 class CropDesc(ctypes.Structure):
     """struct scp_crop_desc"""
     _fields_ = [("img_off", ctypes.c_ulonglong), ("mask_off", ctypes.c_ulonglong), ("depth_off", ctypes.c_ulonglong),
@@ -54,6 +61,7 @@ SYMBOLS = {
     "scp_project_vertices_backward": (ctypes.c_int, [_P] * 5 + [_I] * 4 + [_P] * 4),
     "scp_gradclip_workspace": (ctypes.c_size_t, []),
     "scp_gradclip": (ctypes.c_int, [_P, ctypes.c_longlong, _F, _P, _P, _P, _I, _F, _F, _F, _P, ctypes.c_size_t, _P, _P]),
+    "scp_adamw_flat": (ctypes.c_int, [_P, _P, _I, _P, _P, _P, _F, _F, _F, _P]),
     "scp_selftest_mfma_load": (ctypes.c_int, [_I, _P, _I, _I, _P, _P]),
     "scp_selftest_packed_fp32": (ctypes.c_int, [_I, _P, _I, _I, _P]),
     "scp_vit_linear": (ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 4 + [_P]),
