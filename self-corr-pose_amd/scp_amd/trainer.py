@@ -98,6 +98,8 @@ class Trainer:
         # every gradient lives in one flat buffer (p.grad = view); with torch.distributed initialised its buckets are
         # all-reduced from autograd hooks while backward is still running (scp_amd/parallel.py)
         self.grads = FlatGradients(self._trainable, process_group)
+        if hasattr(self.optim.optimizer, "attach"):
+            self.optim.optimizer.attach(self.grads)     # FlatAdamW: one launch over the flat buffer (scp_amd/optimizers.py)
         self.reducer = self.grads if self.grads.world > 1 else None
         self.rank = torch.distributed.get_rank(process_group) if torch.distributed.is_initialized() else 0
         if self.reducer is not None:

@@ -146,3 +146,67 @@ def test_fused_gradient_clip_equals_the_torch_composition(poison):
     else:
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
         assert float(res[True][0][2]) > 0.1 and float(tr.last_clip[5]) < 1.0        # the pose group really was clipped
+
+
+@pytest.mark.gpu
+def test_flat_adamw_equals_torch_adamw():
+    """optimizers.py:77-79: scp_amd.optimizers.FlatAdamW (one launch over FlatGradients' buffer, csrc/adamw.hip) against torch's
+    fused AdamW on the same gradients for 6 steps -- channels_last convolution weights, odd sizes, per-group learning rates that
+    change every step (OneCycle), a parameter that never gets a gradient and one that starts getting them late (own step count);
+    parameters to 2e-6 of scale, and a state_dict round trip continues identically"""
+    import copy
+    import torch.nn as nn
+    from scp_amd.optimizers import FlatAdamW
+    from scp_amd.parallel import FlatGradients
+    torch.manual_seed(0)
+
+    def build():
+        torch.manual_seed(1)
+        net = nn.ModuleDict({"conv": nn.Conv2d(16, 33, 3), "lin": nn.Linear(77, 5), "late": nn.Linear(9, 9), "never": nn.Linear(4, 4),
+                             "big": nn.Linear(300, 301)}).cuda()
+        net["conv"].to(memory_format=torch.channels_last)
+        return net
+
+    a, b = build(), build()
+    groups = lambda n: [{"params": list(n["conv"].parameters()) + list(n["late"].parameters())},
+                        {"params": list(n["lin"].parameters()) + list(n["never"].parameters()) + list(n["big"].parameters()), "lr": 3e-3}]
+    ref = torch.optim.AdamW(groups(a), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-4, fused=True)
+    own = FlatAdamW(groups(b), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-4)
+    fg = FlatGradients(list(b.parameters()))
+    assert own.attach(fg)
+    sched = [torch.optim.lr_scheduler.OneCycleLR(o, [2e-3, 5e-3], total_steps=20, pct_start=0.3, cycle_momentum=False) for o in (ref, own)]
+    gen = torch.Generator().manual_seed(7)
+
+    def one_step(step, ref_opt, own_opt, scheds):
+        fg.prepare()
+        for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+            pa.grad = None
+            if n.startswith("never") or (n.startswith("late") and step < 3):
+                continue
+            g = torch.randn(pa.shape, generator=gen).cuda()
+            pa.grad = g.clone().contiguous(memory_format=torch.channels_last) if pa.dim() == 4 else g.clone()
+            pb.grad.copy_(g)
+        # what FlatGradients.finish(keep_unused_none=True) leaves behind: grad = None for parameters without a gradient this step
+        for (n, _), pb in zip(a.named_parameters(), b.parameters()):
+            if n.startswith("never") or (n.startswith("late") and step < 3):
+                pb.grad = None
+        ref_opt.step(); own_opt.step()
+        for s_ in scheds:
+            s_.step()
+
+    for step in range(6):
+        one_step(step, ref, own, sched)
+    for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+        scale = float(pa.abs().max())
+        assert float((pa - pb).abs().max()) <= 2e-6 * scale, (n, float((pa - pb).abs().max()), scale)
+    # the state travels: torch's layout out, our flat buffers back in
+    sd = copy.deepcopy(own.state_dict())
+    assert len(sd["state"]) == sum(1 for n, _ in b.named_parameters() if not n.startswith("never"))
+    k0 = next(iter(sd["state"]))
+    assert set(sd["state"][k0]) == {"step", "exp_avg", "exp_avg_sq"}
+    own.load_state_dict(sd)
+    ref.load_state_dict(copy.deepcopy(ref.state_dict()))
+    for step in range(6, 9):
+        one_step(step, ref, own, sched)
+    for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+        assert float((pa - pb).abs().max()) <= 4e-6 * float(pa.abs().max()), n
