@@ -818,7 +818,9 @@ def main():
                                "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32) tiles that never leave registers; VALU-bound by the two softmaxes "
                                        "(~30 VALU instructions per score), DESIGN 4.3"}
         if mnn_ms:
-            n_pairs, ptok, kdim = B, (S // 8) ** 2, 384           # divide_by_frame: one pair per image
+            from scp_amd.losses import pair_indices
+            n_pairs = int(pair_indices(tr.model.pretrain_corr_net.divide_kind, opts.batch_size, opts.repeat)[0].shape[0])
+            ptok, kdim = (S // 8) ** 2, 384                       # image pairs of divide_fn (loss_utils.py:326-345), 32 x 32 DINO tokens each
             fl = 2.0 * n_pairs * ptok * ptok * kdim
             split = dino_mod.GEMM_MODE == "split"
             pk = BF16_MFMA_PEAK_TF / 6.0 if split else FP32_VALU_PEAK_TF

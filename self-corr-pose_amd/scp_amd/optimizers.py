@@ -56,8 +56,11 @@ class FlatAdamW(torch.optim.AdamW):
             e = self._host[i]
             e.param, e.flat_offset, e.numel = p.data_ptr(), grads.span[id(p)][0], p.numel()
         nbytes = ctypes.sizeof(self._host)
-        self._pinned = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-        self._table = torch.empty(nbytes, dtype=torch.uint8, device=flat.device)
+        # the host runs ~2 steps ahead of the device: a ring of staging buffers, each reused only behind the event of the copy that read it
+        self._pinned = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(4)]
+        self._copied = [None] * 4
+        self._slot = 0
+        self._table = [torch.empty(nbytes, dtype=torch.uint8, device=flat.device) for _ in range(4)]
         return True
 
     def _view(self, buf, p):
@@ -86,9 +89,15 @@ class FlatAdamW(torch.optim.AdamW):
             e.lr, e.weight_decay = lr, float(g["weight_decay"])
             e.step_size = lr / (1.0 - b1 ** t)
             e.inv_bias_correction2_sqrt = 1.0 / (1.0 - b2 ** t) ** 0.5
-        ctypes.memmove(self._pinned.data_ptr(), ctypes.addressof(self._host), self._pinned.numel())
-        self._table.copy_(self._pinned, non_blocking=True)
-        capi.check(capi.lib().scp_adamw_flat(ctypes.c_void_p(self._table.data_ptr()), ctypes.c_void_p(self._chunks.data_ptr()),
+        k = self._slot
+        self._slot = (k + 1) % 4
+        if self._copied[k] is not None:
+            self._copied[k].synchronize()              # four steps old: long done
+        ctypes.memmove(self._pinned[k].data_ptr(), ctypes.addressof(self._host), self._pinned[k].numel())
+        self._table[k].copy_(self._pinned[k], non_blocking=True)
+        self._copied[k] = torch.cuda.Event()
+        self._copied[k].record()
+        capi.check(capi.lib().scp_adamw_flat(ctypes.c_void_p(self._table[k].data_ptr()), ctypes.c_void_p(self._chunks.data_ptr()),
                                              self._chunks.shape[0], capi.dev_ptr(self._grads.flat, "grad"), capi.dev_ptr(self._m, "exp_avg"),
                                              capi.dev_ptr(self._v, "exp_avg_sq"), float(b1), float(b2), float(eps), capi.current_stream()),
                    "scp_adamw_flat")
