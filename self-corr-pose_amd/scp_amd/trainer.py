@@ -31,13 +31,15 @@ TUNED_GEMMS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__fil
 
 
 def enable_gemm_tuning():
-    """The GEMM-side twin of cudnn.benchmark: PyTorch's TunableOp times the rocBLAS / hipBLASLt solutions
-    for the few library GEMMs the step still issues (the small pose / shape / texture heads and the mesh encoder's linears: every
-    large product -- ViT, convolutions, correspondence -- runs on the build's own kernels).  Selections recorded on an MI355X are shipped in
-    tuning/gemm_gfx950.csv so that a fresh process starts tuned (TunableOp ignores the file if its
-    library-version validators do not match, and tunes online during the first steps instead).
-    SCP_GEMM_TUNING=0 disables it.  New results go to a scratch file, never back into the package."""
-    if os.environ.get("SCP_GEMM_TUNING", "1") == "0":
+    """PyTorch's TunableOp for the few LIBRARY GEMMs the step still issues (the pose / shape / texture heads and the mesh encoder's
+    linears, ~0.15 ms per step; every large product -- ViT, convolutions, correspondence -- runs on the build's own kernels).
+    SCP_GEMM_TUNING = "read" (default): apply the selections recorded on an MI355X and shipped in tuning/gemm_gfx950.csv, never tune
+    online (TunableOp ignores the file if its library-version validators do not match; the library heuristics then decide);
+    "online": also time the candidates of shapes the file does not hold, during the first steps (what rounds 1-4 did by default: it
+    makes the solution -- and the last bit of those products -- depend on the process, and runs every candidate kernel of the
+    library once); "0": leave TunableOp alone.  New results go to a scratch file, never back into the package."""
+    mode = os.environ.get("SCP_GEMM_TUNING", "read")
+    if mode in ("0", "off"):
         return
     tun = torch.cuda.tunable
     tun.enable(True)
@@ -46,7 +48,7 @@ def enable_gemm_tuning():
     out = os.environ.get("SCP_GEMM_TUNING_OUT") or os.path.join(tempfile.gettempdir(), "scp_tunableop_%d.csv" % os.getpid())
     tun.set_filename(out, False)
     tun.set_max_tuning_duration(30)
-    tun.tuning_enable(True)
+    tun.tuning_enable(mode in ("online", "1"))
     if os.path.exists(TUNED_GEMMS):
         tun.read_file(TUNED_GEMMS)
 

@@ -5,9 +5,9 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-SCP_GEMM_TUNING_OUT=$PWD/gpurun_out/tune_f32.csv python bench.py --steps 3 --warmup 6 --no-cpu-baseline > /dev/null
-SCP_GEMM_TUNING_OUT=$PWD/gpurun_out/tune_bf16.csv python bench.py --steps 3 --warmup 6 --no-cpu-baseline --mixed-bf16 > /dev/null
-SCP_GEMM_TUNING_OUT=$PWD/gpurun_out/tune_test.csv python bench.py --steps 3 --warmup 3 --no-cpu-baseline --workload posefit > /dev/null || true
+SCP_GEMM_TUNING=online SCP_GEMM_TUNING_OUT=$PWD/gpurun_out/tune_f32.csv python bench.py --steps 3 --warmup 6 --no-cpu-baseline > /dev/null
+SCP_GEMM_TUNING=online SCP_GEMM_TUNING_OUT=$PWD/gpurun_out/tune_bf16.csv python bench.py --steps 3 --warmup 6 --no-cpu-baseline --mixed-bf16 > /dev/null
+SCP_GEMM_TUNING=online SCP_GEMM_TUNING_OUT=$PWD/gpurun_out/tune_test.csv python bench.py --steps 3 --warmup 3 --no-cpu-baseline --workload posefit > /dev/null || true
 python3 - <<'PY'
 import os
 seen, out = set(), []
