@@ -405,6 +405,15 @@ size_t scp_conv_nhwc_splitk_workspace(int N, int H, int W, int Cin, int Cout, in
  * NULL = not wanted), one launch */
 int scp_conv_weight_planes(const float* w, long long s_co, long long s_ci, long long s_ky, long long s_kx, int Cout, int Cin, int ksize,
                            void* planes_fwd, void* planes_dgrad, void* stream);
+/* the same for MANY layers in one launch: `descs_device` = n descriptors in device memory (the strides are those of the [Cout,Cin,k,k]
+ * parameter in elements; planes_dgrad may be 0; block0 = index of the layer's first 256-thread block in the launch: layer i owns blocks
+ * [block0_i, block0_i + ceil(Cout Cin k k / 256)), block0 ascending, total_blocks = their sum).  Same bits as n single calls. */
+typedef struct scp_conv_planes_desc {
+    unsigned long long w, planes_fwd, planes_dgrad;
+    long long s_co, s_ci, s_ky, s_kx, block0;
+    int Cout, Cin, ksize, pad_;
+} scp_conv_planes_desc;
+int scp_conv_weight_planes_batch(const scp_conv_planes_desc* descs_device, int n, long long total_blocks, void* stream);
 /* ---- encoder stem: 7x7 / stride 2 / pad 3, 3 -> 64 channels (torchvision ResNet18 conv1 + bn1, image_encoder.py:122-124) -------
  * csrc/conv_stem.hip, fp32 matrix cores.  x [N,3,H,W] NCHW contiguous (H, W even), w [64,3,7,7] with element strides ws_*,
  * y [N,H/2,W/2,64] NHWC raw convolution.  workspace != NULL: also the batch statistics of the BatchNorm that follows, exactly as

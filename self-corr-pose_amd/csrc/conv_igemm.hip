@@ -422,6 +422,38 @@ __global__ void conv_weight_planes_kernel(const float* __restrict__ w, long s_co
     }
 }
 
+// every stale layer of the encoder in ONE launch (Trainer.step refreshes ~27 plane sets right after the optimizer, on the critical
+// path before the forward: 27 launches of 4-30 us each): layer = the last descriptor whose first block is <= blockIdx.x
+__global__ void conv_weight_planes_batch_kernel(const scp_conv_planes_desc* __restrict__ descs, int n) {
+    int li = 0;
+    for (int i = 1; i < n; i++)
+        if ((long long)blockIdx.x >= descs[i].block0) li = i;
+    const scp_conv_planes_desc d = descs[li];
+    const int Cout = d.Cout, Cin = d.Cin, k = d.ksize;
+    const long total = (long)Cout * Cin * k * k;
+    const long i = ((long)blockIdx.x - d.block0) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float* w = reinterpret_cast<const float*>(d.w);
+    __bf16* fwd = reinterpret_cast<__bf16*>(d.planes_fwd);
+    __bf16* dgrad = reinterpret_cast<__bf16*>(d.planes_dgrad);
+    const int ci = (int)(i % Cin);
+    long r = i / Cin;
+    const int kx = (int)(r % k);
+    r /= k;
+    const int ky = (int)(r % k), co = (int)(r / k);
+    const float v = w[co * d.s_co + ci * d.s_ci + ky * d.s_ky + kx * d.s_kx];
+    const __bf16 h = (__bf16)v;
+    const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);
+    const size_t o = scp::tiled_plane_offset(co, (ky * k + kx) * Cin + ci, 0, (k * k * Cin) >> 4);
+    fwd[o] = h; fwd[o + 512] = m; fwd[o + 1024] = l;
+    if (dgrad) {
+        const size_t j = scp::tiled_plane_offset(ci, ((k - 1 - ky) * k + (k - 1 - kx)) * Cout + co, 0, (k * k * Cout) >> 4);
+        dgrad[j] = h; dgrad[j + 512] = m; dgrad[j + 1024] = l;
+    }
+}
+
 using Cfg256x64 = scp::GemmCfg<2, 2, 4, 1, 2, 2>;     // 64-channel layers at 64 x 64 resolution
 using Cfg64x128 = scp::GemmCfg<1, 2, 2, 2, 2, 2>;
 using Cfg64x64 = scp::GemmCfg<1, 1, 2, 2, 2, 2>;
@@ -710,6 +742,14 @@ extern "C" int scp_conv_nhwc_dgrad_stride2(const float* dy, const void* w_dgrad_
     else if (cfg == 1) launch(Cfg64x128{});
     else launch(Cfg64x64{});
     return scp::check_launch("conv_nhwc_dgrad_stride2");
+}
+
+extern "C" int scp_conv_weight_planes_batch(const scp_conv_planes_desc* descs_device, int n, long long total_blocks, void* stream) {
+    if (!descs_device || n <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffLL)
+        return scp::fail(hipErrorInvalidValue, "conv_weight_planes_batch: bad argument");
+    hipLaunchKernelGGL(conv_weight_planes_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       descs_device, n);
+    return scp::check_launch("conv_weight_planes_batch");
 }
 
 extern "C" int scp_conv_weight_planes(const float* w, long long s_co, long long s_ci, long long s_ky, long long s_kx, int Cout, int Cin,

@@ -34,6 +34,13 @@ class AdamWTensor(ctypes.Structure):
                 ("inv_bias_correction2_sqrt", ctypes.c_float), ("active", ctypes.c_int), ("pad_", ctypes.c_int)]
 
 
+class ConvPlanesDesc(ctypes.Structure):
+    """struct scp_conv_planes_desc"""
+    _fields_ = [("w", ctypes.c_ulonglong), ("planes_fwd", ctypes.c_ulonglong), ("planes_dgrad", ctypes.c_ulonglong),
+                ("s_co", ctypes.c_longlong), ("s_ci", ctypes.c_longlong), ("s_ky", ctypes.c_longlong), ("s_kx", ctypes.c_longlong),
+                ("block0", ctypes.c_longlong), ("Cout", ctypes.c_int), ("Cin", ctypes.c_int), ("ksize", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
 class CropDesc(ctypes.Structure):
     """struct scp_crop_desc"""
     _fields_ = [("img_off", ctypes.c_ulonglong), ("mask_off", ctypes.c_ulonglong), ("depth_off", ctypes.c_ulonglong),
@@ -62,6 +69,7 @@ SYMBOLS = {
     "scp_gradclip_workspace": (ctypes.c_size_t, []),
     "scp_gradclip": (ctypes.c_int, [_P, ctypes.c_longlong, _F, _P, _P, _P, _I, _F, _F, _F, _P, ctypes.c_size_t, _P, _P]),
     "scp_adamw_flat": (ctypes.c_int, [_P, _P, _I, _P, _P, _P, _F, _F, _F, _P]),
+    "scp_conv_weight_planes_batch": (ctypes.c_int, [_P, _I, ctypes.c_longlong, _P]),
     "scp_selftest_mfma_load": (ctypes.c_int, [_I, _P, _I, _I, _P, _P]),
     "scp_selftest_packed_fp32": (ctypes.c_int, [_I, _P, _I, _I, _P]),
     "scp_vit_linear": (ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 4 + [_P]),

@@ -173,15 +173,66 @@ WEIGHT_EPOCH = [0]
 
 def refresh_planes(convs):
     """rebuild the split planes of every convolution in `convs` whose weight changed since they were built (Trainer.step: once per
-    step, main stream, before the forward)"""
+    step, main stream, before the forward).  After an optimizer step that is every layer: they go out as ONE launch
+    (scp_conv_weight_planes_batch; the ~27 single launches sat on the critical path between the optimizer and the forward)."""
     if CONV_MODE != "split":
         return
+    todo = []
     for conv in convs:
         w = conv.weight
         # only the layers the own kernels run (own_forward_ok's shape rules: 3x3 / 1x1, Cin a power of two >= 32)
         if w.is_cuda and w.dtype == torch.float32 and w.shape[2] == w.shape[3] and w.shape[2] in (1, 3) and w.shape[1] >= 32 and _pow2(w.shape[1]):
-            with_dgrad = (w.requires_grad and _own_dgrad_ok(w, conv.stride[0])) or "dgrad" in conv.__dict__.get("_scp_planes", {})
+            cache = conv.__dict__.get("_scp_planes", {})
+            with_dgrad = (w.requires_grad and _own_dgrad_ok(w, conv.stride[0])) or "dgrad" in cache
+            key = (w.data_ptr(), w._version, str(w.device), WEIGHT_EPOCH[0])
+            if cache.get("key") != key or (with_dgrad and "dgrad" not in cache):
+                todo.append((conv, with_dgrad, key))
+    if len(todo) < 2 or capi.CAPTURING or CHECK_PLANES or os.environ.get("SCP_PLANES_BATCH", "1") != "1":
+        for conv, with_dgrad, _ in todo:
             weight_planes(conv, with_dgrad=with_dgrad)
+        return
+    dev = todo[0][0].weight.device
+    cur = torch.cuda.current_stream(dev)
+    descs = []
+    for conv, with_dgrad, key in todo:
+        w = conv.weight
+        cache = conv.__dict__.get("_scp_planes")
+        if cache is None:
+            cache = conv.__dict__["_scp_planes"] = {"key": None, "readers": {}}
+            conv.register_load_state_dict_post_hook(lambda module, incompatible: invalidate())
+        cout, cin, k, _ = w.shape
+        if "fwd" not in cache:
+            cache["fwd"] = torch.empty(tiled_planes_numel(cout, k * k * cin), dtype=torch.bfloat16, device=w.device)
+        if with_dgrad and "dgrad" not in cache:
+            cache["dgrad"] = torch.empty(tiled_planes_numel(cin, k * k * cout), dtype=torch.bfloat16, device=w.device)
+        for other in cache["readers"].values():        # streams that read the previous contents finish first (see weight_planes)
+            cur.wait_stream(other)
+        cache["readers"] = {}
+        descs.append((w.data_ptr(), cache["fwd"].data_ptr(), cache["dgrad"].data_ptr() if "dgrad" in cache else 0,
+                      w.stride(0), w.stride(1), w.stride(2), w.stride(3), cout, cin, k))
+    sig = tuple(descs)
+    table = _BATCH_TABLES.get(sig)
+    if table is None:
+        arr = (capi.ConvPlanesDesc * len(descs))()
+        block0 = 0
+        for e, d in zip(arr, descs):
+            e.w, e.planes_fwd, e.planes_dgrad, e.s_co, e.s_ci, e.s_ky, e.s_kx, e.Cout, e.Cin, e.ksize = d
+            e.block0 = block0
+            block0 += (d[7] * d[8] * d[9] * d[9] + 255) // 256
+        host = torch.empty(ctypes.sizeof(arr), dtype=torch.uint8)
+        ctypes.memmove(host.data_ptr(), ctypes.addressof(arr), host.numel())
+        _BATCH_TABLES.clear()                          # pointers of a previous model are of no use to anyone
+        table = _BATCH_TABLES[sig] = (host.to(dev), len(descs), block0)
+    capi.check(capi.lib().scp_conv_weight_planes_batch(ctypes.c_void_p(table[0].data_ptr()), table[1], table[2], capi.current_stream()),
+               "conv_weight_planes_batch")
+    built = torch.cuda.Event()
+    built.record(cur)
+    for conv, _, key in todo:
+        cache = conv.__dict__["_scp_planes"]
+        cache["key"], cache["built_on"], cache["built"] = key, cur, built
+
+
+_BATCH_TABLES = {}
 
 
 def _planes_arg(conv, x, stride):

@@ -300,3 +300,41 @@ def test_weight_planes_follow_every_way_a_weight_can_change(conv_mode, monkeypat
     conv.weight.data.mul_(3.0)
     with pytest.raises(RuntimeError, match="without its split planes"):
         check("stale")
+
+
+def test_batched_plane_refresh_equals_the_per_layer_launches(conv_mode, monkeypatch):
+    """fused_conv.refresh_planes: every stale layer in ONE launch (scp_conv_weight_planes_batch) writes the same bits as one
+    scp_conv_weight_planes launch per layer -- contiguous and channels_last weights, 3x3 and 1x1, with and without the input-gradient set"""
+    from scp_amd import fused_conv
+    if conv_mode != "split":
+        pytest.skip("planes exist in split mode only")
+    torch.manual_seed(5)
+    convs = [nn.Conv2d(64, 64, 3, padding=1), nn.Conv2d(64, 128, 3, stride=2, padding=1), nn.Conv2d(128, 32, 1), nn.Conv2d(256, 512, 3, padding=1)]
+    convs = [c.cuda() for c in convs]
+    convs[1].to(memory_format=torch.channels_last)
+    convs[3].to(memory_format=torch.channels_last)
+    convs[2].weight.requires_grad_(False)                 # no input-gradient planes wanted for this one
+    snaps = {}
+    for batch in ("1", "0"):
+        monkeypatch.setenv("SCP_PLANES_BATCH", batch)
+        for c in convs:
+            c.__dict__.pop("_scp_planes", None)
+        fused_conv.invalidate()
+        fused_conv.refresh_planes(convs)
+        torch.cuda.synchronize()
+        snaps[batch] = [(c._scp_planes["fwd"].clone(), c._scp_planes["dgrad"].clone() if "dgrad" in c._scp_planes else None) for c in convs]
+    for (fa, da), (fb, db) in zip(snaps["1"], snaps["0"]):
+        assert torch.equal(fa.view(torch.int16), fb.view(torch.int16))
+        assert (da is None) == (db is None) and (da is None or torch.equal(da.view(torch.int16), db.view(torch.int16)))
+    assert snaps["1"][2][1] is None and snaps["1"][0][1] is not None
+    # and a second refresh after a weight update reuses the cached descriptor table
+    monkeypatch.setenv("SCP_PLANES_BATCH", "1")
+    with torch.no_grad():
+        for c in convs:
+            c.weight.mul_(1.25)
+    fused_conv.refresh_planes(convs)
+    x = torch.randn(2, 64, 16, 16, device="cuda").contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        got = fused_conv.conv_bias_leaky(x, convs[0], slope=1.0)
+        ref = F.conv2d(x.double(), convs[0].weight.double(), convs[0].bias.double(), padding=1)
+    _close(got, ref, 2e-5, "after batched refresh")
