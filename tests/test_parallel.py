@@ -193,11 +193,11 @@ def _trainer_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def _run(worker, world=2):
+def _run(worker, world=2, extra=()):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -357,20 +357,14 @@ def test_two_rank_rccl_gradient_equals_joint_batch():
     assert all(v >= 2 for v in got.values()), got
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["overlap", "serial"])
-def test_flat_gradients_over_rccl_single_rank(mode, monkeypatch):
-    """the CUDA side of the all-reduce (views with channels_last strides, async RCCL work objects; SCP_STREAMS=overlap: communication
-    stream, events, buckets launched from the gradient hooks; serial, the default: no communication stream, every bucket goes out from
-    finish()) on ONE GPU: a 1-rank nccl group with force_collectives -- the sum over one rank must equal plain autograd and a second
-    step must reuse the same buffers"""
-    from scp_amd import streams
-    monkeypatch.setattr(streams, "MODE", mode)
+def _rccl_single_rank_worker(rank, world, port, out, mode):
     for p in (ROOT, os.path.join(ROOT, "self-corr-pose_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
+    from scp_amd import streams
+    streams.MODE = mode
     from scp_amd.parallel import FlatGradients
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         torch.manual_seed(0)
@@ -393,5 +387,17 @@ def test_flat_gradients_over_rccl_single_rank(mode, monkeypatch):
                 assert p.grad.data_ptr() == red.views[id(p)].data_ptr() and p.grad.stride() == p.stride()
                 torch.testing.assert_close(p.grad, g, rtol=1e-5, atol=1e-6)
             assert flat.data_ptr() == red.flat.data_ptr()
+        out.put((rank, True))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["overlap", "serial"])
+def test_flat_gradients_over_rccl_single_rank(mode):
+    """the CUDA side of the all-reduce (views with channels_last strides, async RCCL work objects; SCP_STREAMS=overlap, the default:
+    communication stream, events, buckets launched from the gradient hooks; serial: no communication stream, every bucket goes out from
+    finish()) on ONE GPU: a 1-rank nccl group with force_collectives -- the sum over one rank must equal plain autograd and a second
+    step must reuse the same buffers.  In its own process like the 2-rank tests: an RCCL group inside the long-lived pytest process
+    aborted twice in a backward when this file ran after tests/test_step_gpu.py (round 5; not reproduced in isolation)."""
+    _run(_rccl_single_rank_worker, world=1, extra=(mode,))
