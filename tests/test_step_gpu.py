@@ -215,11 +215,12 @@ def test_full_step_b32_headline_config_vs_oracle_backend(monkeypatch):
     bad = {k: v for k, v in report.items() if not k[1].startswith("grad_") and v[0] > v[1]}
     assert not bad, bad
     # gradients: the CPU side sums in other orders (oneDNN / C rasteriser in pixel order vs wavefront trees / atomics) and the ReLU /
-    # hard-footprint branches of a few pixels flip with the encoder's rounding; thresholds = what the B = 8 test holds, tightened for
-    # the pinned leg where nothing upstream differs
+    # hard-footprint branches of a few pixels flip with the encoder's rounding.  At this batch those effects average out: observed
+    # (MI355X, round 5) pinned rel-L2 <= 1.2e-3 / cos >= 0.9999993, free running <= 2.9e-3 / >= 0.9999957 -- held to 5e-3 / 0.99998 and
+    # 1.5e-2 / 0.9999 (the small-batch tests above keep their wider bands: there a single flipped pixel is a visible share of a gradient)
     for (leg, k), (rel, cos) in report.items():
         if k.startswith("grad_"):
-            lim_rel, lim_cos = (2e-2, 0.9998) if leg == "pinned" else (5e-2, 0.9995)
+            lim_rel, lim_cos = (5e-3, 0.99998) if leg == "pinned" else (1.5e-2, 0.9999)
             assert rel <= lim_rel and cos >= lim_cos, (leg, k, rel, cos)
 
 
