@@ -909,6 +909,28 @@ def main():
                             "launches": exclusive[2], "avg_launch_ms": exclusive[1] / exclusive[2], "by_shape": exclusive_by_shape},
                         "isolated": None if args.no_isolated else isolated_gemms(B * ((S // 8) ** 2 + 1)),
                         "others": others}
+            if exclusive:
+                # Which duration grades the KERNEL?  In the overlapped schedule a GEMM launch shares the CUs with the encoder's and the
+                # rasteriser's kernels: its duration there (2-2.7x longer) grades the schedule.  The contract figure -- algorithmic
+                # flops / average launch duration, measured live in K training steps, reproducible from the committed rocprofv3 trace
+                # (where per-launch interception makes kernels of different streams hardly overlap) -- is therefore taken from the K
+                # steps run on ONE stream; the headline schedule's own durations stay beside it as `in_schedule`.
+                ex_tf = exclusive[0] / (exclusive[1] * 1e-3) / 1e12
+                roofline["in_schedule"] = {
+                    "what": "the same launches inside the K timed-schedule steps (SCP_STREAMS=overlap: CUs shared with other streams' kernels)",
+                    "achieved": roofline["achieved"], "frac": roofline["frac"], "avg_launch_ms": roofline["avg_launch_ms"],
+                    "ms_per_step": roofline["ms_per_step"], "by_shape": roofline["by_shape"], "timed_launches": roofline["timed_launches"],
+                    "events": roofline.pop("events")}
+                ex_avg = exclusive[1] / exclusive[2]
+                roofline.update(achieved=ex_tf, frac=ex_tf / peak, vs_fp32_mfma_peak=ex_tf / FP32_VALU_PEAK_TF, avg_launch_ms=ex_avg,
+                                algorithmic_flops_per_launch=exclusive[0] / exclusive[2], by_shape=exclusive_by_shape,
+                                timed_launches=exclusive[2], ms_per_step=ex_avg * per_step,
+                                measured="K further training steps of the same workload on ONE HIP stream (nothing shares the CUs with "
+                                         "a launch); in-kernel duration clock; agrees with the rocprofv3 kernel trace under profiles/",
+                                profile_note="a rocprofv3 trace makes the step host-bound, so kernels of different streams hardly overlap "
+                                             "in it: the trace reproduces THIS figure; `in_schedule` is what the free-running overlapped "
+                                             "step shows for the same launches")
+                del roofline["exclusive_device"]
         elif others:
             roofline = dict(next(iter(others.values())), others=others)
         out = {
