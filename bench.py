@@ -730,13 +730,20 @@ def main():
     # the GEMM family once more with the device to itself (one HIP stream for K steps): in the overlapped schedule a launch shares
     # the CUs with the encoder's and the rasteriser's kernels, so its in-schedule duration (the contract's `roofline.achieved`) says how
     # the SCHEDULE treats the kernel; this leg says what the kernel does with the whole device, on the same kernel-duration clock
-    exclusive = None
+    exclusive, in_schedule_ms = None, None
     if stream_policy.overlap() and world == 1 and gemm_clock:
         stream_policy.MODE = "serial"
         try:
             tr.step(data)
             sync()
-            with KernelClock(dino_mod, "vit_linear", 64 * args.steps + 64, device) as kc2:
+            with KernelClock(dino_mod, "vit_linear", 64 * args.steps + 64, device) as kc2, \
+                    KernelTimer(native, "backward_soft_rasterize", is_softtex) as kt2, \
+                    KernelTimer(native, "forward_soft_rasterize", fwd_softtex) as ft2, \
+                    KernelTimer(dino_mod, "fused_attention", lambda *a, **k: len(a) <= 6 and k.get("q_rows") is None, stride=3) as at2, \
+                    KernelTimer(clib, "scp_fvm_forward", anycall) as fvf2, KernelTimer(clib, "scp_fvm_backward", anycall) as fvb2, \
+                    KernelTimer(clib, "scp_mutual_nn_fused", anycall) as mnt2:
+                for t_ in (kt2, ft2, at2, fvf2, fvb2, mnt2):
+                    t_.enabled = True
                 kc2.start()
                 for _ in range(args.steps):
                     tr.step(data)
@@ -744,6 +751,11 @@ def main():
                 kc2.stop()
                 exclusive = kc2.result()
                 exclusive_by_shape = getattr(kc2, "by_shape", None)
+                # the other hand-written kernels on the same footing: their in-schedule averages are kept beside these
+                in_schedule_ms = {"raster_backward": kernel_ms, "raster_forward": fwd_raster_ms, "vit_attention": attn_ms,
+                                  "fvm_forward": fvm_fwd_ms, "fvm_backward": fvm_bwd_ms, "mutual_nn_fused": mnn_ms}
+                kernel_ms, fwd_raster_ms, attn_ms = kt2.mean_ms() or kernel_ms, ft2.mean_ms() or fwd_raster_ms, at2.mean_ms() or attn_ms
+                fvm_fwd_ms, fvm_bwd_ms, mnn_ms = fvf2.mean_ms() or fvm_fwd_ms, fvb2.mean_ms() or fvm_bwd_ms, mnt2.mean_ms() or mnn_ms
         finally:
             stream_policy.MODE = "overlap"
 
@@ -845,6 +857,10 @@ def main():
                 # the live figure is taken while the encoder / render streams share the device; the same kernel alone on
                 # an idle device, for reference (not the roofline claim):
                 "isolated": None if args.no_isolated else isolated_attention(B, n_tok, heads, hd, flops)}
+        if in_schedule_ms:
+            for k_, v_ in others.items():
+                v_["measured"] = "K training steps on ONE HIP stream (the kernel owns the device), HIP events around the launch"
+                v_["in_schedule_avg_launch_ms"] = in_schedule_ms.get(k_)
         roofline = None
         if gemm_total_ms:
             fl = float(np.sum(gemm_flops[-gemm_launches:]))
