@@ -424,33 +424,41 @@ __global__ void conv_weight_planes_kernel(const float* __restrict__ w, long s_co
 
 // every stale layer of the encoder in ONE launch (Trainer.step refreshes ~27 plane sets right after the optimizer, on the critical
 // path before the forward: 27 launches of 4-30 us each): layer = the last descriptor whose first block is <= blockIdx.x
-__global__ void conv_weight_planes_batch_kernel(const scp_conv_planes_desc* __restrict__ descs, int n) {
-    int li = 0;
-    for (int i = 1; i < n; i++)
-        if ((long long)blockIdx.x >= descs[i].block0) li = i;
-    const scp_conv_planes_desc d = descs[li];
+__global__ __launch_bounds__(256) void conv_weight_planes_batch_kernel(const scp_conv_planes_desc* __restrict__ descs, int n) {
+    // the layer of this block: binary search over the ascending block0 (a linear walk over the ~27 descriptors was ~27 dependent scalar
+    // loads in front of every block's first useful instruction: 160 us per launch for 20 us worth of traffic)
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((long long)blockIdx.x >= descs[mid].block0) lo = mid; else hi = mid - 1;
+    }
+    const scp_conv_planes_desc d = descs[lo];
     const int Cout = d.Cout, Cin = d.Cin, k = d.ksize;
     const long total = (long)Cout * Cin * k * k;
-    const long i = ((long)blockIdx.x - d.block0) * blockDim.x + threadIdx.x;
-    if (i >= total) return;
     const float* w = reinterpret_cast<const float*>(d.w);
     __bf16* fwd = reinterpret_cast<__bf16*>(d.planes_fwd);
     __bf16* dgrad = reinterpret_cast<__bf16*>(d.planes_dgrad);
-    const int ci = (int)(i % Cin);
-    long r = i / Cin;
-    const int kx = (int)(r % k);
-    r /= k;
-    const int ky = (int)(r % k), co = (int)(r / k);
-    const float v = w[co * d.s_co + ci * d.s_ci + ky * d.s_ky + kx * d.s_kx];
-    const __bf16 h = (__bf16)v;
-    const float r1 = v - (float)h;
-    const __bf16 m = (__bf16)r1;
-    const __bf16 l = (__bf16)(r1 - (float)m);
-    const size_t o = scp::tiled_plane_offset(co, (ky * k + kx) * Cin + ci, 0, (k * k * Cin) >> 4);
-    fwd[o] = h; fwd[o + 512] = m; fwd[o + 1024] = l;
-    if (dgrad) {
-        const size_t j = scp::tiled_plane_offset(ci, ((k - 1 - ky) * k + (k - 1 - kx)) * Cout + co, 0, (k * k * Cout) >> 4);
-        dgrad[j] = h; dgrad[j + 512] = m; dgrad[j + 1024] = l;
+    const long first = ((long)blockIdx.x - d.block0) * SCP_CONV_PLANES_BLOCK_ELEMS + threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < SCP_CONV_PLANES_BLOCK_ELEMS / 256; e++) {
+        const long i = first + e * 256;
+        if (i >= total) return;
+        const int ci = (int)(i % Cin);
+        long r = i / Cin;
+        const int kx = (int)(r % k);
+        r /= k;
+        const int ky = (int)(r % k), co = (int)(r / k);
+        const float v = w[co * d.s_co + ci * d.s_ci + ky * d.s_ky + kx * d.s_kx];
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const __bf16 l = (__bf16)(r1 - (float)m);
+        const size_t o = scp::tiled_plane_offset(co, (ky * k + kx) * Cin + ci, 0, (k * k * Cin) >> 4);
+        fwd[o] = h; fwd[o + 512] = m; fwd[o + 1024] = l;
+        if (dgrad) {
+            const size_t j = scp::tiled_plane_offset(ci, ((k - 1 - ky) * k + (k - 1 - kx)) * Cout + co, 0, (k * k * Cout) >> 4);
+            dgrad[j] = h; dgrad[j + 512] = m; dgrad[j + 1024] = l;
+        }
     }
 }
 

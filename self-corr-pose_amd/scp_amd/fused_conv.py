@@ -218,7 +218,7 @@ def refresh_planes(convs):
         for e, d in zip(arr, descs):
             e.w, e.planes_fwd, e.planes_dgrad, e.s_co, e.s_ci, e.s_ky, e.s_kx, e.Cout, e.Cin, e.ksize = d
             e.block0 = block0
-            block0 += (d[7] * d[8] * d[9] * d[9] + 255) // 256
+            block0 += (d[7] * d[8] * d[9] * d[9] + capi.CONV_PLANES_BLOCK_ELEMS - 1) // capi.CONV_PLANES_BLOCK_ELEMS
         host = torch.empty(ctypes.sizeof(arr), dtype=torch.uint8)
         ctypes.memmove(host.data_ptr(), ctypes.addressof(arr), host.numel())
         _BATCH_TABLES.clear()                          # pointers of a previous model are of no use to anyone

@@ -149,6 +149,61 @@ def test_fused_gradient_clip_equals_the_torch_composition(poison):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("offset,n", [(0, 100003), (1, 65537), (3, 4096 * 5 + 2), (2, 5), (0, 3)])
+@pytest.mark.parametrize("poison", [False, True])
+def test_gradclip_entry_point_on_unaligned_odd_buffers(offset, n, poison):
+    """scp_gradclip through the C ABI on a buffer that starts off a 16-byte boundary, with a length that is no multiple of 4 and ranges
+    that begin / end inside a float4 chunk (1- and 2-element ranges, a gap, adjacent ranges of different groups) -- the vector body, its
+    head / tail lanes and the element-wise branch of a straddling chunk against float64 on the host; twice the same bits"""
+    import ctypes
+    from scp_amd import capi
+    L = capi.lib()
+    gen = torch.Generator().manual_seed(n + offset)
+    base = torch.randn(n + 8, generator=gen).cuda()
+    ranges = [(0, min(1, n), 0), (min(1, n), min(3, n), 1), (min(6, n), min(n, 4099), 2), (min(n, 4099), min(n, 4101), 0),
+              (min(n, 50001), n, 1)]
+    ranges = [r for r in ranges if r[1] > r[0]]
+    mx = (0.05, 0.7, 1e9)
+    ws_bytes = L.scp_gradclip_workspace()
+    outs = []
+    for rep in range(2):
+        buf = base.clone()
+        flat = buf[offset:offset + n]
+        assert flat.data_ptr() % 16 == (4 * offset) % 16
+        if poison:
+            flat[n // 2] = float("nan")
+        ws = torch.zeros(ws_bytes // 8 + 1, dtype=torch.float64, device="cuda")
+        result = torch.zeros(8, device="cuda")
+        arr = lambda vals, t: (t * len(vals))(*vals)
+        capi.check(L.scp_gradclip(ctypes.c_void_p(flat.data_ptr()), n, ctypes.c_float(0.5), arr([r[0] for r in ranges], ctypes.c_longlong),
+                                  arr([r[1] for r in ranges], ctypes.c_longlong), arr([r[2] for r in ranges], ctypes.c_int), len(ranges),
+                                  ctypes.c_float(mx[0]), ctypes.c_float(mx[1]), ctypes.c_float(mx[2]), ctypes.c_void_p(ws.data_ptr()),
+                                  ws_bytes, ctypes.c_void_p(result.data_ptr()), capi.current_stream()), "scp_gradclip")
+        outs.append((buf.cpu(), result.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    got, res = outs[0]
+    assert torch.equal(got[:offset], base.cpu()[:offset]) and torch.equal(got[offset + n:], base.cpu()[offset + n:])    # nothing outside
+    if poison:
+        assert float(got[offset:offset + n].abs().max()) == 0.0 and float(res[6]) == 0.0 and float(res[:3].abs().max()) == 0.0
+        return
+    g = base.cpu()[offset:offset + n].double() * 0.5
+    ss = [0.0, 0.0, 0.0]
+    grp = torch.full((n,), -1, dtype=torch.long)
+    for b, e, k in ranges:
+        ss[k] += float((g[b:e] ** 2).sum())
+        grp[b:e] = k
+    want = g.clone()
+    for k in range(3):
+        norm = np.float32(np.sqrt(ss[k]))
+        coef = min(np.float32(mx[k]) / (norm + np.float32(1e-6)), np.float32(1.0))
+        assert abs(float(res[k]) - float(norm)) <= 2e-6 * max(float(norm), 1e-30)
+        assert abs(float(res[3 + k]) - float(coef)) <= 4e-6 * float(coef)
+        want[grp == k] *= float(res[3 + k])
+    assert float(res[6]) == 1.0
+    assert float((got[offset:offset + n].double() - want).abs().max()) <= 2e-7 * max(float(want.abs().max()), 1e-30)
+
+
+@pytest.mark.gpu
 def test_flat_adamw_equals_torch_adamw():
     """optimizers.py:77-79: scp_amd.optimizers.FlatAdamW (one launch over FlatGradients' buffer, csrc/adamw.hip) against torch's
     fused AdamW on the same gradients for 6 steps -- channels_last convolution weights, odd sizes, per-group learning rates that
