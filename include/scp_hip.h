@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SCP_ABI_VERSION 5
+#define SCP_ABI_VERSION 6
 
 /* enum values = the integer ids the reference passes (functional/soft_rasterize.py:22-25) */
 enum { SCP_DIST_HARD = 0, SCP_DIST_BARYCENTRIC = 1, SCP_DIST_EUCLIDEAN = 2 };
@@ -406,10 +406,10 @@ size_t scp_conv_nhwc_splitk_workspace(int N, int H, int W, int Cin, int Cout, in
 int scp_conv_weight_planes(const float* w, long long s_co, long long s_ci, long long s_ky, long long s_kx, int Cout, int Cin, int ksize,
                            void* planes_fwd, void* planes_dgrad, void* stream);
 /* the same for MANY layers in one launch: `descs_device` = n descriptors in device memory (the strides are those of the [Cout,Cin,k,k]
- * parameter in elements; planes_dgrad may be 0; block0 = index of the layer's first workgroup in the launch: layer i owns workgroups
- * [block0_i, block0_i + ceil(Cout Cin k k / SCP_CONV_PLANES_BLOCK_ELEMS)), block0 ascending, total_blocks = their sum).  Same bits as
- * n single calls. */
-#define SCP_CONV_PLANES_BLOCK_ELEMS 1024
+ * parameter in elements; planes_dgrad may be 0; block0 = index of the layer's first workgroup in the launch: a workgroup converts one
+ * SCP_CONV_PLANES_TILE x SCP_CONV_PLANES_TILE tile of (Cout, Cin) with all its taps, layer i owns workgroups
+ * [block0_i, block0_i + ceil(Cout / TILE) * ceil(Cin / TILE)), block0 ascending, total_blocks = their sum).  Same bits as n single calls. */
+#define SCP_CONV_PLANES_TILE 32
 typedef struct scp_conv_planes_desc {
     unsigned long long w, planes_fwd, planes_dgrad;
     long long s_co, s_ci, s_ky, s_kx, block0;

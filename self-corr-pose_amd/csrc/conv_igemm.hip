@@ -423,42 +423,73 @@ __global__ void conv_weight_planes_kernel(const float* __restrict__ w, long s_co
 }
 
 // every stale layer of the encoder in ONE launch (Trainer.step refreshes ~27 plane sets right after the optimizer, on the critical
-// path before the forward: 27 launches of 4-30 us each): layer = the last descriptor whose first block is <= blockIdx.x
+// path before the forward).  A workgroup owns a 32 (co) x 32 (ci) tile of one layer with all its taps: the tile is read in the weight's
+// own memory order (contiguous [Cout,Cin,k,k]: 32 k k floats per output channel; channels_last: 32 floats per tap), parked in LDS and
+// written out twice -- forward planes with ci running along a lane row, input-gradient planes with co running along it -- so that every
+// store instruction of a wavefront fills whole 32-byte rows of a [32 rows][16 k] plane tile (the element-per-thread version scattered the
+// input-gradient planes as 2-byte stores 1 KB apart: 160-300 us per step for 20 us worth of traffic).
+constexpr int PT = SCP_CONV_PLANES_TILE, PTAPS = 9;
 __global__ __launch_bounds__(256) void conv_weight_planes_batch_kernel(const scp_conv_planes_desc* __restrict__ descs, int n) {
-    // the layer of this block: binary search over the ascending block0 (a linear walk over the ~27 descriptors was ~27 dependent scalar
-    // loads in front of every block's first useful instruction: 160 us per launch for 20 us worth of traffic)
+    // [tap][co][ci], rows padded by one float and taps by three: conflict-free in both write-out orders, <= 2-way in the read-in order
+    constexpr int PROW = PT + 1, PTAP = PT * PROW + 3;
+    __shared__ float park[PTAPS * PTAP];
+    // the layer of this workgroup: binary search over the ascending block0
     int lo = 0, hi = n - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if ((long long)blockIdx.x >= descs[mid].block0) lo = mid; else hi = mid - 1;
     }
     const scp_conv_planes_desc d = descs[lo];
-    const int Cout = d.Cout, Cin = d.Cin, k = d.ksize;
-    const long total = (long)Cout * Cin * k * k;
+    const int Cout = d.Cout, Cin = d.Cin, k = d.ksize, kk = k * k;
     const float* w = reinterpret_cast<const float*>(d.w);
     __bf16* fwd = reinterpret_cast<__bf16*>(d.planes_fwd);
     __bf16* dgrad = reinterpret_cast<__bf16*>(d.planes_dgrad);
-    const long first = ((long)blockIdx.x - d.block0) * SCP_CONV_PLANES_BLOCK_ELEMS + threadIdx.x;
-#pragma unroll
-    for (int e = 0; e < SCP_CONV_PLANES_BLOCK_ELEMS / 256; e++) {
-        const long i = first + e * 256;
-        if (i >= total) return;
-        const int ci = (int)(i % Cin);
-        long r = i / Cin;
-        const int kx = (int)(r % k);
-        r /= k;
-        const int ky = (int)(r % k), co = (int)(r / k);
-        const float v = w[co * d.s_co + ci * d.s_ci + ky * d.s_ky + kx * d.s_kx];
-        const __bf16 h = (__bf16)v;
-        const float r1 = v - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const __bf16 l = (__bf16)(r1 - (float)m);
-        const size_t o = scp::tiled_plane_offset(co, (ky * k + kx) * Cin + ci, 0, (k * k * Cin) >> 4);
-        fwd[o] = h; fwd[o + 512] = m; fwd[o + 1024] = l;
-        if (dgrad) {
-            const size_t j = scp::tiled_plane_offset(ci, ((k - 1 - ky) * k + (k - 1 - kx)) * Cout + co, 0, (k * k * Cout) >> 4);
-            dgrad[j] = h; dgrad[j + 512] = m; dgrad[j + 1024] = l;
+    const int tiles_ci = (Cin + PT - 1) / PT;
+    const int tile = (int)((long long)blockIdx.x - d.block0);
+    const int co0 = (tile / tiles_ci) * PT, ci0 = (tile % tiles_ci) * PT;
+    const bool ci_fastest = d.s_ci == 1 && kk > 1;       // channels_last storage: ci runs fastest in memory, then the taps
+    const int lane_col = threadIdx.x & (PT - 1), lane_row = threadIdx.x / PT;      // 256 threads = 8 rows of 32
+    for (int tap0 = 0; tap0 < kk; tap0 += PTAPS) {
+        const int nt = min(PTAPS, kk - tap0);
+        for (int idx = threadIdx.x; idx < nt * PT * PT; idx += 256) {
+            int co_l, ci_l, t;
+            if (ci_fastest) { ci_l = idx % PT; t = (idx / PT) % nt; co_l = idx / (PT * nt); }
+            else { t = idx % nt; ci_l = (idx / nt) % PT; co_l = idx / (PT * nt); }
+            const int tap = tap0 + t, co = co0 + co_l, ci = ci0 + ci_l;
+            park[t * PTAP + co_l * PROW + ci_l] = (co < Cout && ci < Cin) ? w[co * d.s_co + ci * d.s_ci + (tap / k) * d.s_ky + (tap % k) * d.s_kx] : 0.f;
         }
+        __syncthreads();
+        for (int t = 0; t < nt; t++) {
+            const int tap = tap0 + t, ky = tap / k, kx = tap % k;
+#pragma unroll
+            for (int r = lane_row; r < PT; r += 256 / PT) {
+                {   // forward planes: row co, K index (tap, ci)
+                    const int co = co0 + r, ci = ci0 + lane_col;
+                    if (co < Cout && ci < Cin) {
+                        const float v = park[t * PTAP + r * PROW + lane_col];
+                        const __bf16 h = (__bf16)v;
+                        const float r1 = v - (float)h;
+                        const __bf16 m = (__bf16)r1;
+                        const __bf16 l = (__bf16)(r1 - (float)m);
+                        const size_t o = scp::tiled_plane_offset(co, tap * Cin + ci, 0, (kk * Cin) >> 4);
+                        fwd[o] = h; fwd[o + 512] = m; fwd[o + 1024] = l;
+                    }
+                }
+                if (dgrad) {   // input-gradient planes: row ci, K index (flipped tap, co)
+                    const int ci = ci0 + r, co = co0 + lane_col;
+                    if (co < Cout && ci < Cin) {
+                        const float v = park[t * PTAP + lane_col * PROW + r];
+                        const __bf16 h = (__bf16)v;
+                        const float r1 = v - (float)h;
+                        const __bf16 m = (__bf16)r1;
+                        const __bf16 l = (__bf16)(r1 - (float)m);
+                        const size_t j = scp::tiled_plane_offset(ci, ((k - 1 - ky) * k + (k - 1 - kx)) * Cout + co, 0, (kk * Cout) >> 4);
+                        dgrad[j] = h; dgrad[j + 512] = m; dgrad[j + 1024] = l;
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 

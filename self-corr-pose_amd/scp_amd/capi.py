@@ -12,8 +12,8 @@ import torch
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # SCP_HIP_LIB: an alternative build of the same library (A/B of kernel variants from tools/); the default is the in-tree build
 LIB_PATH = os.environ.get("SCP_HIP_LIB") or os.path.join(_PKG, "lib", "libscp_hip.so")
-ABI_VERSION = 5
-CONV_PLANES_BLOCK_ELEMS = 1024     # include/scp_hip.h: SCP_CONV_PLANES_BLOCK_ELEMS
+ABI_VERSION = 6
+CONV_PLANES_TILE = 32     # include/scp_hip.h: SCP_CONV_PLANES_TILE
 
 
 class RasterParams(ctypes.Structure):

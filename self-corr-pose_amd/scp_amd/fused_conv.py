@@ -124,10 +124,10 @@ def weight_planes(conv, with_dgrad):
             raise RuntimeError("scp_amd.fused_conv: weight planes are stale under graph capture -- call refresh_planes() first")
         cout, cin, k, _ = w.shape
         if "fwd" not in cache:
-            cache["fwd"] = torch.empty(tiled_planes_numel(cout, k * k * cin), dtype=torch.bfloat16, device=w.device)
+            cache["fwd"] = torch.zeros(tiled_planes_numel(cout, k * k * cin), dtype=torch.bfloat16, device=w.device)
         build_dgrad = with_dgrad or "dgrad" in cache
         if build_dgrad and "dgrad" not in cache:
-            cache["dgrad"] = torch.empty(tiled_planes_numel(cin, k * k * cout), dtype=torch.bfloat16, device=w.device)
+            cache["dgrad"] = torch.zeros(tiled_planes_numel(cin, k * k * cout), dtype=torch.bfloat16, device=w.device)
         # the buffers are rewritten in place: streams that read the previous contents (side-stream encoder pass, look-ahead) finish first
         for other in cache["readers"].values():
             cur.wait_stream(other)
@@ -202,9 +202,9 @@ def refresh_planes(convs):
             conv.register_load_state_dict_post_hook(lambda module, incompatible: invalidate())
         cout, cin, k, _ = w.shape
         if "fwd" not in cache:
-            cache["fwd"] = torch.empty(tiled_planes_numel(cout, k * k * cin), dtype=torch.bfloat16, device=w.device)
+            cache["fwd"] = torch.zeros(tiled_planes_numel(cout, k * k * cin), dtype=torch.bfloat16, device=w.device)
         if with_dgrad and "dgrad" not in cache:
-            cache["dgrad"] = torch.empty(tiled_planes_numel(cin, k * k * cout), dtype=torch.bfloat16, device=w.device)
+            cache["dgrad"] = torch.zeros(tiled_planes_numel(cin, k * k * cout), dtype=torch.bfloat16, device=w.device)
         for other in cache["readers"].values():        # streams that read the previous contents finish first (see weight_planes)
             cur.wait_stream(other)
         cache["readers"] = {}
@@ -218,7 +218,7 @@ def refresh_planes(convs):
         for e, d in zip(arr, descs):
             e.w, e.planes_fwd, e.planes_dgrad, e.s_co, e.s_ci, e.s_ky, e.s_kx, e.Cout, e.Cin, e.ksize = d
             e.block0 = block0
-            block0 += (d[7] * d[8] * d[9] * d[9] + capi.CONV_PLANES_BLOCK_ELEMS - 1) // capi.CONV_PLANES_BLOCK_ELEMS
+            block0 += -(-d[7] // capi.CONV_PLANES_TILE) * -(-d[8] // capi.CONV_PLANES_TILE)      # one workgroup per (Cout, Cin) tile
         host = torch.empty(ctypes.sizeof(arr), dtype=torch.uint8)
         ctypes.memmove(host.data_ptr(), ctypes.addressof(arr), host.numel())
         _BATCH_TABLES.clear()                          # pointers of a previous model are of no use to anyone

@@ -309,10 +309,12 @@ def test_batched_plane_refresh_equals_the_per_layer_launches(conv_mode, monkeypa
     if conv_mode != "split":
         pytest.skip("planes exist in split mode only")
     torch.manual_seed(5)
-    convs = [nn.Conv2d(64, 64, 3, padding=1), nn.Conv2d(64, 128, 3, stride=2, padding=1), nn.Conv2d(128, 32, 1), nn.Conv2d(256, 512, 3, padding=1)]
+    convs = [nn.Conv2d(64, 64, 3, padding=1), nn.Conv2d(64, 128, 3, stride=2, padding=1), nn.Conv2d(128, 32, 1), nn.Conv2d(256, 512, 3, padding=1),
+             nn.Conv2d(64, 48, 3, padding=1), nn.Conv2d(32, 80, 1)]        # the last two: Cout is no multiple of the kernel's 32 x 32 tile
     convs = [c.cuda() for c in convs]
     convs[1].to(memory_format=torch.channels_last)
     convs[3].to(memory_format=torch.channels_last)
+    convs[5].to(memory_format=torch.channels_last)
     convs[2].weight.requires_grad_(False)                 # no input-gradient planes wanted for this one
     snaps = {}
     for batch in ("1", "0"):
