@@ -11,6 +11,9 @@
 //     p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
 // with per-tensor lr / bias corrections (a tensor that starts receiving gradients later has its own step count, like torch's per-
 // parameter `step`).  Inactive tensors (grad = None this step) are skipped.  HBM-bound: 28 B per parameter.
+// The per-step scalars travel as KERNEL ARGUMENTS (scp_adamw_step, one row per class of tensors that share parameter group and step
+// count); the device table is static.  The first version uploaded a per-tensor table every step through a ring of pinned staging
+// buffers: the only host->device copy on the optimizer's path, and the one ingredient torch's own AdamW does not have.
 #include <hip/hip_runtime.h>
 
 #include "scp_common.h"
@@ -21,14 +24,15 @@ constexpr int CHUNK = SCP_ADAMW_CHUNK;
 
 __global__ __launch_bounds__(256) void adamw_flat_kernel(const scp_adamw_tensor* __restrict__ table, const int2* __restrict__ chunks,
                                                          const float* __restrict__ grad, float* __restrict__ exp_avg,
-                                                         float* __restrict__ exp_avg_sq, float beta1, float beta2, float eps) {
+                                                         float* __restrict__ exp_avg_sq, const scp_adamw_step step, float beta1,
+                                                         float beta2, float eps) {
     const int2 c = chunks[blockIdx.x];                   // (tensor index, first element of the chunk)
     const scp_adamw_tensor t = table[c.x];
-    if (!t.active) return;
+    if (t.cls < 0) return;
     float* __restrict__ p = reinterpret_cast<float*>(t.param);
     const long long n = t.numel;
     const long long base = t.flat_offset;
-    const float lr_wd = t.lr * t.weight_decay, step_size = t.step_size, inv_bc2_sqrt = t.inv_bias_correction2_sqrt;
+    const float lr_wd = step.lr_wd[t.cls], step_size = step.step_size[t.cls], inv_bc2_sqrt = step.inv_bias_correction2_sqrt[t.cls];
     const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
     const long long j0 = (long long)c.y, j1 = j0 + CHUNK < n ? j0 + CHUNK : n;
     // 4 elements per thread and iteration where the segment is 16-byte aligned on both sides
@@ -71,9 +75,10 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(const scp_adamw_tensor*
 }  // namespace
 
 extern "C" int scp_adamw_flat(const scp_adamw_tensor* table, const int* chunks, int nchunks, const float* grad, float* exp_avg,
-                              float* exp_avg_sq, float beta1, float beta2, float eps, void* stream) {
+                              float* exp_avg_sq, const scp_adamw_step* step, float beta1, float beta2, float eps, void* stream) {
     if (nchunks <= 0) return 0;
+    if (!step) return scp::fail(hipErrorInvalidValue, "scp_adamw_flat: step scalars missing");
     hipLaunchKernelGGL(adamw_flat_kernel, dim3(nchunks), dim3(256), 0, static_cast<hipStream_t>(stream), table,
-                       reinterpret_cast<const int2*>(chunks), grad, exp_avg, exp_avg_sq, beta1, beta2, eps);
+                       reinterpret_cast<const int2*>(chunks), grad, exp_avg, exp_avg_sq, *step, beta1, beta2, eps);
     return scp::check_launch("adamw_flat");
 }

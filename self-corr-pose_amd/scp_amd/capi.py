@@ -12,7 +12,7 @@ import torch
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # SCP_HIP_LIB: an alternative build of the same library (A/B of kernel variants from tools/); the default is the in-tree build
 LIB_PATH = os.environ.get("SCP_HIP_LIB") or os.path.join(_PKG, "lib", "libscp_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 CONV_PLANES_TILE = 32     # include/scp_hip.h: SCP_CONV_PLANES_TILE
 
 
@@ -28,11 +28,19 @@ class RasterParams(ctypes.Structure):
     ]
 
 
+ADAMW_MAX_CLASSES = 32     # include/scp_hip.h: SCP_ADAMW_MAX_CLASSES
+
+
 class AdamWTensor(ctypes.Structure):
     """struct scp_adamw_tensor"""
     _fields_ = [("param", ctypes.c_ulonglong), ("flat_offset", ctypes.c_longlong), ("numel", ctypes.c_longlong),
-                ("lr", ctypes.c_float), ("weight_decay", ctypes.c_float), ("step_size", ctypes.c_float),
-                ("inv_bias_correction2_sqrt", ctypes.c_float), ("active", ctypes.c_int), ("pad_", ctypes.c_int)]
+                ("cls", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
+class AdamWStep(ctypes.Structure):
+    """struct scp_adamw_step"""
+    _fields_ = [("lr_wd", ctypes.c_float * ADAMW_MAX_CLASSES), ("step_size", ctypes.c_float * ADAMW_MAX_CLASSES),
+                ("inv_bias_correction2_sqrt", ctypes.c_float * ADAMW_MAX_CLASSES)]
 
 
 class ConvPlanesDesc(ctypes.Structure):
@@ -69,7 +77,7 @@ SYMBOLS = {
     "scp_project_vertices_backward": (ctypes.c_int, [_P] * 5 + [_I] * 4 + [_P] * 4),
     "scp_gradclip_workspace": (ctypes.c_size_t, []),
     "scp_gradclip": (ctypes.c_int, [_P, ctypes.c_longlong, _F, _P, _P, _P, _I, _F, _F, _F, _P, ctypes.c_size_t, _P, _P]),
-    "scp_adamw_flat": (ctypes.c_int, [_P, _P, _I, _P, _P, _P, _F, _F, _F, _P]),
+    "scp_adamw_flat": (ctypes.c_int, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _P]),
     "scp_conv_weight_planes_batch": (ctypes.c_int, [_P, _I, ctypes.c_longlong, _P]),
     "scp_selftest_mfma_load": (ctypes.c_int, [_I, _P, _I, _I, _P, _P]),
     "scp_selftest_packed_fp32": (ctypes.c_int, [_I, _P, _I, _I, _P]),

@@ -45,22 +45,23 @@ class FlatAdamW(torch.optim.AdamW):
         self._grads = grads
         self._params = [p for g in self.param_groups for p in g["params"] if id(p) in grads.span]
         self._group_of = {id(p): gi for gi, g in enumerate(self.param_groups) for p in g["params"]}
-        self._steps = [0] * len(self._params)
+        self._steps = [0] * len(self._params)          # per-parameter step count (torch's state["step"])
+        self._calls = 0                                # step() calls since attach / load_state_dict
         self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
         chunks = []
         for i, p in enumerate(self._params):
             chunks += [(i, s0) for s0 in range(0, p.numel(), 4096)]
         self._chunks = torch.tensor(chunks, dtype=torch.int32, device=flat.device).contiguous()
+        # the device table is STATIC (addresses, segments, class of every tensor); this step's scalars go out as kernel arguments, one
+        # row per class = (parameter group, how many step() calls the tensor sat out).  It is uploaded again (a plain blocking copy)
+        # only when some tensor's class changes -- a parameter that starts or stops receiving gradients
         self._host = (capi.AdamWTensor * len(self._params))()
         for i, p in enumerate(self._params):
             e = self._host[i]
-            e.param, e.flat_offset, e.numel = p.data_ptr(), grads.span[id(p)][0], p.numel()
-        nbytes = ctypes.sizeof(self._host)
-        # the host runs ~2 steps ahead of the device: a ring of staging buffers, each reused only behind the event of the copy that read it
-        self._pinned = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(4)]
-        self._copied = [None] * 4
-        self._slot = 0
-        self._table = [torch.empty(nbytes, dtype=torch.uint8, device=flat.device) for _ in range(4)]
+            e.param, e.flat_offset, e.numel, e.cls = p.data_ptr(), grads.span[id(p)][0], p.numel(), -1
+        self._table = torch.empty(ctypes.sizeof(self._host), dtype=torch.uint8, device=flat.device)
+        self._class_ids = {}                           # (group index, calls sat out) -> row of the per-step scalars
+        self._uploaded = None                          # the class column the device table holds
         return True
 
     def _view(self, buf, p):
@@ -72,34 +73,51 @@ class FlatAdamW(torch.optim.AdamW):
         if self._grads is None:
             return super().step(closure)
         import ctypes
+        import numpy as np
         from . import capi
         b1, b2 = self.param_groups[0]["betas"]
         eps = self.param_groups[0]["eps"]
+        self._calls += 1
+        keys = []                                      # per tensor: (parameter group, step() calls it sat out) or None = no gradient
         for i, p in enumerate(self._params):
-            g = self.param_groups[self._group_of[id(p)]]
+            gi = self._group_of[id(p)]
+            g = self.param_groups[gi]
             assert g["betas"] == (b1, b2) and g["eps"] == eps and not g.get("amsgrad") and not g.get("maximize")
-            e = self._host[i]
-            e.active = int(p.grad is not None)
-            if not e.active:
+            if p.grad is None:
+                keys.append(None)
                 continue
+            e = self._host[i]
             assert p.data_ptr() == e.param and p.grad.data_ptr() == self._grads.views[id(p)].data_ptr(), "parameter or its gradient view moved"
             self._steps[i] += 1
-            t = self._steps[i]
+            keys.append((gi, self._calls - self._steps[i]))
+        live = sorted({k for k in keys if k is not None})
+        fresh = [k for k in live if k not in self._class_ids]
+        if fresh:
+            if len(self._class_ids) + len(fresh) > capi.ADAMW_MAX_CLASSES:
+                self._class_ids = {}                   # drop the classes nobody is in any more, renumber
+                fresh = live
+                if len(live) > capi.ADAMW_MAX_CLASSES:
+                    raise RuntimeError("FlatAdamW: more than %d (parameter group, step count) classes" % capi.ADAMW_MAX_CLASSES)
+            for k in fresh:
+                self._class_ids[k] = len(self._class_ids)
+        scalars = capi.AdamWStep()
+        for gi, sat_out in live:
+            c, g, t = self._class_ids[(gi, sat_out)], self.param_groups[gi], self._calls - sat_out
             lr = float(g["lr"])
-            e.lr, e.weight_decay = lr, float(g["weight_decay"])
-            e.step_size = lr / (1.0 - b1 ** t)
-            e.inv_bias_correction2_sqrt = 1.0 / (1.0 - b2 ** t) ** 0.5
-        k = self._slot
-        self._slot = (k + 1) % 4
-        if self._copied[k] is not None:
-            self._copied[k].synchronize()              # four steps old: long done
-        ctypes.memmove(self._pinned[k].data_ptr(), ctypes.addressof(self._host), self._pinned[k].numel())
-        self._table[k].copy_(self._pinned[k], non_blocking=True)
-        self._copied[k] = torch.cuda.Event()
-        self._copied[k].record()
-        capi.check(capi.lib().scp_adamw_flat(ctypes.c_void_p(self._table[k].data_ptr()), ctypes.c_void_p(self._chunks.data_ptr()),
+            scalars.lr_wd[c] = float(np.float32(lr) * np.float32(g["weight_decay"]))          # the product torch forms in fp32
+            scalars.step_size[c] = lr / (1.0 - b1 ** t)
+            scalars.inv_bias_correction2_sqrt[c] = 1.0 / (1.0 - b2 ** t) ** 0.5
+        cls_now = [-1 if k is None else self._class_ids[k] for k in keys]
+        if cls_now != self._uploaded:
+            for e, c in zip(self._host, cls_now):
+                e.cls = c
+            host = torch.frombuffer(bytearray(bytes(self._host)), dtype=torch.uint8)
+            self._table.copy_(host)                    # pageable source: blocking, stream ordered behind the previous step's launch
+            self._uploaded = cls_now
+        capi.check(capi.lib().scp_adamw_flat(ctypes.c_void_p(self._table.data_ptr()), ctypes.c_void_p(self._chunks.data_ptr()),
                                              self._chunks.shape[0], capi.dev_ptr(self._grads.flat, "grad"), capi.dev_ptr(self._m, "exp_avg"),
-                                             capi.dev_ptr(self._v, "exp_avg_sq"), float(b1), float(b2), float(eps), capi.current_stream()),
+                                             capi.dev_ptr(self._v, "exp_avg_sq"), ctypes.byref(scalars), float(b1), float(b2), float(eps),
+                                             capi.current_stream()),
                    "scp_adamw_flat")
         return None
 
@@ -120,6 +138,8 @@ class FlatAdamW(torch.optim.AdamW):
                     self._steps[i] = int(float(st["step"]))
                     self._view(self._m, p).copy_(st["exp_avg"])
                     self._view(self._v, p).copy_(st["exp_avg_sq"])
+            self._calls = max(self._steps, default=0)
+            self._class_ids, self._uploaded = {}, None
             self.state.clear()          # the flat buffers are the state; state_dict() rebuilds the per-parameter view of it
 
 
