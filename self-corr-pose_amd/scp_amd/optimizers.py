@@ -157,8 +157,9 @@ class Optimizers:
         lr = opts.learning_rate
         on_gpu = any(p.is_cuda for g in groups for p in g)
         # on the GPU: torch's fused AdamW (five multi-tensor launches, 0.43 ms at the end of the step).  SCP_ADAMW=flat selects FlatAdamW
-        # (one launch over the trainer's flat gradient buffer, -0.2...-0.5 ms per step, parity-tested in tests/test_project.py); it is
-        # opt-in because the round-5 full GPU suite stalled twice in Trainer.train with it and never without: not root-caused
+        # (one launch over the trainer's flat gradient buffer, -0.3 ms per step, parity-tested in tests/test_project.py).  Opt-in: the full
+        # GPU suite stalled twice in Trainer.train with FlatAdamW's first version (per-step table upload through pinned staging) and never
+        # without; the current version has no upload on its path but has not been through the full suite yet
         cls = FlatAdamW if (on_gpu and os.environ.get("SCP_ADAMW", "torch") == "flat") else torch.optim.AdamW
         self.optimizer = cls([{"params": g} for g in groups], lr=lr, betas=(0.9, 0.999), weight_decay=1e-4,
                              **({"fused": True} if (on_gpu and cls is torch.optim.AdamW) else {}))
