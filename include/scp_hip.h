@@ -413,7 +413,8 @@ int scp_conv_weight_planes(const float* w, long long s_co, long long s_ci, long 
 /* the same for MANY layers in one launch: `descs_device` = n descriptors in device memory (the strides are those of the [Cout,Cin,k,k]
  * parameter in elements; planes_dgrad may be 0; block0 = index of the layer's first workgroup in the launch: a workgroup converts one
  * SCP_CONV_PLANES_TILE x SCP_CONV_PLANES_TILE tile of (Cout, Cin) with all its taps, layer i owns workgroups
- * [block0_i, block0_i + ceil(Cout / TILE) * ceil(Cin / TILE)), block0 ascending, total_blocks = their sum).  Same bits as n single calls. */
+ * [block0_i, block0_i + ceil(Cout / TILE) * ceil(Cin / TILE)), block0 ascending, total_blocks = their sum).  Same bits as n single calls.
+ * Cin must be even, and Cout too where planes_dgrad is given (pairs of neighbouring K positions leave as one 32-bit store). */
 #define SCP_CONV_PLANES_TILE 32
 typedef struct scp_conv_planes_desc {
     unsigned long long w, planes_fwd, planes_dgrad;

@@ -429,28 +429,38 @@ __global__ void conv_weight_planes_kernel(const float* __restrict__ w, long s_co
 // store instruction of a wavefront fills whole 32-byte rows of a [32 rows][16 k] plane tile (the element-per-thread version scattered the
 // input-gradient planes as 2-byte stores 1 KB apart: 160-300 us per step for 20 us worth of traffic).
 constexpr int PT = SCP_CONV_PLANES_TILE, PTAPS = 9;
-__global__ __launch_bounds__(256) void conv_weight_planes_batch_kernel(const scp_conv_planes_desc* __restrict__ descs, int n) {
-    // [tap][co][ci], rows padded by one float and taps by three: conflict-free in both write-out orders, <= 2-way in the read-in order
-    constexpr int PROW = PT + 1, PTAP = PT * PROW + 3;
-    __shared__ float park[PTAPS * PTAP];
-    // the layer of this workgroup: binary search over the ascending block0
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if ((long long)blockIdx.x >= descs[mid].block0) lo = mid; else hi = mid - 1;
-    }
-    const scp_conv_planes_desc d = descs[lo];
-    const int Cout = d.Cout, Cin = d.Cin, k = d.ksize, kk = k * k;
+// [tap][co][ci], rows padded by one float and taps by three: conflict-free in both write-out orders, <= 2-way in the read-in order
+constexpr int PROW = PT + 1, PTAP = PT * PROW + 3;
+
+// x0, x1 -> their (h, m, l) split, each pair packed into one 32-bit word (element 0 in the low half)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+    const float r0 = x0 - (float)h0, r1 = x1 - (float)h1;
+    const __bf16 m0 = (__bf16)r0, m1 = (__bf16)r1;
+    const __bf16 l0 = (__bf16)(r0 - (float)m0), l1 = (__bf16)(r1 - (float)m1);
+    auto pack = [](__bf16 a, __bf16 b) {
+        return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+    };
+    h = pack(h0, h1); m = pack(m0, m1); l = pack(l0, l1);
+}
+
+// one 32 x 32 (co, ci) tile of one layer.  K = the kernel size when it is known at compile time (1, 3: the index arithmetic of the
+// read-in loop is then shifts and multiplications), 0 = any size, PTAPS taps per trip through LDS.
+// Write-out: a lane owns two neighbouring K positions of a plane row (one 4-byte store per plane), 16 lanes one 32-element... row half:
+// every store instruction of a wavefront writes four whole 64-byte runs.  Needs Cin (forward planes) / Cout (input-gradient planes) even,
+// which the planes' own K % 16 == 0 rule implies for odd kernel sizes.
+template <int K>
+__device__ __forceinline__ void planes_tile(const scp_conv_planes_desc& d, float* park, int tile) {
+    const int Cout = d.Cout, Cin = d.Cin, k = K ? K : d.ksize, kk = k * k;
     const float* w = reinterpret_cast<const float*>(d.w);
     __bf16* fwd = reinterpret_cast<__bf16*>(d.planes_fwd);
     __bf16* dgrad = reinterpret_cast<__bf16*>(d.planes_dgrad);
     const int tiles_ci = (Cin + PT - 1) / PT;
-    const int tile = (int)((long long)blockIdx.x - d.block0);
     const int co0 = (tile / tiles_ci) * PT, ci0 = (tile % tiles_ci) * PT;
     const bool ci_fastest = d.s_ci == 1 && kk > 1;       // channels_last storage: ci runs fastest in memory, then the taps
-    const int lane_col = threadIdx.x & (PT - 1), lane_row = threadIdx.x / PT;      // 256 threads = 8 rows of 32
+    const int pair = threadIdx.x & 15, row0 = threadIdx.x >> 4;        // 256 threads = 16 rows of 16 column pairs
     for (int tap0 = 0; tap0 < kk; tap0 += PTAPS) {
-        const int nt = min(PTAPS, kk - tap0);
+        const int nt = K ? K * K : min(PTAPS, kk - tap0);
         for (int idx = threadIdx.x; idx < nt * PT * PT; idx += 256) {
             int co_l, ci_l, t;
             if (ci_fastest) { ci_l = idx % PT; t = (idx / PT) % nt; co_l = idx / (PT * nt); }
@@ -459,38 +469,54 @@ __global__ __launch_bounds__(256) void conv_weight_planes_batch_kernel(const scp
             park[t * PTAP + co_l * PROW + ci_l] = (co < Cout && ci < Cin) ? w[co * d.s_co + ci * d.s_ci + (tap / k) * d.s_ky + (tap % k) * d.s_kx] : 0.f;
         }
         __syncthreads();
-        for (int t = 0; t < nt; t++) {
+        auto write_tap = [&](int t) {
             const int tap = tap0 + t, ky = tap / k, kx = tap % k;
 #pragma unroll
-            for (int r = lane_row; r < PT; r += 256 / PT) {
+            for (int r = row0; r < PT; r += 16) {
                 {   // forward planes: row co, K index (tap, ci)
-                    const int co = co0 + r, ci = ci0 + lane_col;
+                    const int co = co0 + r, ci = ci0 + 2 * pair;
                     if (co < Cout && ci < Cin) {
-                        const float v = park[t * PTAP + r * PROW + lane_col];
-                        const __bf16 h = (__bf16)v;
-                        const float r1 = v - (float)h;
-                        const __bf16 m = (__bf16)r1;
-                        const __bf16 l = (__bf16)(r1 - (float)m);
-                        const size_t o = scp::tiled_plane_offset(co, tap * Cin + ci, 0, (kk * Cin) >> 4);
-                        fwd[o] = h; fwd[o + 512] = m; fwd[o + 1024] = l;
+                        unsigned h, m, l;
+                        split_pair(park[t * PTAP + r * PROW + 2 * pair], park[t * PTAP + r * PROW + 2 * pair + 1], h, m, l);
+                        unsigned* o = reinterpret_cast<unsigned*>(fwd + scp::tiled_plane_offset(co, tap * Cin + ci, 0, (kk * Cin) >> 4));
+                        o[0] = h; o[256] = m; o[512] = l;
                     }
                 }
                 if (dgrad) {   // input-gradient planes: row ci, K index (flipped tap, co)
-                    const int ci = ci0 + r, co = co0 + lane_col;
+                    const int ci = ci0 + r, co = co0 + 2 * pair;
                     if (co < Cout && ci < Cin) {
-                        const float v = park[t * PTAP + lane_col * PROW + r];
-                        const __bf16 h = (__bf16)v;
-                        const float r1 = v - (float)h;
-                        const __bf16 m = (__bf16)r1;
-                        const __bf16 l = (__bf16)(r1 - (float)m);
-                        const size_t j = scp::tiled_plane_offset(ci, ((k - 1 - ky) * k + (k - 1 - kx)) * Cout + co, 0, (kk * Cout) >> 4);
-                        dgrad[j] = h; dgrad[j + 512] = m; dgrad[j + 1024] = l;
+                        unsigned h, m, l;
+                        split_pair(park[t * PTAP + (2 * pair) * PROW + r], park[t * PTAP + (2 * pair + 1) * PROW + r], h, m, l);
+                        unsigned* o = reinterpret_cast<unsigned*>(
+                            dgrad + scp::tiled_plane_offset(ci, ((k - 1 - ky) * k + (k - 1 - kx)) * Cout + co, 0, (kk * Cout) >> 4));
+                        o[0] = h; o[256] = m; o[512] = l;
                     }
                 }
             }
+        };
+        if constexpr (K > 0) {
+#pragma unroll
+            for (int t = 0; t < K * K; t++) write_tap(t);
+        } else {
+            for (int t = 0; t < nt; t++) write_tap(t);
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void conv_weight_planes_batch_kernel(const scp_conv_planes_desc* __restrict__ descs, int n) {
+    __shared__ float park[PTAPS * PTAP];
+    // the layer of this workgroup: binary search over the ascending block0
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((long long)blockIdx.x >= descs[mid].block0) lo = mid; else hi = mid - 1;
+    }
+    const scp_conv_planes_desc d = descs[lo];
+    const int tile = (int)((long long)blockIdx.x - d.block0);
+    if (d.ksize == 3) planes_tile<3>(d, park, tile);
+    else if (d.ksize == 1) planes_tile<1>(d, park, tile);
+    else planes_tile<0>(d, park, tile);
 }
 
 using Cfg256x64 = scp::GemmCfg<2, 2, 4, 1, 2, 2>;     // 64-channel layers at 64 x 64 resolution

@@ -181,7 +181,8 @@ def refresh_planes(convs):
     for conv in convs:
         w = conv.weight
         # only the layers the own kernels run (own_forward_ok's shape rules: 3x3 / 1x1, Cin a power of two >= 32)
-        if w.is_cuda and w.dtype == torch.float32 and w.shape[2] == w.shape[3] and w.shape[2] in (1, 3) and w.shape[1] >= 32 and _pow2(w.shape[1]):
+        if (w.is_cuda and w.dtype == torch.float32 and w.shape[2] == w.shape[3] and w.shape[2] in (1, 3) and w.shape[1] >= 32 and _pow2(w.shape[1])
+                and w.shape[0] % 2 == 0):          # even Cout: the batched kernel stores pairs of K positions (include/scp_hip.h)
             cache = conv.__dict__.get("_scp_planes", {})
             with_dgrad = (w.requires_grad and _own_dgrad_ok(w, conv.stride[0])) or "dgrad" in cache
             key = (w.data_ptr(), w._version, str(w.device), WEIGHT_EPOCH[0])
