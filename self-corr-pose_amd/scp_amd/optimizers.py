@@ -23,6 +23,23 @@ def group_of(name):
     return None
 
 
+def assign_classes(class_ids, live, max_classes):
+    """rows of FlatAdamW's per-step scalar table: `class_ids` {key: row} extended by the keys of `live` it does not hold yet (existing
+    rows never move: the device table that names them stays valid); when the table would overflow, the keys nobody is in any more are
+    dropped and the live ones renumbered from 0 (the caller notices through the changed rows and rewrites the device table)."""
+    fresh = [k for k in live if k not in class_ids]
+    if not fresh:
+        return class_ids
+    if len(class_ids) + len(fresh) > max_classes:
+        if len(live) > max_classes:
+            raise RuntimeError("FlatAdamW: more than %d (parameter group, step count) classes" % max_classes)
+        return {k: i for i, k in enumerate(live)}
+    out = dict(class_ids)
+    for k in fresh:
+        out[k] = len(out)
+    return out
+
+
 class FlatAdamW(torch.optim.AdamW):
     """torch.optim.AdamW whose step() is ONE launch (csrc/adamw.hip, scp_adamw_flat) over the flat gradient buffer of
     scp_amd.parallel.FlatGradients: the parameters stay where they are, gradients and both moments live in flat buffers in the same
@@ -91,15 +108,7 @@ class FlatAdamW(torch.optim.AdamW):
             self._steps[i] += 1
             keys.append((gi, self._calls - self._steps[i]))
         live = sorted({k for k in keys if k is not None})
-        fresh = [k for k in live if k not in self._class_ids]
-        if fresh:
-            if len(self._class_ids) + len(fresh) > capi.ADAMW_MAX_CLASSES:
-                self._class_ids = {}                   # drop the classes nobody is in any more, renumber
-                fresh = live
-                if len(live) > capi.ADAMW_MAX_CLASSES:
-                    raise RuntimeError("FlatAdamW: more than %d (parameter group, step count) classes" % capi.ADAMW_MAX_CLASSES)
-            for k in fresh:
-                self._class_ids[k] = len(self._class_ids)
+        self._class_ids = assign_classes(self._class_ids, live, capi.ADAMW_MAX_CLASSES)
         scalars = capi.AdamWStep()
         for gi, sat_out in live:
             c, g, t = self._class_ids[(gi, sat_out)], self.param_groups[gi], self._calls - sat_out

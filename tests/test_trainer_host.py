@@ -209,3 +209,20 @@ def test_sync_batchnorm_modules_take_the_stock_path():
     finally:
         fused_conv._ConvBNAct.apply = orig
     assert not calls and y.shape == (2, 64, 8, 8)
+
+
+def test_flat_adamw_class_rows_are_stable_and_recycled():
+    """scp_amd.optimizers.assign_classes (the host half of FlatAdamW's kernel-argument table): rows never move while there is room, a
+    full table drops the classes nobody is in and renumbers, more live classes than rows is an error"""
+    from scp_amd.optimizers import assign_classes
+    ids = assign_classes({}, [(0, 0), (1, 0)], 4)
+    assert ids == {(0, 0): 0, (1, 0): 1}
+    assert assign_classes(ids, [(0, 0)], 4) is ids                              # nothing new: the same object, nothing to upload
+    ids2 = assign_classes(ids, [(0, 0), (1, 3)], 4)
+    assert ids2 == {(0, 0): 0, (1, 0): 1, (1, 3): 2} and ids == {(0, 0): 0, (1, 0): 1}
+    ids3 = assign_classes(ids2, [(0, 0), (1, 4)], 4)
+    assert ids3[(0, 0)] == 0 and ids3[(1, 4)] == 3
+    ids4 = assign_classes(ids3, [(0, 0), (1, 5)], 4)                              # full: dead classes go, live ones are renumbered
+    assert ids4 == {(0, 0): 0, (1, 5): 1}
+    with pytest.raises(RuntimeError, match="classes"):
+        assign_classes(ids4, [(g, 0) for g in range(5)], 4)
