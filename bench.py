@@ -599,6 +599,23 @@ def bench_posefit(args):
     print(json.dumps(out))
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves, one process per GPU, the way
+    scripts/train.sh:5-7 / train.py:29-36 of the reference start theirs (torch.distributed.launch) -- here torch.distributed.run on
+    127.0.0.1 with a free port; the ranks' stdout (rank 0 prints the one JSON line) and exit status pass through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: the only mode the host driver supports (RCCL over xGMI)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -622,6 +639,8 @@ def main():
     if args.workload == "posefit":
         return bench_posefit(args)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -940,13 +959,18 @@ def main():
                 ex_avg = exclusive[1] / exclusive[2]
                 roofline.update(achieved=ex_tf, frac=ex_tf / peak, vs_fp32_mfma_peak=ex_tf / FP32_VALU_PEAK_TF, avg_launch_ms=ex_avg,
                                 algorithmic_flops_per_launch=exclusive[0] / exclusive[2], by_shape=exclusive_by_shape,
-                                timed_launches=exclusive[2], ms_per_step=ex_avg * per_step,
+                                timed_launches=exclusive[2], gemm_ms_per_step_one_stream_leg=ex_avg * per_step,
+                                schedule_of_contract_figures="one-stream leg (K extra steps, SCP_STREAMS=serial): achieved / frac / "
+                                                             "avg_launch_ms here are NOT durations inside the timed overlapped step -- "
+                                                             "those are under in_schedule; the line's top-level value / ms_per_step "
+                                                             "are the overlapped schedule's",
                                 measured="K further training steps of the same workload on ONE HIP stream (nothing shares the CUs with "
                                          "a launch); in-kernel duration clock; agrees with the rocprofv3 kernel trace under profiles/",
                                 profile_note="a rocprofv3 trace makes the step host-bound, so kernels of different streams hardly overlap "
                                              "in it: the trace reproduces THIS figure; `in_schedule` is what the free-running overlapped "
                                              "step shows for the same launches")
                 del roofline["exclusive_device"]
+                del roofline["ms_per_step"]      # no key of the timed step's name carrying another schedule's figure
         elif others:
             roofline = dict(next(iter(others.values())), others=others)
         out = {

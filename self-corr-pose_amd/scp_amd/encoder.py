@@ -32,8 +32,11 @@ class Encoder(nn.Module):
         # NHWC and copied back, 2 x 25 MB per pass at B = 32); otherwise (stock stem: bf16 autocast, eval-mode BatchNorm, ...) NHWC.
         from .fused_conv import stem_takes_own_kernels
         r = self.backbone.resnet
-        nchw = img.is_cuda and stem_takes_own_kernels(img.detach().float() if img.dtype != torch.float32 else img.detach(), r.conv1, r.bn1,
-                                                      autocast=bool(getattr(self.opts, "mixed_bf16", False)))
+        # asked with the metadata of the tensor the stem WILL see (fp32 output of jitter_normalize, the image's own requires_grad, the
+        # autocast state the stem will run under: opts.mixed_bf16's or one the caller opened) -- nothing is converted to ask
+        nchw = img.is_cuda and stem_takes_own_kernels(
+            None, r.conv1, r.bn1, autocast=bool(getattr(self.opts, "mixed_bf16", False)) or torch.is_autocast_enabled(),
+            meta=(tuple(img.shape), torch.float32, True, bool(img.requires_grad and torch.is_grad_enabled())))
         x = imgops.jitter_normalize(img, self.random_jitter, self.resnet_transform, channels_last=not nchw)
         if x.is_cuda and not nchw:
             x = x.contiguous(memory_format=torch.channels_last)

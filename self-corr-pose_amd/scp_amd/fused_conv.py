@@ -439,24 +439,30 @@ class _StemConvBNAct(Function):
         return None, dw, dgamma, dbeta, None, None
 
 
-def stem_takes_own_kernels(x, conv, bn, autocast=None):
+def stem_takes_own_kernels(x, conv, bn, autocast=None, meta=None):
     """whether stem_conv_bn_act(x, conv, bn) will run csrc/conv_stem.hip -- which reads the image as NCHW rows; the encoder asks before
-    choosing the layout of the normalised image (scp_amd/encoder.py), so that no layout copy is made only to be undone"""
+    choosing the layout of the normalised image (scp_amd/encoder.py), so that no layout copy is made only to be undone.
+    `meta` = (shape, dtype, is_cuda, requires_grad) stands in for a tensor that does not exist yet (x is then ignored): the question is
+    about metadata only, nothing is converted to answer it."""
     w = conv.weight
+    shape, dtype, is_cuda, requires_grad = meta if meta is not None else (tuple(x.shape), x.dtype, x.is_cuda, x.requires_grad)
     autocast = torch.is_autocast_enabled() if autocast is None else autocast
-    return (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 4 and tuple(w.shape) == (64, 3, 7, 7)
+    return (is_cuda and dtype == torch.float32 and w.dtype == torch.float32 and len(shape) == 4 and tuple(w.shape) == (64, 3, 7, 7)
             and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
-            and x.shape[1] == 3 and x.shape[2] % 2 == 0 and x.shape[3] % 4 == 0 and x.shape[2] >= 8 and x.shape[3] >= 8
-            and not x.requires_grad and type(bn) is nn.BatchNorm2d and (bn.training or bn.running_mean is None)
+            and shape[1] == 3 and shape[2] % 2 == 0 and shape[3] % 4 == 0 and shape[2] >= 8 and shape[3] >= 8
+            and not requires_grad and type(bn) is nn.BatchNorm2d and (bn.training or bn.running_mean is None)
             and not autocast and os.environ.get("SCP_STEM", "own") == "own")
 
 
 def stem_conv_bn_act(x, conv, bn, relu=True):
     """relu(bn(conv(x))) for the 7x7 / stride-2 / pad-3 stem of the ResNet trunk; anything else (CPU, eval-mode BatchNorm, autocast,
-    an image that needs a gradient, odd sizes) takes the stock composition"""
+    an image that needs a gradient, odd sizes) takes the stock composition -- on channels_last input, which is what the layers behind
+    it run in (a caller that guessed NCHW for the own kernel and was wrong pays one layout copy here, not one per layer)"""
     from .fused_bn import bn_act
     if stem_takes_own_kernels(x, conv, bn):
         return _StemConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, bn, relu)
+    if x.is_cuda and x.dim() == 4 and conv.weight.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
     return bn_act(conv(x), bn, relu=relu)
 
 

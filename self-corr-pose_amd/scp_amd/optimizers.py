@@ -79,7 +79,27 @@ class FlatAdamW(torch.optim.AdamW):
         self._table = torch.empty(ctypes.sizeof(self._host), dtype=torch.uint8, device=flat.device)
         self._class_ids = {}                           # (group index, calls sat out) -> row of the per-step scalars
         self._uploaded = None                          # the class column the device table holds
+        # state that was loaded (or stepped the torch way) BEFORE attach() moves into the flat buffers instead of being dropped
+        if any(self.state.get(p) for p in self._params):
+            self._import_state()
         return True
+
+    def _import_state(self):
+        """self.state (torch's per-parameter dicts) -> step counts and flat moment buffers.  A parameter WITHOUT an entry is reset (step 0,
+        zero moments) exactly as torch's AdamW treats a parameter it has no state for."""
+        for i, p in enumerate(self._params):
+            st = self.state.get(p)
+            if st:
+                self._steps[i] = int(float(st["step"]))
+                self._view(self._m, p).copy_(st["exp_avg"])
+                self._view(self._v, p).copy_(st["exp_avg_sq"])
+            else:
+                self._steps[i] = 0
+                self._view(self._m, p).zero_()
+                self._view(self._v, p).zero_()
+        self._calls = max(self._steps, default=0)
+        self._class_ids, self._uploaded = {}, None
+        self.state.clear()              # the flat buffers are the state; state_dict() rebuilds the per-parameter view of it
 
     def _view(self, buf, p):
         off = self._grads.span[id(p)][0]
@@ -141,15 +161,7 @@ class FlatAdamW(torch.optim.AdamW):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         if self._grads is not None:
-            for i, p in enumerate(self._params):
-                st = self.state.get(p)
-                if st:
-                    self._steps[i] = int(float(st["step"]))
-                    self._view(self._m, p).copy_(st["exp_avg"])
-                    self._view(self._v, p).copy_(st["exp_avg_sq"])
-            self._calls = max(self._steps, default=0)
-            self._class_ids, self._uploaded = {}, None
-            self.state.clear()          # the flat buffers are the state; state_dict() rebuilds the per-parameter view of it
+            self._import_state()
 
 
 class Optimizers:

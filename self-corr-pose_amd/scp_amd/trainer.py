@@ -259,7 +259,7 @@ class Trainer:
             total, aux, grad = self.step(data, next_data=nxt_dev)
             pending.append(total.detach())
             if (i + 1) % opts.batch_log_interval == 0:
-                vals = torch.stack(pending).cpu().tolist()
+                vals = self._read_back(pending, "Trainer.train: losses of iterations %d..%d" % (i + 2 - len(pending), i + 1))
                 self.grads.check_static_graph()        # the host is synchronised here anyway
                 history.extend(vals)
                 pending = []
@@ -270,8 +270,26 @@ class Trainer:
             if opts.save_freq and (i + 1) % opts.save_freq == 0:
                 self.save(os.path.join(save_dir, "pred_net_%d.pth" % (i + 1)))
         if pending:
-            history.extend(torch.stack(pending).cpu().tolist())
+            history.extend(self._read_back(pending, "Trainer.train: losses of the last %d iterations" % len(pending)))
         return history
+
+    def named_streams(self):
+        """the HIP streams a step enqueues on, by role (for DeviceStall reports)"""
+        m = self.model
+        out = {"main": torch.cuda.current_stream(self.device),
+               "rotation-cycle side stream": getattr(m, "_cycle_stream", None), "texture-pass side stream": getattr(m, "_tex_stream", None),
+               "frozen-ViT side stream": getattr(m.pretrain_corr_net, "_side_stream", None),
+               "all-reduce stream": getattr(self.grads, "comm_stream", None)}
+        return {k: v for k, v in out.items() if v is not None}
+
+    def _read_back(self, pending, what):
+        """device scalars -> host floats; the wait for the device is bounded (streams.wait_bounded raises DeviceStall)"""
+        stacked = torch.stack(pending)
+        if stacked.is_cuda:
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.device))
+            streams.wait_bounded(done, what, self.named_streams)
+        return stacked.cpu().tolist()
 
     def save(self, path):
         """rank 0 writes (trainer.py:152-158 guards with local_rank <= 0).  COLLECTIVE when world > 1: every rank must call it

@@ -265,3 +265,60 @@ def test_flat_adamw_equals_torch_adamw():
         one_step(step, ref, own, sched)
     for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
         assert float((pa - pb).abs().max()) <= 4e-6 * float(pa.abs().max()), n
+
+
+@pytest.mark.gpu
+def test_flat_adamw_state_reset_and_load_then_attach():
+    """(i) loading a state WITHOUT entries onto a stepped FlatAdamW resets steps and moments like torch's AdamW (which would
+    find no state and start over); (ii) a state loaded BEFORE attach() is imported into the flat buffers, not dropped"""
+    import copy
+    import torch.nn as nn
+    from scp_amd.optimizers import FlatAdamW
+    from scp_amd.parallel import FlatGradients
+
+    def build():
+        torch.manual_seed(3)
+        return nn.Linear(40, 7).cuda()
+
+    gen = torch.Generator().manual_seed(11)
+    grads = [[torch.randn(p.shape, generator=gen).cuda() for p in build().parameters()] for _ in range(6)]
+
+    def run(opt, net, fg, steps):
+        for k in steps:
+            if fg is not None:
+                fg.prepare()
+            for p, g in zip(net.parameters(), grads[k]):
+                if fg is not None:
+                    p.grad.copy_(g)
+                else:
+                    p.grad = g.clone()
+            opt.step()
+
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), weight_decay=1e-4)
+    # (i) empty state after three steps == a fresh optimizer on the same parameters
+    a, b = build(), build()
+    ref, own = torch.optim.AdamW(a.parameters(), fused=True, **kw), FlatAdamW(b.parameters(), **kw)
+    fg = FlatGradients(list(b.parameters()))
+    assert own.attach(fg)
+    run(ref, a, None, range(3)); run(own, b, fg, range(3))
+    empty = {"state": {}, "param_groups": copy.deepcopy(own.state_dict()["param_groups"])}
+    own.load_state_dict(empty)
+    ref = torch.optim.AdamW(a.parameters(), fused=True, **kw)
+    assert own._steps == [0, 0] and float(own._m.abs().max()) == 0.0 and float(own._v.abs().max()) == 0.0
+    run(ref, a, None, range(3, 6)); run(own, b, fg, range(3, 6))
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert float((pa - pb).abs().max()) <= 4e-6 * float(pa.abs().max())
+    # (ii) load first, attach afterwards
+    sd = copy.deepcopy(own.state_dict())
+    c = build()
+    with torch.no_grad():
+        for pc, pb in zip(c.parameters(), b.parameters()):
+            pc.copy_(pb)
+    late = FlatAdamW(c.parameters(), **kw)
+    late.load_state_dict(sd)
+    fg2 = FlatGradients(list(c.parameters()))
+    assert late.attach(fg2)
+    assert late._steps == own._steps and torch.equal(late._m, own._m) and torch.equal(late._v, own._v)
+    run(own, b, fg, [0]); run(late, c, fg2, [0])
+    for pb, pc in zip(b.parameters(), c.parameters()):
+        assert torch.equal(pb, pc)
