@@ -92,6 +92,20 @@ struct FvmArgs {
     float* g_mesh;         // [B, V, 64]
 };
 
+// blockIdx -> (unit, image), XCD-aware: workgroup i runs on XCD i % 8 (observed placement), so workgroup i takes logical id
+// (i % 8) * per_xcd + i / 8 -- consecutive logical ids = the units of ONE image share an XCD, and that image's features / scores are
+// fetched into one L2 instead of eight (round 6: the vertex-side backward re-read every image's [64, P] features on every XCD;
+// 854 MB counter traffic for 165 MB algorithmic, profiles/r05_traffic.json).  Returns false for the padding workgroups.
+__device__ __forceinline__ bool xcd_unit(int per_image, int B, int& unit, int& b) {
+    const int total = per_image * B, per_xcd = (total + 7) >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || logical >= total) return false;
+    b = logical / per_image;
+    unit = logical - b * per_image;
+    return true;
+}
+__host__ inline unsigned xcd_grid(int per_image, int B) { return 8u * (unsigned)((per_image * B + 7) >> 3); }
+
 // pixel of lane l31 in wavefront w of strip blk: 16 x-positions x 2 rows, the four lanes 4g..4g+3 form one 2x2 pool cell
 __device__ __forceinline__ int strip_pixel(int blk, int wave, int l31) {
     return (2 * blk + (l31 & 1)) * WF + 16 * wave + (l31 >> 1);
@@ -171,7 +185,8 @@ __global__ __launch_bounds__(256) void fvm_forward_kernel(const FvmArgs a) {
     __shared__ float ttile[4][32 * TROW];                                     // per wavefront: the score tile on its way to the other orientation
     __shared__ __attribute__((aligned(16))) float colred2[2][4][32][4];       // column partials of the pooled scores (a9's bridge)
 
-    const int blk = blockIdx.x, b = blockIdx.y;
+    int blk, b;
+    if (!xcd_unit(a.nblk, a.B, blk, b)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int p = strip_pixel(blk, wave, l31);
     const bool masked = !(a.mask[(size_t)b * a.P + p] > 0.f);
@@ -356,7 +371,8 @@ __global__ __launch_bounds__(256, FVM_IMG_WAVES) void fvm_backward_img_kernel(co
     __shared__ __attribute__((aligned(16))) float ct[2][32 * 8];     // per vertex: cmax, 1/csum, gi0, gi1, d_c
     __shared__ __attribute__((aligned(16))) float gpt[2][4][8 * GPROW];   // per wavefront: g_pooled of its 8 pool cells x the tile's vertices
 
-    const int blk = blockIdx.x, b = blockIdx.y;
+    int blk, b;
+    if (!xcd_unit(a.nblk, a.B, blk, b)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int p = strip_pixel(blk, wave, l31);
     const bool masked = !(a.mask[(size_t)b * a.P + p] > 0.f);
@@ -487,7 +503,8 @@ __global__ __launch_bounds__(256, FVM_MESH_WAVES) void fvm_backward_mesh_kernel(
     __shared__ __attribute__((aligned(16))) float pt[4][32 * 12];       // per wavefront, per pixel: rmax, 1/rsum, gm0..2, d_r, gx, gy, live, p2
     float (*red)[C * IROW] = it;
 
-    const int tv = blockIdx.x, b = blockIdx.y;
+    int tv, b;
+    if (!xcd_unit(a.ntile, a.B, tv, b)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int v = 32 * tv + l31;
     const bool vok = v < a.V;
@@ -624,7 +641,7 @@ extern "C" int scp_fvm_forward(const float* img_feat, const float* mesh_feat, co
     a.pooled = pooled; a.match = match; a.rowstat = rowstat; a.colpart = static_cast<float*>(workspace);
     a.grid_half = grid_half; a.colpart2 = a.colpart + (size_t)B * a.nblk * V * 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(fvm_forward_kernel, dim3(a.nblk, B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(fvm_forward_kernel, dim3(xcd_grid(a.nblk, B)), dim3(256), 0, st, a);
     if (int e = scp::check_launch("fvm_forward")) return e;
     hipLaunchKernelGGL(fvm_col_merge_kernel, dim3((B * V + 255) / 256), dim3(256), 0, st, a.colpart, B, a.nblk, V, imatch, colstat);
     if (int e = scp::check_launch("fvm_col_merge")) return e;
@@ -649,11 +666,11 @@ extern "C" int scp_fvm_backward(const float* img_feat, const float* mesh_feat, c
     a.g_match = g_match; a.g_imatch = g_imatch; a.g_pooled = g_pooled; a.g_img = g_img_feat; a.g_mesh = g_mesh_feat;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (g_img_feat) {
-        hipLaunchKernelGGL(fvm_backward_img_kernel, dim3(a.nblk, B), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(fvm_backward_img_kernel, dim3(xcd_grid(a.nblk, B)), dim3(256), 0, st, a);
         if (int e = scp::check_launch("fvm_backward_img")) return e;
     }
     if (g_mesh_feat) {
-        hipLaunchKernelGGL(fvm_backward_mesh_kernel, dim3(a.ntile, B), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(fvm_backward_mesh_kernel, dim3(xcd_grid(a.ntile, B)), dim3(256), 0, st, a);
         if (int e = scp::check_launch("fvm_backward_mesh")) return e;
     }
     return 0;

@@ -1,6 +1,6 @@
 """tests/stall_diag.py -- what is the device doing when a GPU test stops making progress?
 
-A watchdog thread per test (armed by tests/conftest.py on GPU boxes): a test still running after SCP_STALL_AFTER seconds (default 150, below
+A watchdog thread per test (armed by tests/conftest.py on GPU boxes): a test still running after SCP_STALL_AFTER seconds (default 75, below
 pytest.ini's timeout) gets a report on stderr and in gpurun_out/stall_<test>.txt BEFORE pytest-timeout ends the run:
   * the Python stack of every thread (faulthandler);
   * every torch stream / event of the process: busy or idle, and which attribute holds it;
@@ -19,7 +19,7 @@ import sys
 import threading
 import time
 
-AFTER = float(os.environ.get("SCP_STALL_AFTER", "150"))
+AFTER = float(os.environ.get("SCP_STALL_AFTER", "75"))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -93,41 +93,54 @@ def torch_state():
 
 
 def report(what, path=None, gdb=True):
-    """write the report; returns its text"""
+    """write the report section by section (a section that hangs -- rocgdb on a wedged device -- must not cost the ones before it)"""
     pid = os.getpid()
-    parts = ["==== stall_diag: %s still running after %.0f s (pid %d) ====\n" % (what, AFTER, pid)]
-    parts.append("---- KFD (first sample)\n" + kfd_state(pid))
-    try:
-        parts.append("---- torch streams / events\n" + torch_state())
-    except Exception as e:                                      # noqa: BLE001
-        parts.append("torch_state failed: %r\n" % (e,))
-    time.sleep(1.0)
-    parts.append("---- KFD (1 s later)\n" + kfd_state(pid))
-    parts.append("---- children\n" + _sh("ps -o pid,ppid,stat,etime,wchan:24,cmd --ppid %d; ps -L -o tid,stat,wchan:28,comm -p %d | head -60" % (pid, pid)))
-    parts.append("---- rocm-smi\n" + _sh("rocm-smi --showuse --showpids --showmemuse 2>&1 | tail -30", 60))
-    parts.append("---- dmesg\n" + _sh("dmesg 2>&1 | tail -40", 20))
-    if gdb and os.path.exists("/opt/rocm/bin/rocgdb"):
-        cmd = ("/opt/rocm/bin/rocgdb -p %d -batch -ex 'set pagination off' -ex 'info agents' -ex 'info queues' -ex 'info dispatches' "
-               "-ex 'info threads' 2>&1 | grep -v '^\\[New\\|^warning: \\|Thread debugging\\|^Reading symbols\\|No such file' | head -260" % pid)
-        parts.append("---- rocgdb\n" + _sh(cmd, 300))
-    text = "".join(parts)
     out = sys.__stderr__
-    print("\n" + text, file=out)
-    print("---- python stacks", file=out)
-    out.flush()
-    faulthandler.dump_traceback(file=out, all_threads=True)
-    out.flush()
+    fh = None
     if path:
         try:
             os.makedirs(os.path.dirname(path), exist_ok=True)
-            with open(path, "w") as f:
-                f.write(text)
-                f.write("---- python stacks\n")
-                f.flush()
-                faulthandler.dump_traceback(file=f, all_threads=True)
+            fh = open(path, "w")
         except Exception as e:                                  # noqa: BLE001
-            print("stall_diag: could not write %s: %r" % (path, e), file=out)
-    return text
+            print("stall_diag: could not open %s: %r" % (path, e), file=out)
+
+    def emit(text):
+        for f in (out, fh):
+            if f is not None:
+                try:
+                    f.write(text)
+                    f.flush()
+                    os.fsync(f.fileno())
+                except Exception:                               # noqa: BLE001
+                    pass
+
+    emit("\n==== stall_diag: %s still running after %.0f s (pid %d) ====\n" % (what, AFTER, pid))
+    emit("---- python stacks\n")
+    for f in (out, fh):
+        if f is not None:
+            faulthandler.dump_traceback(file=f, all_threads=True)
+            f.flush()
+    emit("---- KFD (first sample)\n" + kfd_state(pid))
+    try:
+        emit("---- torch streams / events\n" + torch_state())
+    except Exception as e:                                      # noqa: BLE001
+        emit("torch_state failed: %r\n" % (e,))
+    time.sleep(1.0)
+    emit("---- KFD (1 s later)\n" + kfd_state(pid))
+    emit("---- children\n" + _sh("ps -o pid,ppid,stat,etime,wchan:24,cmd --ppid %d; ps -L -o tid,stat,wchan:28,comm -p %d | head -60" % (pid, pid)))
+    emit("---- rocm-smi\n" + _sh("rocm-smi --showuse --showpids --showmemuse 2>&1 | tail -30", 60))
+    emit("---- dmesg\n" + _sh("dmesg 2>&1 | tail -40", 20))
+    emit("---- debugfs (best effort)\n" + _sh("mountpoint -q /sys/kernel/debug || mount -t debugfs none /sys/kernel/debug 2>&1; "
+                                              "for f in /sys/kernel/debug/kfd/hqds /sys/kernel/debug/kfd/rls /sys/kernel/debug/dri/*/amdgpu_fence_info; do "
+                                              "echo \"== $f\"; head -c 6000 $f 2>&1; done", 30))
+    if gdb and os.path.exists("/opt/rocm/bin/rocgdb"):
+        cmd = ("timeout -s KILL 80 /opt/rocm/bin/rocgdb -p %d -batch -ex 'set pagination off' -ex 'info agents' -ex 'info queues' -ex 'info dispatches' "
+               "-ex 'info threads' 2>&1 | grep -v '^\\[New\\|^warning: \\|Thread debugging\\|^Reading symbols\\|No such file' | head -260" % pid)
+        emit("---- rocgdb\n")
+        emit(_sh(cmd, 90))
+    emit("==== stall_diag: end of report\n")
+    if fh is not None:
+        fh.close()
 
 
 class Watch:
