@@ -249,9 +249,10 @@ def gemm_peak_tf():
     return BF16_MFMA_PEAK_TF / 6.0 if dino_mod.GEMM_MODE == "split" else FP32_VALU_PEAK_TF
 
 
-def build_trainer(device, world, batch_size=8, repeat=4, seed=0, mixed_bf16=None, high_res=False):
+def build_trainer(device, world, batch_size=8, repeat=4, seed=0, mixed_bf16=None, high_res=False, category=None):
     """high_res: BASELINE configs[4] geometry -- 512 x 512 images, corr_h = corr_w = 128 (the only consistent choice), ViT
-    sequence 4097, icosphere-4 mesh (2562 v / 5120 f)"""
+    sequence 4097, icosphere-4 mesh (2562 v / 5120 f).  category: one of the five Wild6D presets (config/<cat>_wild6d/base_config.txt as
+    restated in scp_amd.flags) with ITS shape prior (scp_amd.mesh.category_prior: 482 .. 995 vertices) instead of the synthetic mesh"""
     if mixed_bf16 is None:      # tools/*.py reuse this builder; SCP_MIXED_BF16=1 switches them to configs[4] precision
         mixed_bf16 = os.environ.get("SCP_MIXED_BF16", "0") == "1"
     import scp_amd.dino as dino
@@ -260,10 +261,15 @@ def build_trainer(device, world, batch_size=8, repeat=4, seed=0, mixed_bf16=None
     from scp_amd.trainer import Trainer
     dino.ALLOW_RANDOM_INIT = True
     extra = dict(img_size=512, corr_h=128, corr_w=128) if high_res else {}
-    opts = Options("laptop_wild6d", batch_size=batch_size, repeat=repeat, train=True, ngpu=world, vis_freq=10 ** 9,
+    opts = Options((category or "laptop") + "_wild6d", batch_size=batch_size, repeat=repeat, train=True, ngpu=world, vis_freq=10 ** 9,
                    mixed_bf16=mixed_bf16, **extra)
     torch.manual_seed(seed)
-    return Trainer(opts, prior=synthetic.bottle_like(4 if high_res else 3), device=device), opts
+    if category:
+        from scp_amd.mesh import category_prior
+        prior = category_prior(category)
+    else:
+        prior = synthetic.bottle_like(4 if high_res else 3)
+    return Trainer(opts, prior=prior, device=device), opts
 
 
 def pin_rng_consumers(model, seed=99):
@@ -633,6 +639,9 @@ def main():
                     help="BASELINE configs[4] geometry: 512x512 images, 2562-vertex / 5120-face mesh, B = --hr-batch x 4 (with --mixed-bf16: "
                          "its precision too); NOT the headline")
     ap.add_argument("--hr-batch", type=int, default=2, help="batch_size (videos) of the --high-res workload; repeat stays 4")
+    ap.add_argument("--category", choices=["bottle", "bowl", "camera", "laptop", "mug"], default=None,
+                    help="BASELINE configs[4] 'all 5 categories': this category's flag preset and shape prior (482-995 vertices) instead "
+                         "of the laptop flags on the synthetic 642-vertex mesh; NOT the headline (tools/r06/categories.sh loops over them)")
     ap.add_argument("--workload", choices=["train", "posefit"], default="train",
                     help="train = BASELINE.json's metric (default); posefit = the test-time pose-fitting path (SURVEY 8f #4)")
     args = ap.parse_args()
@@ -660,8 +669,9 @@ def main():
 
     from scp_amd import synthetic as synth
     from scp_amd.soft_renderer.cuda import soft_rasterize as native
-    tr, opts = build_trainer(device, world, batch_size=args.hr_batch if args.high_res else 8, mixed_bf16=args.mixed_bf16, high_res=args.high_res)
-    if args.high_res:
+    tr, opts = build_trainer(device, world, batch_size=args.hr_batch if args.high_res else 8, mixed_bf16=args.mixed_bf16, high_res=args.high_res,
+                             category=args.category)
+    if args.high_res or args.category:
         args.no_cpu_baseline = True          # the CPU leg and the parity leg are the headline workload's
     data = synth.make_batch(opts.batch_size, opts.repeat, opts.img_size, seed=100 + rank, device=device)
     n_faces, n_verts = tr.model.mesh.num_faces, tr.model.mesh.num_verts
@@ -974,7 +984,8 @@ def main():
         elif others:
             roofline = dict(next(iter(others.values())), others=others)
         out = {
-            "metric": ("train iters/sec (batch=%d, 512x512, 5120-face/2562-vert mesh; configs[4], not the headline)" % B) if args.high_res
+            "metric": ("train iters/sec (batch=%d, %dx%d, %d-face/%d-vert mesh%s; configs[4], not the headline)" % (
+                B, S, S, n_faces, n_verts, ", %s_wild6d preset + prior" % args.category if args.category else "")) if (args.high_res or args.category)
             else "train iters/sec (batch=32, 256x256, 1280-face/642-vert mesh)",
             "value": world * args.steps / elapsed, "unit": "iters/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
@@ -982,8 +993,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "gradients": grads_ok,
             "dtype": "bf16 convolutions + ViT linears, f32 elsewhere (configs[4] precision; not the headline)" if args.mixed_bf16 else "f32",
             "data": "synthetic",
-            "config": {"workload": ("configs[4] geometry: B=%d (batch_size %d x repeat 4) 512x512 per GPU, 2562v/5120f mesh, laptop_wild6d flags, "
-                                    "full training step (fwd+bwd+clip+AdamW)" % (B, args.hr_batch)) if args.high_res else
+            "config": {"workload": ("configs[4] %s: B=%d (batch_size %d x repeat 4) %dx%d per GPU, %dv/%df mesh, %s_wild6d flags, "
+                                    "full training step (fwd+bwd+clip+AdamW)" % (
+                                        "geometry" if args.high_res else "category at the headline geometry", B, opts.batch_size, S, S, n_verts,
+                                        n_faces, args.category or "laptop")) if (args.high_res or args.category) else
                                    "configs[2]: B=32 (batch_size 8 x repeat 4) 256x256 per GPU, 642v/1280f mesh, "
                                    "laptop_wild6d flags, full training step (fwd+bwd+clip+AdamW)",
                        "images_per_sec": world * args.steps * B / elapsed, "parallelism": "dp%d" % world,

@@ -33,6 +33,9 @@
 // division residuals, never a contraction of the reference's arithmetic.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "scp_hip.h"
 #include "scp_common.h"
 
@@ -643,6 +646,234 @@ __global__ __launch_bounds__(THREADS) void raster_forward_kernel(const RasterArg
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward on a per-wavefront PAIR QUEUE (round 6; softmax rgb + vertex textures: every forward pass of the training step).
+//
+// raster_forward_kernel above runs the whole pair arithmetic under the divergence of its face loop: a face that covers 36 of a
+// wavefront's 64 pixels costs the full ~270 instructions with 28 lanes idle (measured: lane use 56 %, profiles/r04_pmc_softras.txt).
+// Only a small part of that arithmetic is order dependent.  Split it:
+//   scan      (lane = pixel)  bbox + early-out test of every staged face, survivors appended IN (face, pixel) ORDER to a u16 ring,
+//                             the face's hit mask and ring position kept per face;
+//   coverage  (lane = PAIR)   as soon as 64 pairs are queued: barycentrics, distance, sigmoid, clipped weights, depth, normalised
+//                             depth, interpolated colours -- ~200 of the ~270 instructions, at full lane use -- into a result ring;
+//   apply     (lane = pixel)  the group's faces in order: a pixel reads ITS record of the face (position = the face's base + rank of
+//                             the lane in the hit mask) and performs the order-dependent state update (alpha product in double, online
+//                             softmax with rescale, z-test of the fused hard-colour output) exactly as forward_pair does.
+// Same expressions, same order per pixel => the images are bit-identical to raster_forward_kernel's (tests/test_softras_gpu.py compares
+// the two; SCP_RASTER_FWD=legacy selects the old kernel).  Everything the two phases exchange stays inside one wavefront: no barrier
+// besides the two per staged batch that the old kernel has as well.
+// ------------------------------------------------------------------------------------------------
+constexpr int FQCAP = 128;                        // queue / result ring entries per wavefront (outstanding <= 63 + 64)
+constexpr unsigned FP_COVER = 1u, FP_SOFT = 2u, FP_HARD = 4u;
+// result record (dwords): 0 flags, 1 frag, 2 normalised depth, 3-5 colour; dual: 6 depth, 7-9 hard colour, 10 face index, 11 unused
+template <bool DUAL> struct FwdRec { static constexpr int N = DUAL ? 12 : 6; };
+
+template <bool FAST, bool DUAL>
+__device__ __forceinline__ void forward_cover(const RasterArgs& a, const float* rec, float xp, float yp, float* out) {
+    float v[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = rec[R_V + k];
+    Cover cv;
+    unsigned flags = 0u;
+    float frag = 0.f, zn = 0.f, zp = 0.f, col[3] = {0.f, 0.f, 0.f}, hard[3] = {0.f, 0.f, 0.f};
+    if (pair_coverage<FAST>(a, cv, v, rec, xp, yp)) {
+        flags = FP_COVER;
+        frag = cv.frag;
+        float wc[3] = {cv.w[0], cv.w[1], cv.w[2]};
+        clip_weights(wc);
+        zp = pair_depth<FAST>(wc, v, rec);
+        if (!(zp < a.near_ || zp > a.far_)) {
+            const bool front = front_facing(v) || a.double_side;
+            if (DUAL && front && weights_inside(cv.w)) {
+                flags |= FP_HARD;
+                const float* tex = rec + R_TEX2;
+#pragma unroll
+                for (int k = 0; k < 3; k++) hard[k] = wc[0] * tex[k] + wc[1] * tex[3 + k] + wc[2] * tex[6 + k];
+            }
+            if (front) {
+                flags |= FP_SOFT;
+                zn = xdiv<FAST>(a.far_ - zp, a.range, a.rcp_range);
+                const float* tex = rec + R_TEX;
+#pragma unroll
+                for (int k = 0; k < 3; k++) col[k] = wc[0] * tex[k] + wc[1] * tex[3 + k] + wc[2] * tex[6 + k];
+            }
+        }
+    }
+    out[0] = __uint_as_float(flags);
+    out[1] = frag;
+    out[2] = zn;
+    out[3] = col[0]; out[4] = col[1]; out[5] = col[2];
+    if (DUAL) {
+        out[6] = zp;
+        out[7] = hard[0]; out[8] = hard[1]; out[9] = hard[2];
+        out[10] = __uint_as_float(reinterpret_cast<const unsigned*>(rec)[R_IDX]);
+    }
+}
+
+// the order-dependent half of forward_pair (kernel.cu:405-453), from a result record
+template <bool FAST, bool DUAL>
+__device__ __forceinline__ void forward_apply(const RasterArgs& a, PixelState& st, HardState& hs, const float* r) {
+    const unsigned flags = __float_as_uint(r[0]);
+    if (!(flags & FP_COVER)) return;
+    const float frag = r[1];
+    if (a.alpha_mode == SCP_ALPHA_PROD) st.col[3] = (float)((double)st.col[3] * (1. - (double)frag));
+    else if (a.alpha_mode == SCP_ALPHA_SUM) st.col[3] += frag;
+    else if (frag > 0.5) st.col[3] = 1.f;
+    if (DUAL && (flags & FP_HARD)) {
+        const float zp = r[6];
+        if (zp < hs.zmin) {
+            hs.zmin = zp;
+            hs.fmin = (int)__float_as_uint(r[10]);
+            hs.col[0] = r[7]; hs.col[1] = r[8]; hs.col[2] = r[9];
+        }
+    }
+    if (flags & FP_SOFT) {
+        const float zn = r[2];
+        float rescale = 1.f;
+        if (zn > st.sm_max) {
+            rescale = expf(xdiv<FAST>(st.sm_max - zn, a.gamma, a.rcp_gamma));
+            st.sm_max = zn;
+        }
+        const float ez = expf(xdiv<FAST>(zn - st.sm_max, a.gamma, a.rcp_gamma));
+        st.sm_sum = rescale * st.sm_sum + ez * frag;
+#pragma unroll
+        for (int k = 0; k < 3; k++) st.col[k] = rescale * st.col[k] + ez * frag * r[3 + k];
+    }
+}
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool DUAL>
+__global__ __launch_bounds__(THREADS) void raster_forward_pq_kernel(const RasterArgs a) {
+    constexpr int NREC = FwdRec<DUAL>::N;
+    __shared__ __attribute__((aligned(16))) float stage[NB * REC];
+    __shared__ __attribute__((aligned(16))) float ring[4 * FQCAP * NREC];
+    __shared__ float4 bbox[NB];
+    __shared__ unsigned list[LIST_CAP];
+    __shared__ unsigned long long hitmask[4 * NB];
+    __shared__ int hitbase[4 * NB];
+    __shared__ float2 pixxy[THREADS];
+    __shared__ unsigned short queue[4 * FQCAP];
+    __shared__ int wave_cnt[4];
+
+    const int tile_id = logical_tile(a);
+    if (tile_id >= a.total_tiles) return;
+    int tx0, ty0;
+    const Pixel px = pixel_of_thread(a, tile_id, tx0, ty0);
+    const TileRect rect = tile_rect(a, tx0, ty0);
+    const size_t npix = (size_t)a.S * a.S;
+    float* out = a.soft_colors + (size_t)px.bn * 4 * npix + px.pn;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    PixelState st;
+    st.col[0] = st.col[1] = st.col[2] = 1.f;
+    st.col[3] = a.alpha_mode == SCP_ALPHA_PROD ? 1.f : 0.f;
+    st.sm_sum = expf(a.eps / a.gamma);
+    st.sm_max = a.eps;
+    if (px.valid) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) st.col[k] = out[k * npix] * st.sm_sum;
+    }
+    st.zmin = 10000000;
+    st.fmin = -1;
+    HardState hs;
+    hs.col[0] = hs.col[1] = hs.col[2] = 0.f;
+    hs.zmin = 10000000;
+    hs.fmin = -1;
+
+    pixxy[threadIdx.x] = make_float2(px.xp, px.yp);
+    unsigned short* qw = queue + wave * FQCAP;
+    float* rw = ring + wave * FQCAP * NREC;
+    unsigned long long* hm = hitmask + wave * NB;
+    int* hb = hitbase + wave * NB;
+    const float2* pxy = pixxy + wave * 64;
+
+    int n = 0;
+    for (int c = 0; c < a.F; c += THREADS) {
+        n = bin_chunk(a, px.bn, c, rect, list, wave_cnt, n);
+        if (n <= LIST_CAP - THREADS && c + THREADS < a.F) continue;
+        for (int s = 0; s < n; s += NB) {
+            const int cnt = min(NB, n - s);
+            stage_faces<true, DUAL>(a, px.bn, list, s, cnt, stage, bbox);
+            __syncthreads();
+            int head = 0, tail = 0, q = 0;
+            while (true) {
+                // scan: pairs in (face, pixel) order; the face's mask and first ring position stay available for the apply phase
+                while (tail - head < 64 && q < cnt) {
+                    const float4 bb = bbox[q];
+                    bool hit = px.valid && !(px.xp > bb.y || px.xp < bb.x || px.yp > bb.w || px.yp < bb.z);
+                    if (__ballot(hit) != 0ull) hit = hit && !behind_an_edge(stage + q * REC, px.xp, px.yp);
+                    const unsigned long long m = __ballot(hit);
+                    if (lane == 0) { hm[q] = m; hb[q] = tail; }
+                    if (m != 0ull) {
+                        if (hit) qw[(tail + __popcll(m & lt)) & (FQCAP - 1)] = (unsigned short)(lane | (q << 8));
+                        tail += __popcll(m);
+                    }
+                    q++;
+                }
+                if (tail == head) break;
+                const int ng = min(64, tail - head);
+                wave_sync();
+                // coverage: lane = pair
+                if (lane < ng) {
+                    const int pos = (head + lane) & (FQCAP - 1);
+                    const unsigned e = qw[pos];
+                    const float* rec = stage + (e >> 8) * REC;
+                    const float2 xy = pxy[e & 63u];
+                    float* r = rw + pos * NREC;
+                    if (reinterpret_cast<const unsigned*>(rec)[R_SLOW] != 0u || a.const_slow) forward_cover<false, DUAL>(a, rec, xy.x, xy.y, r);
+                    else forward_cover<true, DUAL>(a, rec, xy.x, xy.y, r);
+                }
+                wave_sync();
+                // apply: lane = pixel, the group's faces in order
+                const int qf = __builtin_amdgcn_readfirstlane((int)(qw[head & (FQCAP - 1)] >> 8));
+                const int ql = __builtin_amdgcn_readfirstlane((int)(qw[(head + ng - 1) & (FQCAP - 1)] >> 8));
+                for (int qq = qf; qq <= ql; qq++) {
+                    const unsigned long long m = hm[qq];
+                    if (m == 0ull) continue;
+                    const int pos = hb[qq] + __popcll(m & lt);
+                    if (((m >> lane) & 1ull) && pos >= head && pos < head + ng) {
+                        const float* r = rw + (pos & (FQCAP - 1)) * NREC;
+                        if (a.const_slow) forward_apply<false, DUAL>(a, st, hs, r);
+                        else forward_apply<true, DUAL>(a, st, hs, r);
+                    }
+                }
+                head += ng;
+                wave_sync();
+            }
+            __syncthreads();
+        }
+        n = 0;
+    }
+
+    if (!px.valid) return;
+    float alpha;
+    if (a.alpha_mode == SCP_ALPHA_PROD) alpha = (float)(1. - (double)st.col[3]);
+    else if (a.alpha_mode == SCP_ALPHA_SUM) alpha = st.col[3] / a.F;
+    else alpha = st.col[3];
+    out[3 * npix] = alpha;
+    if (DUAL) {
+        float* out2 = a.soft_colors2 + (size_t)px.bn * 4 * npix + px.pn;
+        out2[3 * npix] = alpha;
+        if (hs.fmin != -1) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) out2[k * npix] = hs.col[k];
+        }
+        float* ag2 = a.aggrs_info2 + (size_t)px.bn * 2 * npix + px.pn;
+        ag2[0] = hs.zmin;
+        ag2[npix] = (float)hs.fmin;
+    }
+    float* ag = a.aggrs_info + (size_t)px.bn * 2 * npix + px.pn;
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[k * npix] = st.col[k] / st.sm_sum;
+    ag[0] = st.sm_sum;
+    ag[npix] = st.sm_max;
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward (kernel.cu:486-668)
 // ------------------------------------------------------------------------------------------------
 // Cross-lane reductions with DPP (data-parallel primitives: the cross-lane operand is read through
@@ -1028,6 +1259,12 @@ int dispatch(const RasterArgs& a, int rgb, int sample, hipStream_t st) {
     return scp::check_launch("soft_rasterize");
 }
 
+// SCP_RASTER_FWD=legacy: the per-face forward kernel for the softmax / vertex-texture passes too (A/B and the bit-equality test)
+bool forward_legacy() {
+    const char* e = getenv("SCP_RASTER_FWD");
+    return e != nullptr && strcmp(e, "legacy") == 0;
+}
+
 template <int RGB, int SAMPLE> struct FwdLaunch {
     static void go(dim3 g, dim3 b, hipStream_t st, const RasterArgs& a) {
         hipLaunchKernelGGL((raster_forward_kernel<RGB, SAMPLE>), g, b, 0, st, a);
@@ -1055,6 +1292,10 @@ extern "C" int scp_soft_rasterize_forward(const float* faces, const float* textu
         hipLaunchKernelGGL(face_setup_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, faces, faces_info, nf);
         if (int e = scp::check_launch("face_setup")) return e;
     }
+    if (p->func_id_rgb == SCP_RGB_SOFTMAX && p->texture_sample_type == SCP_SAMPLE_VERTEX && !forward_legacy()) {
+        hipLaunchKernelGGL((raster_forward_pq_kernel<false>), dim3(a.tiles_per_xcd * 8), dim3(THREADS), 0, st, a);
+        return scp::check_launch("soft_rasterize_forward (pair queue)");
+    }
     return dispatch<FwdLaunch>(a, p->func_id_rgb, p->texture_sample_type, st);
 }
 
@@ -1076,8 +1317,11 @@ extern "C" int scp_soft_rasterize_forward_dual(const float* faces, const float* 
         hipLaunchKernelGGL(face_setup_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, faces, faces_info, nf);
         if (int e = scp::check_launch("face_setup")) return e;
     }
-    hipLaunchKernelGGL((raster_forward_kernel<SCP_RGB_SOFTMAX, SCP_SAMPLE_VERTEX, true>), dim3(a.tiles_per_xcd * 8),
-                       dim3(THREADS), 0, st, a);
+    if (forward_legacy())
+        hipLaunchKernelGGL((raster_forward_kernel<SCP_RGB_SOFTMAX, SCP_SAMPLE_VERTEX, true>), dim3(a.tiles_per_xcd * 8),
+                           dim3(THREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL((raster_forward_pq_kernel<true>), dim3(a.tiles_per_xcd * 8), dim3(THREADS), 0, st, a);
     return scp::check_launch("soft_rasterize_forward_dual");
 }
 

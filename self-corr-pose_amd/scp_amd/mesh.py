@@ -89,6 +89,19 @@ def _nearest_index_hip(x, y):
     return idx
 
 
+def category_prior(category):
+    """(verts [V,3] float32, faces [F,3] int32) of a Wild6D category's shape prior -- the data of the reference's
+    config/<category>_wild6d/<category>.obj (bottle 642 v / 1280 f, bowl 482 / 912, camera 974 / 1944, laptop 995 / 1986, mug 884 / 1764),
+    packed by tools/make_priors.py so that the five shipped presets (scp_amd.flags.PRESETS) run on a box without the reference's
+    config directory.  opts.shape_prior_path still wins when it is set."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "wild6d_priors.npz")
+    with np.load(path) as d:
+        if category + "_v" not in d:
+            raise KeyError("no packed prior for category %r (have: %s)" % (category, sorted(k[:-2] for k in d.files if k.endswith("_v"))))
+        return d[category + "_v"].copy(), d[category + "_f"].copy()
+
+
 class CanonicalMesh(nn.Module):
     def __init__(self, opts, prior=None):
         """`prior` = (verts [V,3], faces [F,3]) arrays; if None, opts.shape_prior_path is read"""

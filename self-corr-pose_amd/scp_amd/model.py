@@ -53,6 +53,7 @@ class MeshNet(nn.Module):
         if opts.train and getattr(self, "overlap_dino", streams.overlap()):
             self.pretrain_corr_net.prefetch_features(img, mask)
         img_feat, mesh_feat, pred_v, rotation, translation, scale = self.encoder(img, mean_v, pp_crop, foc_crop)
+        streams.crumb("forward: encoder done")
         # The rotation-cycle branch (a second, independent encoder pass over the rotated images) only
         # needs img / mask / img_feat: it runs on a side HIP stream next to the correspondence + render +
         # loss work of the main stream (many small, latency-bound kernels); autograd replays each
@@ -64,8 +65,10 @@ class MeshNet(nn.Module):
             main = torch.cuda.current_stream(img.device)
             self._cycle_stream.wait_stream(main)
             with torch.cuda.stream(self._cycle_stream):
+                streams.crumb("rotation cycle: start")
                 cycle_side = self.corr_net.compute_rotation_cycle_loss(img, mask, img_feat, self.encoder,
                                                                        angle=self.rotation_angle)[0]
+                streams.crumb("rotation cycle: done")
             for t in (img, mask, img_feat):
                 t.record_stream(self._cycle_stream)
 
@@ -87,7 +90,9 @@ class MeshNet(nn.Module):
             main = torch.cuda.current_stream(img.device)
             self._tex_stream.wait_stream(main)
             with torch.cuda.stream(self._tex_stream):
+                streams.crumb("texture pass: start")
                 texture_loss = wts.tex_wt * self._texture_loss(pred_v, faces, tex, cam, img, mask, occ_arg).mean(0)
+                streams.crumb("texture pass: done")
             for t in (pred_v, faces, tex, foc_crop, pp_crop, rotation, translation, img, mask) + ((occ_arg,) if occ_arg is not None else ()):
                 t.record_stream(self._tex_stream)
         else:
@@ -119,7 +124,9 @@ class MeshNet(nn.Module):
         pullfar_loss = wts.pullfar_wt * F.relu(1 - translation[:, :, -1]).mean()
         deform_loss = wts.deform_wt * F.smooth_l1_loss(pred_v, mean_v, reduction="mean")
 
+        streams.crumb("forward: render + image losses + regularisers done")
         cycle_loss_pt = self.pretrain_corr_net.compute_cycle_loss(img, mask, depth_weight, pointcorr)[0] * wts.cycle_loss_pt_wt
+        streams.crumb("forward: ViT features joined, bridge loss done")
         if cycle_side is not None:
             torch.cuda.current_stream(img.device).wait_stream(self._cycle_stream)
             cycle_loss = cycle_side * wts.cycle_loss_wt

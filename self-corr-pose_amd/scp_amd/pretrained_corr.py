@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import dino, ops
+from . import dino, ops, streams
 from .correspondence import make_meshgrid
 from .dino import DINO
 from .losses import pair_indices
@@ -126,6 +126,7 @@ class PretrainedCorrespondence(nn.Module):
             self._side_stream = torch.cuda.Stream(device=img.device)
         self._side_stream.wait_stream(torch.cuda.current_stream(img.device))
         with torch.cuda.stream(self._side_stream):
+            streams.crumb("ViT prefetch: start")
             if self.use_graphs and mask is not None and self.nn_override is None and self.topk_override is None and not dino.MIXED_BF16:
                 # the whole frozen pass (ViT + matching, ~150 launches) as one HIP-graph replay (scp_amd/graphed.py)
                 if getattr(self, "_vit_graph", None) is None:
@@ -138,6 +139,7 @@ class PretrainedCorrespondence(nn.Module):
                 # the mutual-nearest-neighbour matching of the re-paired batch (fused score GEMM + dual argmax, top-k) needs nothing
                 # but the keys and the masks either: it stays on the side stream instead of the main stream's critical path
                 matched = self._match_pairs(keys, mask) if mask is not None else None
+            streams.crumb("ViT prefetch: done")
         img.record_stream(self._side_stream)
         if mask is not None:
             mask.record_stream(self._side_stream)

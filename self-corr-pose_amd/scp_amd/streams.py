@@ -107,6 +107,51 @@ def wait_bounded(event, what, named_streams=None, timeout=None):
                         busy.append(name)
                 except Exception as e:                      # noqa: BLE001 -- the report must not raise something else
                     busy.append("%s (query failed: %r)" % (name, e))
-            raise DeviceStall("%s: the device did not finish within %.0f s; busy streams: %s" % (what, timeout, ", ".join(busy) or "none"))
+            where = crumb_report(named_streams)
+            raise DeviceStall("%s: the device did not finish within %.0f s; busy streams: %s%s" % (what, timeout, ", ".join(busy) or "none",
+                                                                                                 ("; crumbs: " + where) if where else ""))
         time.sleep(pause)
         pause = min(pause * 1.5, 2e-3)
+
+
+# ---- optional breadcrumbs: where on each stream did the device stop? -----------------------------------------------------------------
+# SCP_CRUMBS=1: Trainer.step / MeshNet.forward / the ViT prefetch record a named event on their stream at every phase boundary; a
+# DeviceStall then lists, per stream, the last crumb the device reached and the first it did not.  Off by default: an event record is a
+# marker packet in the stream's queue, and the uninstrumented step is the product.
+CRUMBS = os.environ.get("SCP_CRUMBS", "0") == "1"
+_crumbs = []
+
+
+def crumb(name, stream=None):
+    if not CRUMBS:
+        return
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    ev = torch.cuda.Event()
+    ev.record(s)
+    _crumbs.append((name, s.cuda_stream, ev))
+    if len(_crumbs) > 6000:
+        del _crumbs[:3000]
+
+
+def crumb_report(named_streams=None):
+    """per stream: 'last reached -> first not reached' over the recorded crumbs (empty string when crumbs are off)"""
+    if not _crumbs:
+        return ""
+    names = {}
+    for k, s in ((named_streams() if callable(named_streams) else (named_streams or {})).items()):
+        if s is not None:
+            names[s.cuda_stream] = k
+    per = {}
+    for name, sid, ev in _crumbs:
+        per.setdefault(sid, []).append((name, ev))
+    out = []
+    for sid, lst in per.items():
+        done = [ev.query() for _, ev in lst]
+        first_pending = next((i for i, d in enumerate(done) if not d), None)
+        if first_pending is None:
+            out.append("%s: all %d crumbs reached (last: %s)" % (names.get(sid, hex(sid)), len(lst), lst[-1][0]))
+        else:
+            out.append("%s: reached %s, NOT reached %s (%d pending)" % (names.get(sid, hex(sid)), lst[first_pending - 1][0] if first_pending else "<nothing>",
+                                                                        lst[first_pending][0], len(lst) - first_pending))
+    return "; ".join(out)

@@ -219,16 +219,21 @@ class Trainer:
             self.model.overlap_dino = self.model.overlap_rotation_cycle = self.model.overlap_texture_pass = False
             next_data = None
         try:
+            streams.crumb("step %d: start" % self.iteration)
             total_loss, aux_output = self.model(data)
+            streams.crumb("step %d: forward done" % self.iteration)
             if next_data is not None:
                 self.model.pretrain_corr_net.prefetch_features(next_data[0], next_data[1])
             total_loss.mean().backward()
+            streams.crumb("step %d: backward done" % self.iteration)
         finally:
             if serial:
                 self.model.overlap_dino, self.model.overlap_rotation_cycle, self.model.overlap_texture_pass = saved
         self._steps_done += 1
         grad = self.collect_grad()
+        streams.crumb("step %d: clip done" % self.iteration)
         self.optim.step(self.iteration)
+        streams.crumb("step %d: optimizer done" % self.iteration)
         self.iteration += 1
         return total_loss, aux_output, grad
 

@@ -22,6 +22,8 @@ ORDER = ["test_softras_gpu", "test_softras_ref_gpu", "test_corr", "test_pretrain
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "child_process: loop-level GPU test (DataLoader workers, whole train / test loops): runs in a process "
+                                       "of its own with a hard timeout, so that whatever it does to the device cannot take the suite with it")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -50,3 +52,32 @@ def pytest_runtest_call(item):
     import stall_diag
     with stall_diag.Watch(item.nodeid):
         yield
+
+
+CHILD_TIMEOUT = float(os.environ.get("SCP_CHILD_TIMEOUT", "170"))
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_pyfunc_call(pyfuncitem):
+    """`child_process` tests: the parent runs `pytest <nodeid>` in a fresh interpreter (its own HIP context, its own DataLoader workers)
+    under a hard limit and reports the child's verdict; a stalled child is killed with its process group, its stall report
+    (tests/stall_diag.py, printed by the child after 75 s) is part of the failure message"""
+    if pyfuncitem.get_closest_marker("child_process") is None or os.environ.get("SCP_TEST_CHILD") == "1":
+        return None
+    import signal
+    import subprocess
+    import torch
+    if not torch.cuda.is_available():
+        return None
+    env = dict(os.environ, SCP_TEST_CHILD="1")
+    cmd = [sys.executable, "-m", "pytest", pyfuncitem.nodeid, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "--timeout=%d" % int(CHILD_TIMEOUT - 10)]
+    proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=CHILD_TIMEOUT)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        out, _ = proc.communicate()
+        pytest.fail("child process of %s exceeded %.0f s and was killed\n%s" % (pyfuncitem.nodeid, CHILD_TIMEOUT, (out or "")[-8000:]), pytrace=False)
+    if proc.returncode != 0:
+        pytest.fail("child process of %s failed (rc %d)\n%s" % (pyfuncitem.nodeid, proc.returncode, (out or "")[-8000:]), pytrace=False)
+    return True

@@ -288,3 +288,76 @@ def test_render_all_fused_equals_unfused():
     r.share_hardtex_with_depth = True
     for a, b in zip(fused, plain):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("pname,size,subdiv,n", [("softtex", 250, 3, 2), ("depth", 96, 2, 3), ("softtex", 256, 3, 32), ("depth", 256, 3, 32),
+                                                  ("softtex", 512, 4, 1)])
+def test_pair_queue_forward_is_bit_identical_to_the_per_face_forward(pname, size, subdiv, n, monkeypatch):
+    """round 6: the softmax / vertex-texture forward passes run on a per-wavefront pair queue (raster_forward_pq_kernel: coverage
+    arithmetic per PAIR at full lane use, the order-dependent per-pixel update applied in face order afterwards).  Same expressions in
+    the same order per pixel: images and aggregates must equal the per-face kernel's (SCP_RASTER_FWD=legacy) BIT FOR BIT -- ragged
+    image sizes, the headline batch, the 5120-face mesh (chunked binning), and an alpha mode / distance mode other than the step's"""
+    from scp_amd.soft_renderer.cuda import soft_rasterize as native
+    v, f = scenes.bottle_like(subdiv)
+    fv, ftex = scenes.raster_inputs(v, f, n, seed=3 * size + subdiv, tex="depth" if pname == "depth" else "rand")
+    kw = dict(image_size=size, dist_func="euclidean", aggr_func_alpha="prod", **PASSES[pname])
+
+    def render(**over):
+        captured = {}
+        orig = native.forward_soft_rasterize
+
+        def spy(*a):
+            out = orig(*a)
+            captured["aggrs_info"] = out[1]
+            return out
+        native.forward_soft_rasterize = spy
+        try:
+            from scp_amd.soft_renderer import functional as srf
+            img = srf.soft_rasterize(torch.tensor(fv, device=DEV), torch.tensor(ftex, device=DEV), **dict(kw, **over))
+        finally:
+            native.forward_soft_rasterize = orig
+        return img.clone(), captured["aggrs_info"].clone()
+
+    variants = [{}] if n > 3 else [{}, dict(aggr_func_alpha="sum"), dict(dist_func="barycentric"), dict(aggr_func_alpha="hard", dist_func="hard")]
+    for over in variants:
+        monkeypatch.setenv("SCP_RASTER_FWD", "legacy")
+        img0, ag0 = render(**over)
+        monkeypatch.delenv("SCP_RASTER_FWD")
+        img1, ag1 = render(**over)
+        as_bits = lambda t: t.view(torch.int32)
+        assert torch.equal(as_bits(img0), as_bits(img1)), (over, float((img0 - img1).abs().max()), int((as_bits(img0) != as_bits(img1)).sum()))
+        assert torch.equal(as_bits(ag0), as_bits(ag1)), (over, int((as_bits(ag0) != as_bits(ag1)).sum()))
+    assert float(img1[:, 3].max()) > 0.5, "the scene must cover something"
+
+
+def test_pair_queue_dual_forward_is_bit_identical_to_the_per_face_forward(monkeypatch):
+    """the fused depth + hard-colour forward (scp_soft_rasterize_forward_dual, the step's sigma = 1e-4 group) on the pair queue vs the
+    per-face kernel: both images and both aggregate buffers bit for bit, at the headline batch and on a ragged size"""
+    import ctypes
+    from scp_amd import capi
+    for size, n in ((256, 32), (250, 2)):
+        v, f = scenes.bottle_like(3)
+        fv, ftex = scenes.raster_inputs(v, f, n, seed=size, tex="depth")
+        _, ftex2 = scenes.raster_inputs(v, f, n, seed=size + 1, tex="canon")
+        fv_t, tex_t, tex2_t = (torch.tensor(x, device=DEV).contiguous() for x in (fv, ftex, ftex2))
+        nf = fv.shape[1]
+        p = capi.RasterParams(batch_size=n, num_faces=nf, image_size=size, texture_size=3, near_=1.0, far_=100.0, eps=1e-3, sigma_val=1e-4,
+                              dist_eps=9.21024036697585, gamma_val=1e-4, func_id_dist=2, func_id_rgb=1, func_id_alpha=2,
+                              texture_sample_type=1, double_side=0)
+
+        def run():
+            info = torch.zeros(n, nf, 27, device=DEV)
+            ag, ag2 = torch.zeros(n, 2, size, size, device=DEV), torch.zeros(n, 2, size, size, device=DEV)
+            img, img2 = torch.ones(n, 4, size, size, device=DEV), torch.zeros(n, 4, size, size, device=DEV)
+            P = lambda t: ctypes.c_void_p(t.data_ptr())
+            capi.check(capi.lib().scp_soft_rasterize_forward_dual(P(fv_t.view(n, nf, 9)), P(tex_t.view(n, nf, 9)), P(info), P(ag), P(img),
+                                                                   P(tex2_t.view(n, nf, 9)), P(ag2), P(img2), ctypes.byref(p), capi.current_stream()),
+                       "forward_dual")
+            return [t.view(torch.int32).clone() for t in (img, ag, img2, ag2)]
+        monkeypatch.setenv("SCP_RASTER_FWD", "legacy")
+        ref = run()
+        monkeypatch.delenv("SCP_RASTER_FWD")
+        got = run()
+        for a, b, name in zip(ref, got, ("soft", "aggrs", "hard", "aggrs_hard")):
+            assert torch.equal(a, b), (size, name, int((a != b).sum()))
+        assert int((got[3][:, 1].view(torch.float32) >= 0).sum()) > 0, "some pixel must have a z-buffer winner"

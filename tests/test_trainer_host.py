@@ -226,3 +226,43 @@ def test_flat_adamw_class_rows_are_stable_and_recycled():
     assert ids4 == {(0, 0): 0, (1, 5): 1}
     with pytest.raises(RuntimeError, match="classes"):
         assign_classes(ids4, [(g, 0) for g in range(5)], 4)
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` with no launcher around it starts N ranks itself (torch.distributed.run on
+    127.0.0.1, a free port, one process per GPU: what scripts/train.sh:5-7 / train.py:29-36 do) and passes their status through; inside
+    a rank (WORLD_SIZE set) it does not launch again"""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("scp_bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    tail = cmd[cmd.index(os.path.join(root, "bench.py")) + 1:]
+    assert tail == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # a rank of that launch (WORLD_SIZE present) must go on to run, not launch again: without a GPU that is the "needs an MI355X" exit
+    seen.clear()
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "0")
+    if not torch.cuda.is_available():
+        with pytest.raises(SystemExit) as e:
+            bench.main()
+        assert "MI355X" in str(e.value.code) and not seen
