@@ -149,7 +149,7 @@ class KernelClock:
 
 
 INIT_STEPS = 3
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")   # written by tools/traffic_report.py from rocprofv3 PMC passes
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_traffic.json")   # written by tools/traffic_report.py from rocprofv3 PMC passes
 
 
 def measured_traffic(key, size_tag):
@@ -881,7 +881,8 @@ def main():
                            "split operands, N=%d, 6x64, B=%d)" if attn_split else
                            "vit_attention_kernel (fp32 MFMA flash attention, N=%d, 6x64, B=%d)") % (n_tok, B), "bound": "mfma",
                 "achieved": tf, "peak": attn_peak, "unit": "TFLOP/s", "frac": tf / attn_peak, "vs_fp32_mfma_peak": tf / FP32_VALU_PEAK_TF,
-                "traffic": measured_traffic("vit_attention", size_tag), "avg_launch_ms": attn_ms,
+                "traffic": (lambda t: None if t is None else t / 9.0)(measured_traffic("vit_attention", size_tag)),   # 8 full launches + the query-selected one of block 8
+                "traffic_per_step": measured_traffic("vit_attention", size_tag), "avg_launch_ms": attn_ms,
                 "algorithmic_flops_per_launch": flops, "launches_per_step": 8,      # + 1 query-selected launch (block 8), not timed
                 # the live figure is taken while the encoder / render streams share the device; the same kernel alone on
                 # an idle device, for reference (not the roofline claim):
@@ -920,7 +921,11 @@ def main():
                         "arithmetic": ("fp32-accurate: operands represented exactly, dropped partial products < 2^-24 |a b|; error "
                                        "vs float64 not above the fp32 matrix cores' (tests/test_vit_gpu.py); SCP_VIT_GEMM=fp32 "
                                        "selects the fp32 cores" if split else "v_mfma_f32_32x32x2_f32"),
-                        "traffic": measured_traffic("vit_gemm", size_tag), "traffic_source": "profiles/r05_traffic.json (per step)",
+                        # the contract's `traffic` is per launch, like `achieved`: the family's counter bytes of one step / its launches
+                        "traffic": (lambda t: None if t is None else t / per_step)(measured_traffic("vit_gemm", size_tag)),
+                        "traffic_per_step": measured_traffic("vit_gemm", size_tag),
+                        "traffic_source": "profiles/r06_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 "
+                                          "(gfx950) + WRITE, per training step (steps counted from the trace), here / launches per step",
                         "clock": "in-kernel s_memrealtime stamps: first workgroup start to last workgroup end of every full launch "
                                  "of the timed region (= rocprofv3 kernel-trace duration; profiles/r04_kernel_stats_timed_window.csv)",
                         "avg_launch_ms": cms / cn, "algorithmic_flops_per_launch": cfl / cn,

