@@ -99,6 +99,7 @@ def test_loader_feeds_the_trainer_batch_shape(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.child_process
 def test_trainer_train_loop_on_disk_dataset(tmp_path):
     """end to end: synthetic Wild6D directory -> data_loader (PIL decode on workers, HIP crop+resize) -> Trainer.train
     (the loop of model/trainer.py:104-125) -> checkpoint; finite losses, parameters move, checkpoint reloads"""
@@ -145,6 +146,7 @@ def test_test_dataset_order_box_and_ground_truth(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.child_process
 def test_tester_test_loop_on_disk_test_set(tmp_path):
     """end to end: on-disk test set + pkl annotations -> test_loader -> Tester.test() -> pose metric table"""
     import scenes

@@ -201,6 +201,7 @@ def test_early_stop_rewinds_generator(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.child_process
 def test_tester_predict_end_to_end():
     """eval-mode MeshNet forward -> batched pose fitting on the GPU at 256x256 (recipe weights): shapes, finiteness,
     proper rotations, and the fitted similarity reproduces the correspondences it was fitted to"""
