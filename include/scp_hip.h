@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SCP_ABI_VERSION 7
+#define SCP_ABI_VERSION 8
 
 /* enum values = the integer ids the reference passes (functional/soft_rasterize.py:22-25) */
 enum { SCP_DIST_HARD = 0, SCP_DIST_BARYCENTRIC = 1, SCP_DIST_EUCLIDEAN = 2 };
@@ -53,6 +53,13 @@ typedef struct scp_raster_params {
 
 int scp_abi_version(void);
 const char* scp_last_error(void);
+
+/* A HIP stream of the step's own (hipStreamNonBlocking, normal priority), created when the caller asks for it -- not taken from a
+ * framework's pool of long-lived streams whose earlier users the caller knows nothing about (model/trainer.py has one stream; the side
+ * streams of scp_amd.streams are this build's).  *stream receives the hipStream_t; scp_stream_destroy waits for nothing: the caller
+ * synchronises first.  Round 6: DESIGN 5.4. */
+int scp_stream_create(void** stream);
+int scp_stream_destroy(void* stream);
 
 /* Replaces forward_soft_rasterize (cpp:59-91).
  *   faces        [B,F,9]   in   (x_ndc, y_ndc up, z) per corner

@@ -22,3 +22,16 @@ int check_launch(const char* what) {
 
 extern "C" int scp_abi_version(void) { return SCP_ABI_VERSION; }
 extern "C" const char* scp_last_error(void) { return g_err; }
+
+extern "C" int scp_stream_create(void** stream) {
+    if (!stream) return scp::fail(hipErrorInvalidValue, "scp_stream_create: NULL out pointer");
+    hipStream_t s = nullptr;
+    const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) return scp::fail(static_cast<int>(e), "scp_stream_create");
+    *stream = static_cast<void*>(s);
+    return 0;
+}
+extern "C" int scp_stream_destroy(void* stream) {
+    const hipError_t e = hipStreamDestroy(static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : scp::fail(static_cast<int>(e), "scp_stream_destroy");
+}

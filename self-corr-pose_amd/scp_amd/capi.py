@@ -12,7 +12,7 @@ import torch
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # SCP_HIP_LIB: an alternative build of the same library (A/B of kernel variants from tools/); the default is the in-tree build
 LIB_PATH = os.environ.get("SCP_HIP_LIB") or os.path.join(_PKG, "lib", "libscp_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 CONV_PLANES_TILE = 32     # include/scp_hip.h: SCP_CONV_PLANES_TILE
 
 
@@ -66,6 +66,8 @@ _RP = ctypes.POINTER(RasterParams)
 SYMBOLS = {
     "scp_abi_version": (ctypes.c_int, []),
     "scp_last_error": (ctypes.c_char_p, []),
+    "scp_stream_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
+    "scp_stream_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "scp_soft_rasterize_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _RP, _P]),
     "scp_soft_rasterize_backward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _RP, _P]),
     "scp_soft_rasterize_count_pairs": (ctypes.c_int, [_P, _P, _RP, _P]),

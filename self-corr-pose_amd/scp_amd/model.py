@@ -61,7 +61,7 @@ class MeshNet(nn.Module):
         cycle_side = None
         if opts.train and img.is_cuda and getattr(self, "overlap_rotation_cycle", streams.overlap()):
             if getattr(self, "_cycle_stream", None) is None:
-                self._cycle_stream = torch.cuda.Stream(device=img.device)
+                self._cycle_stream = streams.side_stream(img.device)
             main = torch.cuda.current_stream(img.device)
             self._cycle_stream.wait_stream(main)
             with torch.cuda.stream(self._cycle_stream):
@@ -86,7 +86,7 @@ class MeshNet(nn.Module):
         tex_side = opts.train and img.is_cuda and tex is not None and getattr(self, "overlap_texture_pass", streams.overlap())
         if tex_side:
             if getattr(self, "_tex_stream", None) is None:
-                self._tex_stream = torch.cuda.Stream(device=img.device)
+                self._tex_stream = streams.side_stream(img.device)
             main = torch.cuda.current_stream(img.device)
             self._tex_stream.wait_stream(main)
             with torch.cuda.stream(self._tex_stream):

@@ -69,7 +69,7 @@ class FlatGradients:
         # SCP_STREAMS=serial (scp_amd/streams.py): no communication stream and no launches from the gradient hooks -- the buckets go
         # out from finish(), after backward, so that the reduction kernels never share a compute unit with the backward's bf16-MFMA kernels
         self.overlap = dev.type != "cuda" or streams.overlap()
-        self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" and self.active and self.overlap else None
+        self.comm_stream = streams.side_stream(dev) if dev.type == "cuda" and self.active and self.overlap else None
         # hooks at every world size: with one rank they only record which parameters received a gradient (finish() needs that
         # to leave the unused ones at grad = None)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]

@@ -123,7 +123,7 @@ class PretrainedCorrespondence(nn.Module):
         if pre is not None and pre[0] is img:
             return                      # already in flight (e.g. started during the previous step's backward)
         if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream(device=img.device)
+            self._side_stream = streams.side_stream(img.device)
         self._side_stream.wait_stream(torch.cuda.current_stream(img.device))
         with torch.cuda.stream(self._side_stream):
             streams.crumb("ViT prefetch: start")

@@ -155,3 +155,31 @@ def crumb_report(named_streams=None):
             out.append("%s: reached %s, NOT reached %s (%d pending)" % (names.get(sid, hex(sid)), lst[first_pending - 1][0] if first_pending else "<nothing>",
                                                                         lst[first_pending][0], len(lst) - first_pending))
     return "; ".join(out)
+
+
+# ---- the step's own side streams ------------------------------------------------------------------------------------------------------
+# SCP_SIDE_STREAMS=own (default): a side stream is a HIP stream this build creates for the purpose (scp_stream_create), wrapped as a
+# torch.cuda.ExternalStream -- a fresh stream nobody used before.  SCP_SIDE_STREAMS=pool: torch.cuda.Stream(), i.e. the next entry of
+# torch's round-robin pool of 32 long-lived streams per device, whose earlier users (other libraries, earlier phases of the process) and
+# hardware-queue placement the step knows nothing about.  Round 6: with the three side streams of the step on pool entries
+# that had been used before, the step loop stalled on the device -- every stream waiting, no wavefront resident -- in 24 of 30 fresh
+# processes at one pool position and in none at any other; the GPU suite hit that position whenever test_coresidency_gpu.py had run first.
+SIDE_STREAMS = os.environ.get("SCP_SIDE_STREAMS", "own")
+_own_streams = []          # (handle, wrapper): kept for the life of the process -- a stream the autograd graph may still name is never destroyed
+
+
+def side_stream(device):
+    """a stream for one overlapped branch of the step (frozen ViT, rotation-cycle pass, texture pass, gradient all-reduce)"""
+    import torch
+    if SIDE_STREAMS != "own":
+        return torch.cuda.Stream(device=device)
+    import ctypes
+    from . import capi
+    dev = torch.device(device)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(index):
+        capi.check(capi.lib().scp_stream_create(ctypes.byref(handle)), "scp_stream_create")
+    s = torch.cuda.ExternalStream(handle.value, device=torch.device("cuda", index))
+    _own_streams.append((handle.value, s))
+    return s

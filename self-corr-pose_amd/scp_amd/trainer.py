@@ -99,7 +99,9 @@ class Trainer:
         self._trainable = [p for _, p in named]
         # every gradient lives in one flat buffer (p.grad = view); with torch.distributed initialised its buckets are
         # all-reduced from autograd hooks while backward is still running (scp_amd/parallel.py)
-        self.grads = FlatGradients(self._trainable, process_group)
+        # SCP_FORCE_COLLECTIVES=1: the N > 1 code path (gradient hooks, communication stream, bucketed all-reduce inside backward) in a
+        # ONE-rank group -- how the multi-GPU schedule of the step is exercised on a one-GPU box (tools/r06/hang_repro.py, tests)
+        self.grads = FlatGradients(self._trainable, process_group, force_collectives=os.environ.get("SCP_FORCE_COLLECTIVES") == "1")
         if hasattr(self.optim.optimizer, "attach"):
             self.optim.optimizer.attach(self.grads)     # FlatAdamW: one launch over the flat buffer (scp_amd/optimizers.py)
         self.reducer = self.grads if self.grads.world > 1 else None
