@@ -430,8 +430,8 @@ def test_step_loop_does_not_stall_on_used_pool_streams():
     B = 6 loop with look-ahead, in a process where 35 streams of torch's round-robin pool had been USED before the Trainer took its three
     side streams from that pool, stalled on the device (every stream waiting, no wavefront resident) in 24 of 30 fresh processes -- and
     in none at any other pool position (profiles/r06_stall_rates_call4.txt, _call5.txt).  The step's side streams are now HIP streams of
-    its own (scp_amd.streams.side_stream): five fresh processes in that exact situation must all run through.  The old arrangement
-    (SCP_SIDE_STREAMS=pool) runs twice as a control and is REPORTED, not asserted: it stalls on most boxes, which is the point."""
+    its own (scp_amd.streams.side_stream): four fresh processes in that exact situation must all run through.  The old arrangement
+    (SCP_SIDE_STREAMS=pool) runs once as a control and is REPORTED, not asserted: it stalls on most boxes, which is the point."""
     import os
     import subprocess
     import sys
@@ -443,7 +443,7 @@ def test_step_loop_does_not_stall_on_used_pool_streams():
         r = subprocess.run([sys.executable, script, "35", "steps"], env=e, capture_output=True, text=True, timeout=150)
         lines = [l for l in r.stdout.splitlines() if l.startswith(("OK", "HANG"))]
         return lines[-1] if lines else "?? rc=%d %s" % (r.returncode, (r.stdout + r.stderr)[-400:])
-    got = [trial(SCP_SIDE_STREAMS="own") for _ in range(5)]
+    got = [trial(SCP_SIDE_STREAMS="own") for _ in range(4)]
     assert all(g.startswith("OK") for g in got), got
-    control = [trial(SCP_SIDE_STREAMS="pool") for _ in range(2)]
-    print("control (pool streams at position 35): %d of 2 stalled" % sum(c.startswith("HANG") for c in control))
+    control = [trial(SCP_SIDE_STREAMS="pool") for _ in range(1)]
+    print("control (pool streams at position 35): %d of 1 stalled" % sum(c.startswith("HANG") for c in control))
