@@ -168,41 +168,6 @@ SIDE_STREAMS = os.environ.get("SCP_SIDE_STREAMS", "own")
 _own_streams = []          # (handle, wrapper): kept for the life of the process -- a stream the autograd graph may still name is never destroyed
 
 
-RESERVE = int(os.environ.get("SCP_RESERVE_STREAM_SLOTS", "6"))
-_reserved = {}             # device index -> the parked streams
-
-
-def reserve_low_stream_slots(device):
-    """Park RESERVE (6) used-once HIP streams per device before the step creates its own.
-
-    What round 6 measured (profiles/r06_stall_rates_call4.txt .. _call7.txt, ~500 fresh processes of tools/r06/hang_repro.py): the step
-    loop stalls on the device -- every stream waiting, no wavefront resident, CPU-side waits (ROC_CPU_WAIT_FOR_SIGNAL=1) block the host
-    instead -- exactly when two of its concurrently active streams are the FIFTH and the SIXTH stream the process ever enqueued work on
-    (HIP instantiates a stream's queue object at its first enqueue).  torch pool entries (3,4,5) after 35 or after 3 used streams, entries
-    (4,5,6) after 36, own streams after 3 used streams: 60-90 % of the processes stall; one position earlier or later, pool or own, 4 or 16
-    hardware queues, with the main loop on the null stream or on a pool stream: 0 of 8-10 each.  The cause sits below this code (HIP
-    runtime / ROCr, torch 2.10.0+rocm7.0, HIP 7.0.51831); what the step can do is never hold those two positions: after this call every
-    stream it creates is at least the seventh.  Idempotent; the parked streams are never destroyed (a freed slot could be handed out
-    again)."""
-    import torch
-    dev = torch.device(device)
-    if dev.type != "cuda" or RESERVE <= 0:
-        return
-    index = dev.index if dev.index is not None else torch.cuda.current_device()
-    if index in _reserved:
-        return
-    parked = []
-    _reserved[index] = parked
-    for _ in range(RESERVE):
-        s = _new_own_stream(index)
-        with torch.cuda.stream(s):
-            torch.zeros(1, device=torch.device("cuda", index))      # the first enqueue: the stream now holds its slot
-        parked.append(s)
-    torch.cuda.current_stream(index).synchronize()
-    for s in parked:
-        s.synchronize()
-
-
 def _new_own_stream(index):
     import ctypes
     import torch
@@ -218,7 +183,6 @@ def _new_own_stream(index):
 def side_stream(device):
     """a stream for one overlapped branch of the step (frozen ViT, rotation-cycle pass, texture pass, gradient all-reduce)"""
     import torch
-    reserve_low_stream_slots(device)
     if SIDE_STREAMS != "own":
         return torch.cuda.Stream(device=device)
     dev = torch.device(device)

@@ -66,9 +66,6 @@ class Trainer:
             if self.device.index is not None:
                 torch.cuda.set_device(self.device)
             enable_gemm_tuning()
-            # before anything of the trainer (communication stream, RCCL's own streams at the first collective, the side streams of
-            # the first overlapped step) creates a stream: scp_amd/streams.py reserve_low_stream_slots, DESIGN 5.4
-            streams.reserve_low_stream_slots(self.device)
         # the rotation-cycle branch runs on a side stream (model.py); its parameters' AccumulateGrad nodes
         # then see gradients from two streams, which autograd synchronises correctly but warns about
         if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
