@@ -83,7 +83,7 @@ class MeshNet(nn.Module):
         # GPU they run on a second side stream.  Both chains are rasteriser launches (VALU-bound, far from filling the device)
         # strung together by small latency-bound kernels, forward and -- autograd replays nodes on their forward stream --
         # backward; side by side they shorten the step's serial middle part.
-        tex_side = opts.train and img.is_cuda and tex is not None and getattr(self, "overlap_texture_pass", streams.overlap())
+        tex_side = opts.train and img.is_cuda and tex is not None and getattr(self, "overlap_texture_pass", streams.overlap_texture())
         if tex_side:
             if getattr(self, "_tex_stream", None) is None:
                 self._tex_stream = streams.side_stream(img.device)

@@ -81,6 +81,19 @@ def overlap():
     return MODE == "overlap"
 
 
+def overlap_texture():
+    """the soft-texture render pass + its loss on a THIRD side stream?  Off by default since round 6 (SCP_TEXTURE_STREAM=1 switches it on).
+    With three side streams (frozen ViT, rotation-cycle pass, texture pass) the step loop has stream placements at which the device stops
+    -- every stream waiting on an event, no wavefront resident; with ROC_CPU_WAIT_FOR_SIGNAL=1 the host blocks instead -- in 60-100 % of
+    fresh processes: torch pool entries (3,4,5) / (4,5,6) after other users of the pool, the step's own streams as the 5th-7th or 8th-10th
+    stream of the process, with 4 or 16 hardware queues alike (profiles/r06_stall_rates_call4..8.txt, ~600 processes of
+    tools/r06/hang_repro.py; this is what hung round 5's GPU suite).  With the texture pass on the main stream -- two side streams -- 0 of
+    98 processes stalled over 14 placements, pool and own streams (profiles/r06_stall_rates_call10.txt); the cause sits below this code
+    (torch 2.10.0+rocm7.0 / HIP 7.0.51831) and is not understood, so the default is the schedule that has no known stalling placement.
+    Cost: DESIGN 5.4."""
+    return overlap() and os.environ.get("SCP_TEXTURE_STREAM", "0") == "1"
+
+
 class DeviceStall(RuntimeError):
     """the device did not finish work the host is waiting for within the bound (see wait_bounded)"""
 

@@ -217,7 +217,8 @@ class Trainer:
         # are cached per process; a perturbed search can settle on slower solvers for the whole run).
         serial = (self._steps_done == 0 or not streams.overlap()) and self.device.type == "cuda"
         if serial:
-            saved = tuple(getattr(self.model, k, streams.overlap()) for k in ("overlap_dino", "overlap_rotation_cycle", "overlap_texture_pass"))
+            saved = tuple(getattr(self.model, k, d) for k, d in (("overlap_dino", streams.overlap()), ("overlap_rotation_cycle", streams.overlap()),
+                                                                 ("overlap_texture_pass", streams.overlap_texture())))
             self.model.overlap_dino = self.model.overlap_rotation_cycle = self.model.overlap_texture_pass = False
             next_data = None
         try:

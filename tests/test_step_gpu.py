@@ -425,25 +425,30 @@ def test_training_reduces_the_loss_on_a_fixed_batch():
     assert last < 0.9 * first, (first, last, losses[::5])
 
 
-def test_step_loop_does_not_stall_on_used_pool_streams():
-    """Round 5's GPU suite hung in Trainer.train.  Round 6 reproduced it without pytest or DataLoader: eight steps of the
-    B = 6 loop with look-ahead, in a process where 35 streams of torch's round-robin pool had been USED before the Trainer took its three
-    side streams from that pool, stalled on the device (every stream waiting, no wavefront resident) in 24 of 30 fresh processes -- and
-    in none at any other pool position (profiles/r06_stall_rates_call4.txt, _call5.txt).  The step's side streams are now HIP streams of
-    its own (scp_amd.streams.side_stream): four fresh processes in that exact situation must all run through.  The old arrangement
-    (SCP_SIDE_STREAMS=pool) runs once as a control and is REPORTED, not asserted: it stalls on most boxes, which is the point."""
+def test_step_loop_does_not_stall_at_the_known_bad_stream_placements():
+    """Round 5's GPU suite hung in Trainer.train.  Round 6 reproduced it without pytest or DataLoader
+    (tools/r06/hang_repro.py, one trial per fresh process): eight steps of the B = 6 loop with look-ahead stop on the device -- every stream
+    waiting, no wavefront resident -- in 60-100 % of the processes when the step runs THREE side streams and those sit at certain
+    placements (torch pool entries (3,4,5) after 35 or 3 other used streams; own streams after 3), and in 0 of 98 processes over 14
+    placements with the texture pass on the main stream (profiles/r06_stall_rates_call4..10.txt).  The default schedule (two side
+    streams of the step's own) must run through at the placements that stalled, with and without the multi-GPU schedule's communication
+    stream (one-rank RCCL group); the three-stream schedule on pool streams runs once as a control and is REPORTED, not asserted (it
+    stalls on most boxes, which is the point)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = os.path.join(root, "tools", "r06", "hang_repro.py")
 
-    def trial(**env):
+    def trial(pre, **env):
         e = dict(os.environ, SCP_DEVICE_TIMEOUT_S="10", SCP_REPRO_ITERS="8", **env)
-        r = subprocess.run([sys.executable, script, "35", "steps"], env=e, capture_output=True, text=True, timeout=150)
+        for k in ("SCP_TEXTURE_STREAM", "SCP_SIDE_STREAMS", "SCP_FORCE_COLLECTIVES"):
+            if k not in env:
+                e.pop(k, None)
+        r = subprocess.run([sys.executable, script, str(pre), "steps"], env=e, capture_output=True, text=True, timeout=150)
         lines = [l for l in r.stdout.splitlines() if l.startswith(("OK", "HANG"))]
         return lines[-1] if lines else "?? rc=%d %s" % (r.returncode, (r.stdout + r.stderr)[-400:])
-    got = [trial(SCP_SIDE_STREAMS="own") for _ in range(4)]
+    got = [trial(35), trial(3), trial(0), trial(35, SCP_FORCE_COLLECTIVES="1")]
     assert all(g.startswith("OK") for g in got), got
-    control = [trial(SCP_SIDE_STREAMS="pool") for _ in range(1)]
-    print("control (pool streams at position 35): %d of 1 stalled" % sum(c.startswith("HANG") for c in control))
+    control = trial(35, SCP_TEXTURE_STREAM="1", SCP_SIDE_STREAMS="pool")
+    print("control (three side streams on pool entries 3,4,5): %s" % control[:4])
