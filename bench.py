@@ -833,8 +833,8 @@ def main():
             if fwd_raster_ms:
                 # forward of the same pass: faces + textures in, faces_info + aggrs_info + soft_colors out
                 fb = 4.0 * B * (n_faces * (9 + 9 + 27) + S * S * (4 + 2))
-                fr = {"kernel": ("raster_forward_kernel<softmax,vertex>" if os.environ.get("SCP_RASTER_FWD") == "legacy" else
-                                 "raster_forward_pq_kernel (per-wavefront pair queue; round 6)") + " (sigma=1e-3 texture pass; + the per-face setup kernel of the same call)",
+                fr = {"kernel": ("raster_forward_pq_kernel (per-wavefront pair queue, opt-in)" if os.environ.get("SCP_RASTER_FWD") == "pq" else
+                                 "raster_forward_kernel<softmax,vertex>") + " (sigma=1e-3 texture pass; + the per-face setup kernel of the same call)",
                       "bound": "hbm", "achieved": fb / (fwd_raster_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": fb / (fwd_raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic("raster_forward_softtex", size_tag),
                       "avg_launch_ms": fwd_raster_ms, "algorithmic_bytes_per_launch": fb,

@@ -646,7 +646,8 @@ __global__ __launch_bounds__(THREADS) void raster_forward_kernel(const RasterArg
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward on a per-wavefront PAIR QUEUE (round 6; softmax rgb + vertex textures: every forward pass of the training step).
+// forward on a per-wavefront PAIR QUEUE (round 6 experiment, opt-in SCP_RASTER_FWD=pq; softmax rgb + vertex textures).  Built on the
+// estimate of DESIGN 5.3 (r5), bit-identical to raster_forward_kernel -- and measured 1.2-1.4x SLOWER than it, see forward_legacy().
 //
 // raster_forward_kernel above runs the whole pair arithmetic under the divergence of its face loop: a face that covers 36 of a
 // wavefront's 64 pixels costs the full ~270 instructions with 28 lanes idle (measured: lane use 56 %, profiles/r04_pmc_softras.txt).
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(THREADS) void raster_forward_kernel(const RasterArg
 //                             the lane in the hit mask) and performs the order-dependent state update (alpha product in double, online
 //                             softmax with rescale, z-test of the fused hard-colour output) exactly as forward_pair does.
 // Same expressions, same order per pixel => the images are bit-identical to raster_forward_kernel's (tests/test_softras_gpu.py compares
-// the two; SCP_RASTER_FWD=legacy selects the old kernel).  Everything the two phases exchange stays inside one wavefront: no barrier
+// the two; SCP_RASTER_FWD=pq selects this kernel).  Everything the two phases exchange stays inside one wavefront: no barrier
 // besides the two per staged batch that the old kernel has as well.
 // ------------------------------------------------------------------------------------------------
 constexpr int FQCAP = 128;                        // queue / result ring entries per wavefront (outstanding <= 63 + 64)
@@ -1259,10 +1260,13 @@ int dispatch(const RasterArgs& a, int rgb, int sample, hipStream_t st) {
     return scp::check_launch("soft_rasterize");
 }
 
-// SCP_RASTER_FWD=legacy: the per-face forward kernel for the softmax / vertex-texture passes too (A/B and the bit-equality test)
+// SCP_RASTER_FWD=pq: the pair-queue forward kernel for the softmax / vertex-texture passes (A/B and the bit-equality test).  NOT the
+// default: measured on the MI355X it is bit-identical to the per-face kernel and SLOWER (sigma = 1e-3 pass 0.95 vs 0.67 ms, sigma = 1e-4
+// pass 0.41 vs 0.35 ms at B = 32, gpurun_out/r06i -> profiles/r06_softras_forward_ab.txt): the LDS round trip of the records and the
+// face-ordered apply loop cost more than the full-lane coverage arithmetic saves.
 bool forward_legacy() {
     const char* e = getenv("SCP_RASTER_FWD");
-    return e != nullptr && strcmp(e, "legacy") == 0;
+    return !(e != nullptr && strcmp(e, "pq") == 0);
 }
 
 template <int RGB, int SAMPLE> struct FwdLaunch {

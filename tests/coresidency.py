@@ -25,16 +25,36 @@ class MfmaLoad:
     """with MfmaLoad(kind): ...   -- `blocks` workgroups looping one matrix instruction on a side stream for the duration of the block.
     kind 0 = v_mfma_f32_32x32x16_bf16 (the aggressor), 1 = v_mfma_f32_32x32x2_f32 (the control that must change nothing)."""
 
+    _hip = None
+
     def __init__(self, kind=0, blocks=512, device="cuda"):
         self.kind, self.blocks = kind, blocks
         self.stream = torch.cuda.Stream(device=device)
-        self.stop = torch.zeros(1, dtype=torch.int32, device=device)
         self.sink = torch.empty(blocks * 256, device=device)
-        self.stopper = torch.cuda.Stream(device=device)
+        # the stop flag lives in COHERENT pinned host memory and is raised by a plain host store: a flag in device memory needs a kernel
+        # on a third stream to raise it, and when that stream shares a hardware queue with the load stream the store waits behind every
+        # queued load launch (round 6: four stage screens took 45 s each that way)
+        if MfmaLoad._hip is None:
+            MfmaLoad._hip = ctypes.CDLL("libamdhip64.so")
+        ptr = ctypes.c_void_p()
+        code = MfmaLoad._hip.hipHostMalloc(ctypes.byref(ptr), ctypes.c_size_t(64), ctypes.c_uint(0x40000000))    # hipHostMallocCoherent
+        if code != 0 or not ptr.value:
+            raise RuntimeError("hipHostMalloc(coherent) failed: %d" % code)
+        self._stop_ptr = ptr.value
+        self._stop = ctypes.c_int.from_address(ptr.value)
+        self._stop.value = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_stop_ptr", None):
+                MfmaLoad._hip.hipHostFree(ctypes.c_void_p(self._stop_ptr))
+                self._stop_ptr = None
+        except Exception:                               # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def __enter__(self):
         main = torch.cuda.current_stream()
-        self.stop.zero_()
+        self._stop.value = 0
         self.stream.wait_stream(main)
         # 2^24 instructions bound one launch to ~0.3 s even if nobody raises the flag; re-armed by keep_alive()
         self._launch()
@@ -42,17 +62,15 @@ class MfmaLoad:
 
     def _launch(self):
         capi.check(capi.lib().scp_selftest_mfma_load(self.kind, ctypes.c_void_p(self.sink.data_ptr()), self.blocks, 1 << 24,
-                                                    ctypes.c_void_p(self.stop.data_ptr()), ctypes.c_void_p(self.stream.cuda_stream)), "mfma_load")
+                                                    ctypes.c_void_p(self._stop_ptr), ctypes.c_void_p(self.stream.cuda_stream)), "mfma_load")
 
     def keep_alive(self):
         """queue another bounded launch behind the running one (call between passes of a long victim)"""
         self._launch()
 
     def __exit__(self, *exc):
-        with torch.cuda.stream(self.stopper):        # raise the flag from a third stream: the main stream may still be busy
-            self.stop.fill_(1)
+        self._stop.value = 1                         # host store into coherent memory: every queued launch leaves at its first poll
         self.stream.synchronize()
-        self.stopper.synchronize()
         torch.cuda.current_stream().wait_stream(self.stream)
         return False
 

@@ -293,9 +293,9 @@ def test_render_all_fused_equals_unfused():
 @pytest.mark.parametrize("pname,size,subdiv,n", [("softtex", 250, 3, 2), ("depth", 96, 2, 3), ("softtex", 256, 3, 32), ("depth", 256, 3, 32),
                                                   ("softtex", 512, 4, 1)])
 def test_pair_queue_forward_is_bit_identical_to_the_per_face_forward(pname, size, subdiv, n, monkeypatch):
-    """round 6: the softmax / vertex-texture forward passes run on a per-wavefront pair queue (raster_forward_pq_kernel: coverage
-    arithmetic per PAIR at full lane use, the order-dependent per-pixel update applied in face order afterwards).  Same expressions in
-    the same order per pixel: images and aggregates must equal the per-face kernel's (SCP_RASTER_FWD=legacy) BIT FOR BIT -- ragged
+    """round 6: the pair-queue forward (raster_forward_pq_kernel, opt-in SCP_RASTER_FWD=pq: coverage arithmetic per PAIR at full lane
+    use, the order-dependent per-pixel update applied in face order afterwards; measured slower than the per-face kernel, so not the
+    default).  Same expressions in the same order per pixel: images and aggregates must equal the per-face kernel's BIT FOR BIT -- ragged
     image sizes, the headline batch, the 5120-face mesh (chunked binning), and an alpha mode / distance mode other than the step's"""
     from scp_amd.soft_renderer.cuda import soft_rasterize as native
     v, f = scenes.bottle_like(subdiv)
@@ -320,10 +320,11 @@ def test_pair_queue_forward_is_bit_identical_to_the_per_face_forward(pname, size
 
     variants = [{}] if n > 3 else [{}, dict(aggr_func_alpha="sum"), dict(dist_func="barycentric"), dict(aggr_func_alpha="hard", dist_func="hard")]
     for over in variants:
-        monkeypatch.setenv("SCP_RASTER_FWD", "legacy")
+        monkeypatch.delenv("SCP_RASTER_FWD", raising=False)
         img0, ag0 = render(**over)
-        monkeypatch.delenv("SCP_RASTER_FWD")
+        monkeypatch.setenv("SCP_RASTER_FWD", "pq")
         img1, ag1 = render(**over)
+        monkeypatch.delenv("SCP_RASTER_FWD")
         as_bits = lambda t: t.view(torch.int32)
         assert torch.equal(as_bits(img0), as_bits(img1)), (over, float((img0 - img1).abs().max()), int((as_bits(img0) != as_bits(img1)).sum()))
         assert torch.equal(as_bits(ag0), as_bits(ag1)), (over, int((as_bits(ag0) != as_bits(ag1)).sum()))
@@ -354,10 +355,11 @@ def test_pair_queue_dual_forward_is_bit_identical_to_the_per_face_forward(monkey
                                                                    P(tex2_t.view(n, nf, 9)), P(ag2), P(img2), ctypes.byref(p), capi.current_stream()),
                        "forward_dual")
             return [t.view(torch.int32).clone() for t in (img, ag, img2, ag2)]
-        monkeypatch.setenv("SCP_RASTER_FWD", "legacy")
+        monkeypatch.delenv("SCP_RASTER_FWD", raising=False)
         ref = run()
-        monkeypatch.delenv("SCP_RASTER_FWD")
+        monkeypatch.setenv("SCP_RASTER_FWD", "pq")
         got = run()
+        monkeypatch.delenv("SCP_RASTER_FWD")
         for a, b, name in zip(ref, got, ("soft", "aggrs", "hard", "aggrs_hard")):
             assert torch.equal(a, b), (size, name, int((a != b).sum()))
         assert int((got[3][:, 1].view(torch.float32) >= 0).sum()) > 0, "some pixel must have a z-buffer winner"

@@ -12,7 +12,7 @@ FAMILIES = {"vit_gemm": "vit_gemm_kernel", "vit_attention": "vit_attention_", "v
             "raster_forward": "raster_forward_", "corr_fused": "fvm_", "conv_igemm": "conv_igemm_kernel",
             "conv_wgrad": "conv_wgrad_kernel", "wgrad_fold": "wgrad_fold_kernel", "mutual_nn_fused": "mutual_nn_fused_kernel",
             # round 5: the keys bench.py's roofline.others looks up (per C-ABI call; one call of each per step)
-            "raster_forward_softtex": "raster_forward_pq_kernel<false>", "fvm_forward": "fvm_forward_kernel",
+            "raster_forward_softtex": "raster_forward_kernel<1, 1, false>", "fvm_forward": "fvm_forward_kernel",
             "fvm_backward": "fvm_backward_", "project_vertices": "project_", "gradclip": "gradclip_"}
 
 
