@@ -42,9 +42,9 @@ __global__ __launch_bounds__(256) void mfma_load_kernel(float* out, int iters, c
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc, 0, 0, 0);
             __builtin_amdgcn_s_sleep(7);
         }
-        // a persistent load: leave as soon as the host-side screen raises *stop (device memory or COHERENT host memory; polled every 256 instructions; `iters` bounds the
+        // a persistent load: leave as soon as the host-side screen raises *stop (device memory or COHERENT host memory; polled every 16 384 instructions = ~0.25 ms -- 2 048 wavefronts polling host memory every 256 instructions saturated PCIe and starved every launch of the process, round 6; `iters` bounds the
         // launch whatever happens to the flag, so a failed test cannot leave the device spinning)
-        if (stop != nullptr && (k & 255) == 255 && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+        if (stop != nullptr && (k & 16383) == 16383 && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
     }
     float s = 0.f;
 #pragma unroll
