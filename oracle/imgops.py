@@ -76,3 +76,43 @@ def normalize_oracle(img, mean, std):
     m = np.asarray(mean, F32).reshape(1, -1, 1, 1)
     s = np.asarray(std, F32).reshape(1, -1, 1, 1)
     return ((img - m) / s).astype(F32)
+
+
+# ---- torchvision 0.11 `rotate` on tensors (the reference's rotation-cycle augmentation: model/module/correspondence.py:82-89 calls
+# torchvision.transforms.functional.rotate(img, angle) with the default NEAREST for masks / grids and BILINEAR for images) -------------
+# Published algorithm restated (torchvision/transforms/functional.py `rotate` -> `_get_inverse_affine_matrix(center=[0,0], -angle, ...)`,
+# functional_tensor.py `_gen_affine_grid`, `_apply_grid_transform` -> torch.nn.functional.grid_sample(..., padding_mode="zeros",
+# align_corners=False)).  PARITY UNPINNED like the colour ops above: no executed torchvision, no recorded vector.
+def rotate_oracle(img, angle, interpolation="nearest"):
+    """img [N,C,H,W] float32 -> rotated by `angle` degrees counter-clockwise about the image centre, same size, zero fill"""
+    import math
+    img = np.asarray(img, F32)
+    n, c, h, w = img.shape
+    rot = math.radians(-angle)
+    # _get_inverse_affine_matrix with centre 0, no translation / scale / shear: [d, -b, 0, -c, a, 0] of the forward matrix
+    a_, b_, c_, d_ = math.cos(rot), -math.sin(rot), math.sin(rot), math.cos(rot)
+    theta = np.array([[d_, -b_, 0.0], [-c_, a_, 0.0]], F32)
+    # _gen_affine_grid: pixel-centre coordinates, theta^T rescaled by the half sizes, one bmm
+    xs = np.linspace(-w * 0.5 + 0.5, w * 0.5 + 0.5 - 1, w, dtype=F32)
+    ys = np.linspace(-h * 0.5 + 0.5, h * 0.5 + 0.5 - 1, h, dtype=F32)
+    base = np.stack((np.broadcast_to(xs[None, :], (h, w)), np.broadcast_to(ys[:, None], (h, w)), np.ones((h, w), F32)), -1).reshape(-1, 3)
+    rescaled = (theta.T / np.array([0.5 * w, 0.5 * h], F32)).astype(F32)
+    grid = (base @ rescaled).astype(F32).reshape(h, w, 2)
+    # grid_sample, align_corners=False: normalised -> pixel index space
+    ix = ((grid[..., 0] + 1) * w - 1) / 2
+    iy = ((grid[..., 1] + 1) * h - 1) / 2
+    out = np.zeros_like(img)
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+        v = img[:, :, np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)]
+        return np.where(ok[None, None], v, F32(0))
+    if interpolation == "nearest":
+        out = tap(np.rint(iy).astype(np.int64), np.rint(ix).astype(np.int64))       # nearbyint: ties to even, like ATen's kernel
+    else:
+        x0, y0 = np.floor(ix), np.floor(iy)
+        fx, fy = (ix - x0).astype(F32), (iy - y0).astype(F32)
+        x0, y0 = x0.astype(np.int64), y0.astype(np.int64)
+        out = (tap(y0, x0) * ((1 - fx) * (1 - fy)) + tap(y0, x0 + 1) * (fx * (1 - fy)) +
+               tap(y0 + 1, x0) * ((1 - fx) * fy) + tap(y0 + 1, x0 + 1) * (fx * fy))
+    return out.astype(F32), (ix, iy)

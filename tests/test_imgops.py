@@ -79,3 +79,38 @@ def test_fused_jitter_full_size_is_deterministic_and_bounded():
     order, ratio, shift = jit.draw()
     ref = norm(imgops.ColorJitter.apply_ops(img, order, ratio, shift))
     assert (a - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("angle", [17.0, 45.0, 133.7, 271.3, 359.0])
+def test_rotate_at_arbitrary_angles_follows_the_published_torchvision_algorithm(angle):
+    """VERDICT r5 missing #4: the rotation-cycle augmentation at angles that are not multiples of 90 degrees (correspondence.py:82-89 draws
+    U(0, 360)).  torchvision is absent, so the comparator is oracle/imgops.rotate_oracle -- torchvision 0.11's published tensor algorithm
+    (inverse affine matrix, pixel-centre base grid, grid_sample with zero padding) restated in numpy: parity UNPINNED to an executed
+    torchvision, pinned to its formulas.  Bilinear: 2e-5 everywhere.  Nearest (masks, the ground-truth grid): exact wherever the source
+    coordinate is not within 1e-3 of a rounding tie (two float32 evaluation orders of the same affine map may round a tie differently)."""
+    g = torch.Generator().manual_seed(int(angle * 10))
+    img = torch.rand(2, 3, 64, 64, generator=g)
+    mask = (torch.rand(2, 1, 64, 64, generator=g) > 0.5).float()
+    got_b = imgops.rotate(img, angle, "bilinear").numpy()
+    ref_b, _ = oracle_imgops.rotate_oracle(img.numpy(), angle, "bilinear")
+    assert np.abs(got_b - ref_b).max() <= 2e-5
+    got_n = imgops.rotate(mask, angle, "nearest").numpy()
+    ref_n, (ix, iy) = oracle_imgops.rotate_oracle(mask.numpy(), angle, "nearest")
+    tie = (np.abs(ix - np.floor(ix) - 0.5) < 1e-3) | (np.abs(iy - np.floor(iy) - 0.5) < 1e-3)
+    assert np.array_equal(got_n[:, :, ~tie], ref_n[:, :, ~tie])
+    assert tie.mean() < 0.05 and 0.2 < got_n.mean() < 0.6, "the comparison must cover nearly all pixels of a half-filled mask (45 degrees: the diagonals are ties)"
+
+
+@pytest.mark.gpu
+def test_rotate_at_arbitrary_angles_on_the_gpu_equals_the_cpu_path():
+    """the same ATen grid path on the MI355X: bilinear to 2e-6, nearest exact off the ties"""
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(2, 3, 64, 64, generator=g)
+    for angle in (17.0, 133.7, 271.3):
+        cpu = imgops.rotate(img, angle, "bilinear")
+        gpu = imgops.rotate(img.cuda(), angle, "bilinear").cpu()
+        assert float((cpu - gpu).abs().max()) <= 2e-6
+        ref_n, (ix, iy) = oracle_imgops.rotate_oracle(img.numpy(), angle, "nearest")
+        tie = (np.abs(ix - np.floor(ix) - 0.5) < 1e-3) | (np.abs(iy - np.floor(iy) - 0.5) < 1e-3)
+        gpu_n = imgops.rotate(img.cuda(), angle, "nearest").cpu().numpy()
+        assert np.array_equal(gpu_n[:, :, ~tie], ref_n[:, :, ~tie])
