@@ -79,8 +79,8 @@ class MeshNet(nn.Module):
 
         occ_arg = occ if opts.use_occ else None
         cam = (foc_crop, pp_crop, rotation, translation)
-        # The soft-texture pass and its loss share nothing with the mask / depth / canonical-xyz group but their inputs: on the
-        # GPU they run on a second side stream.  Both chains are rasteriser launches (VALU-bound, far from filling the device)
+        # The soft-texture pass and its loss share nothing with the mask / depth / canonical-xyz group but their inputs: with
+        # SCP_TEXTURE_STREAM=1 they run on a side stream of their own (off by default since round 6, streams.overlap_texture()).  Both chains are rasteriser launches (VALU-bound, far from filling the device)
         # strung together by small latency-bound kernels, forward and -- autograd replays nodes on their forward stream --
         # backward; side by side they shorten the step's serial middle part.
         tex_side = opts.train and img.is_cuda and tex is not None and getattr(self, "overlap_texture_pass", streams.overlap_texture())

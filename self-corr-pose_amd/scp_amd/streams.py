@@ -1,8 +1,9 @@
 """scp_amd/streams.py -- which kernels of a training step may share the device.
 
-SCP_STREAMS=overlap (default): the frozen-DINO ViT, the rotation-cycle branch (second encoder pass) and the soft-texture render pass run
-on side HIP streams, Trainer.step() starts the NEXT batch's ViT pass during this step's backward (look-ahead) and the gradient buckets
-are all-reduced from inside backward.  ~6 ms per step faster at B = 32 than one stream (30.0 vs 36.2 ms on one MI355X).
+SCP_STREAMS=overlap (default): the frozen-DINO ViT and the rotation-cycle branch (second encoder pass) run on side HIP streams of the
+step's own (side_stream below), Trainer.step() starts the NEXT batch's ViT pass during this step's backward (look-ahead) and the gradient
+buckets are all-reduced from inside backward.  ~6 ms per step faster at B = 32 than one stream (29.2-30.5 vs 36.2 ms on one MI355X).
+The soft-texture render pass on a THIRD side stream (-0.4 ms) is opt-in, SCP_TEXTURE_STREAM=1: see overlap_texture() for why.
 SCP_STREAMS=serial: one HIP stream; kernels of the step never run side by side.
 
 Why this was `serial` for half a round, and why it no longer has to be.  Round 4 found kernels returning different results
