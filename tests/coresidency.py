@@ -56,26 +56,17 @@ class MfmaLoad:
         main = torch.cuda.current_stream()
         self._stop.value = 0
         self.stream.wait_stream(main)
-        # 2^24 instructions bound one launch to 0.3-1.7 s (alone / sharing the SIMDs) even if nobody raises the flag; re-armed by keep_alive()
-        self._pending = []
-        self._launch()
+        # 2^24 instructions bound one launch to ~0.3 s even if nobody raises the flag; re-armed by keep_alive()
         self._launch()
         return self
 
     def _launch(self):
         capi.check(capi.lib().scp_selftest_mfma_load(self.kind, ctypes.c_void_p(self.sink.data_ptr()), self.blocks, 1 << 24,
                                                     ctypes.c_void_p(self._stop_ptr), ctypes.c_void_p(self.stream.cuda_stream)), "mfma_load")
-        ev = torch.cuda.Event()
-        ev.record(self.stream)
-        self._pending = [e for e in getattr(self, "_pending", []) if not e.query()] + [ev]
 
     def keep_alive(self):
-        """keep TWO bounded launches outstanding (the running one + one behind it), never more: a victim that synchronises device-wide
-        (an allocator hipFree, a blocking copy) waits for every queued load launch to run out its bound -- with one launch queued per four
-        passes regardless of progress, such a victim's screen took 45 s (26 launches x 1.7 s) instead of 1 s (round 6)"""
-        self._pending = [e for e in getattr(self, "_pending", []) if not e.query()]
-        if len(self._pending) < 2:
-            self._launch()
+        """queue another bounded launch behind the running one (call between passes of a long victim)"""
+        self._launch()
 
     def __exit__(self, *exc):
         self._stop.value = 1                         # host store into coherent memory: every queued launch leaves at its first poll
@@ -140,7 +131,8 @@ def screen(victim, passes, kind=0, blocks=512, unloaded=3):
     with load:
         for k in range(passes):
             out = _flat(victim())
-            load.keep_alive()
+            if k % 4 == 3:
+                load.keep_alive()
             if det:
                 ok = _same_bits(out, ref)
                 d = 0.0 if ok else _dev(out, ref)
