@@ -21,7 +21,7 @@ import coresidency as cr
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PASSES = int(os.environ.get("SCP_SCREEN_PASSES", "100"))     # suite default; the recorded table (profiles/r05_coresidency_screen.txt) used 300
+PASSES = int(os.environ.get("SCP_SCREEN_PASSES", "40"))     # suite default; the recorded table (profiles/r05_coresidency_screen.txt) used 300
 
 _CONTROL = {}
 
