@@ -283,6 +283,8 @@ class Trainer:
 
     def named_streams(self):
         """the HIP streams a step enqueues on, by role (for DeviceStall reports)"""
+        if self.device.type != "cuda":
+            return {}
         m = self.model
         out = {"main": torch.cuda.current_stream(self.device),
                "rotation-cycle side stream": getattr(m, "_cycle_stream", None), "texture-pass side stream": getattr(m, "_tex_stream", None),
