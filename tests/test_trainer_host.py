@@ -266,3 +266,39 @@ def test_bench_launches_its_own_ranks(monkeypatch):
         with pytest.raises(SystemExit) as e:
             bench.main()
         assert "MI355X" in str(e.value.code) and not seen
+
+
+def test_wait_bounded_raises_device_stall_naming_the_busy_streams(monkeypatch):
+    """host logic of scp_amd.streams.wait_bounded (the loops' only host<->device waits go through it): returns when the event completes,
+    raises DeviceStall past the bound with the streams that still have work and the breadcrumb summary"""
+    import time
+    from scp_amd import streams
+
+    class FakeEvent:
+        def __init__(self, done_after):
+            self.t0, self.done_after = time.monotonic(), done_after
+
+        def query(self):
+            return time.monotonic() - self.t0 >= self.done_after
+
+    class FakeStream:
+        def __init__(self, idle, handle=0):
+            self.idle, self.cuda_stream = idle, handle
+
+        def query(self):
+            return self.idle
+
+    streams.wait_bounded(FakeEvent(0.02), "quick", {"main": FakeStream(True)}, timeout=5.0)          # completes: no exception
+    named = {"main": FakeStream(False, 1), "frozen-ViT side stream": FakeStream(True, 2), "rotation-cycle side stream": FakeStream(False, 3)}
+    with pytest.raises(streams.DeviceStall) as e:
+        streams.wait_bounded(FakeEvent(1e9), "Trainer.train: losses of iterations 1..2", lambda: named, timeout=0.05)
+    msg = str(e.value)
+    assert "iterations 1..2" in msg and "main" in msg and "rotation-cycle side stream" in msg and "frozen-ViT" not in msg
+    # breadcrumbs: per stream, the last crumb reached and the first not reached
+    monkeypatch.setattr(streams, "_crumbs", [("step 0: start", 1, FakeEvent(0)), ("step 0: forward done", 1, FakeEvent(1e9)),
+                                             ("ViT prefetch: start", 2, FakeEvent(0))])
+    rep = streams.crumb_report(named)
+    assert "main: reached step 0: start, NOT reached step 0: forward done" in rep and "frozen-ViT side stream: all 1 crumbs reached" in rep
+    assert streams.stall_timeout() == 300.0
+    monkeypatch.setenv("SCP_DEVICE_TIMEOUT_S", "12")
+    assert streams.stall_timeout() == 12.0
